@@ -1,0 +1,652 @@
+/*
+ * oracle/letkf_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * CPU restatement in plain C of the reference's LETKF analysis hot path
+ * (see letkf_oracle.h).  The operation order of every routine follows the
+ * cited Fortran so that results agree with the compiled reference
+ * (oracle/_ref) to a few ulp; tests/test_oracle_vs_ref.py pins that.
+ * Citations are file:line under /root/reference.
+ */
+#include "letkf_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define CM(a, ld, i, j) ((a)[(size_t)(i) + (size_t)(ld) * (size_t)(j)])
+
+static inline double dsign(double a, double b) { return (b >= 0.0) ? fabs(a) : -fabs(a); }
+
+/* common/netlib.f:504-523 -- sqrt(a^2+b^2) by the Moler-Morrison iteration */
+double orc_pythag(double a, double b) {
+  double p = fmax(fabs(a), fabs(b));
+  if (p == 0.0) return p;
+  double q = fmin(fabs(a), fabs(b)) / p;
+  double r = q * q;
+  for (;;) {
+    double t = 4.0 + r;
+    if (t == 4.0) break;
+    double s = r / t;
+    double u = 1.0 + 2.0 * s;
+    p = u * p;
+    double su = s / u;
+    r = su * su * r;
+  }
+  return p;
+}
+
+/* common/netlib.f:1023-1186 -- Householder reduction to tridiagonal form with
+ * accumulation of the transformation (Martin, Reinsch, Wilkinson 1968).
+ * 1-based loop variables are kept (shifted at the access) so the control flow
+ * can be checked line by line against the Fortran. */
+void orc_tred2(int nm, int n, const double *a, double *d, double *e, double *z) {
+#define Z(i, j) CM(z, nm, (i)-1, (j)-1)
+#define A(i, j) CM(a, nm, (i)-1, (j)-1)
+#define D(i) d[(i)-1]
+#define E(i) e[(i)-1]
+  int i, j, k, l;
+  double f, g, h, hh, scale;
+
+  for (i = 1; i <= n; ++i) {               /* :1067-1073 */
+    for (j = i; j <= n; ++j) Z(j, i) = A(j, i);
+    D(i) = A(n, i);
+  }
+  if (n > 1) {
+    for (i = n; i >= 2; --i) {             /* :1077 */
+      l = i - 1;
+      h = 0.0;
+      scale = 0.0;
+      int skip = (l < 2);
+      if (!skip) {
+        for (k = 1; k <= l; ++k) scale += fabs(D(k));   /* :1084-1085 */
+        if (scale == 0.0) skip = 1;
+      }
+      if (skip) {                          /* :1088-1096 */
+        E(i) = D(l);
+        for (j = 1; j <= l; ++j) {
+          D(j) = Z(l, j);
+          Z(i, j) = 0.0;
+          Z(j, i) = 0.0;
+        }
+      } else {
+        for (k = 1; k <= l; ++k) {         /* :1098-1101 */
+          D(k) /= scale;
+          h += D(k) * D(k);
+        }
+        f = D(l);
+        g = -dsign(sqrt(h), f);
+        E(i) = scale * g;
+        h -= f * g;
+        D(l) = f - g;
+        for (j = 1; j <= l; ++j) E(j) = 0.0;            /* form a*u :1109 */
+        for (j = 1; j <= l; ++j) {
+          f = D(j);
+          Z(j, i) = f;
+          g = E(j) + Z(j, j) * f;
+          for (k = j + 1; k <= l; ++k) {
+            g += Z(k, j) * D(k);
+            E(k) += Z(k, j) * f;
+          }
+          E(j) = g;
+        }
+        f = 0.0;                            /* form p :1127 */
+        for (j = 1; j <= l; ++j) {
+          E(j) /= h;
+          f += E(j) * D(j);
+        }
+        hh = f / (h + h);
+        for (j = 1; j <= l; ++j) E(j) -= hh * D(j);     /* form q :1136 */
+        for (j = 1; j <= l; ++j) {          /* form reduced a :1139 */
+          f = D(j);
+          g = E(j);
+          for (k = j; k <= l; ++k) Z(k, j) = Z(k, j) - f * E(k) - g * D(k);
+          D(j) = Z(l, j);
+          Z(i, j) = 0.0;
+        }
+      }
+      D(i) = h;                             /* :1150 */
+    }
+    for (i = 2; i <= n; ++i) {              /* accumulation :1153 */
+      l = i - 1;
+      Z(n, l) = Z(l, l);
+      Z(l, l) = 1.0;
+      h = D(i);
+      if (h != 0.0) {
+        for (k = 1; k <= l; ++k) D(k) = Z(k, i) / h;
+        for (j = 1; j <= l; ++j) {
+          g = 0.0;
+          for (k = 1; k <= l; ++k) g += Z(k, i) * Z(k, j);
+          for (k = 1; k <= l; ++k) Z(k, j) -= g * D(k);
+        }
+      }
+      for (k = 1; k <= l; ++k) Z(k, i) = 0.0;
+    }
+  }
+  for (i = 1; i <= n; ++i) {                /* :1178-1181 */
+    D(i) = Z(n, i);
+    Z(n, i) = 0.0;
+  }
+  Z(n, n) = 1.0;
+  E(1) = 0.0;
+#undef A
+}
+
+/* common/netlib.f:718-887 -- implicit-shift QL on the tridiagonal matrix with
+ * accumulation into z; at most 30 iterations per eigenvalue; ascending order. */
+void orc_tql2(int nm, int n, double *d, double *e, double *z, int *ierr) {
+  int i, j, k, l, m, l1, l2;
+  double c, c2, c3 = 0.0, dl1, el1, f, g, h, p, r, s, s2 = 0.0, tst1, tst2;
+
+  *ierr = 0;
+  if (n == 1) return;
+  for (i = 2; i <= n; ++i) E(i - 1) = E(i);
+  f = 0.0;
+  tst1 = 0.0;
+  E(n) = 0.0;
+
+  for (l = 1; l <= n; ++l) {
+    j = 0;
+    h = fabs(D(l)) + fabs(E(l));
+    if (tst1 < h) tst1 = h;
+    for (m = l; m <= n; ++m) {              /* :795-800 */
+      tst2 = tst1 + fabs(E(m));
+      if (tst2 == tst1) break;
+    }
+    if (m != l) {
+      do {
+        if (j == 30) {                      /* :803, :885 */
+          *ierr = l;
+          return;
+        }
+        ++j;
+        l1 = l + 1;
+        l2 = l1 + 1;
+        g = D(l);
+        p = (D(l1) - g) / (2.0 * E(l));
+        r = orc_pythag(p, 1.0);
+        D(l) = E(l) / (p + dsign(r, p));
+        D(l1) = E(l) * (p + dsign(r, p));
+        dl1 = D(l1);
+        h = g - D(l);
+        for (i = l2; i <= n; ++i) D(i) -= h;
+        f += h;
+        p = D(m);                           /* QL transformation :822 */
+        c = 1.0;
+        c2 = c;
+        el1 = E(l1);
+        s = 0.0;
+        for (i = m - 1; i >= l; --i) {
+          c3 = c2;
+          c2 = c;
+          s2 = s;
+          g = c * E(i);
+          h = c * p;
+          r = orc_pythag(p, E(i));
+          E(i + 1) = s * r;
+          s = E(i) / r;
+          c = p / r;
+          p = c * D(i) - s * g;
+          D(i + 1) = h + s * (c * g + s * D(i));
+          for (k = 1; k <= n; ++k) {        /* form vector :843-847 */
+            h = Z(k, i + 1);
+            Z(k, i + 1) = s * Z(k, i) + c * h;
+            Z(k, i) = c * Z(k, i) - s * h;
+          }
+        }
+        p = -s * s2 * c3 * el1 * E(l) / dl1;
+        E(l) = s * p;
+        D(l) = c * p;
+        tst2 = tst1 + fabs(E(l));
+      } while (tst2 > tst1);
+    }
+    D(l) += f;                              /* :856 */
+  }
+  for (int ii = 2; ii <= n; ++ii) {         /* selection sort :859-880 */
+    i = ii - 1;
+    k = i;
+    p = D(i);
+    for (j = ii; j <= n; ++j) {
+      if (D(j) >= p) continue;
+      k = j;
+      p = D(j);
+    }
+    if (k == i) continue;
+    D(k) = D(i);
+    D(i) = p;
+    for (j = 1; j <= n; ++j) {
+      p = Z(j, i);
+      Z(j, i) = Z(j, k);
+      Z(j, k) = p;
+    }
+  }
+#undef Z
+#undef D
+#undef E
+}
+
+/* common/netlib.f:524-582, matz /= 0 branch */
+void orc_rs(int nm, int n, const double *a, double *w, double *z, double *fv1, int *ierr) {
+  if (n > nm) {
+    *ierr = 10 * n;
+    return;
+  }
+  orc_tred2(nm, n, a, w, fv1, z);
+  orc_tql2(nm, n, w, fv1, z, ierr);
+}
+
+/* common/common_mtx.f90:41-99 */
+int orc_mtx_eigen(int n, const double *a, double *eival, double *eivec, int *nrank_eff) {
+  size_t nn = (size_t)n * (size_t)n;
+  double *eivec8 = (double *)calloc(nn, sizeof(double));
+  double *eival8 = (double *)malloc(sizeof(double) * (size_t)n);
+  double *wrk1 = (double *)malloc(sizeof(double) * (size_t)n);
+  int ierr = 0, rc = 0;
+
+  orc_rs(n, n, a, eival8, eivec8, wrk1, &ierr);    /* :58-60 (a8 = a is read-only here) */
+  if (ierr != 0) {                                   /* :61-64 */
+    rc = 2;
+    goto done;
+  }
+  int nr = n;
+  if (eival8[n - 1] > 0) {                           /* :67-74 */
+    for (int i = 0; i < n; ++i) {
+      if (eival8[i] < fabs(eival8[n - 1]) * sqrt(DBL_EPSILON)) {
+        --nr;
+        eival8[i] = 0.0;
+        for (int r = 0; r < n; ++r) CM(eivec8, n, r, i) = 0.0;
+      }
+    }
+  } else {                                           /* :75-78 */
+    rc = 2;
+    goto done;
+  }
+  if (nr < n && eival8[0] != 0) {                    /* :80-91, incl. the eivec/eivec8 slip at :85 */
+    int j = 0;
+    for (int i = n; i >= 1; --i) {
+      if (eival8[i - 1] == 0) {
+        int src = n - nr - j; /* 1-based */
+        eival8[i - 1] = eival8[src - 1];
+        for (int r = 0; r < n; ++r) CM(eivec, n, r, i - 1) = CM(eivec8, n, r, src - 1);
+        eival8[src - 1] = 0.0;
+        for (int r = 0; r < n; ++r) CM(eivec8, n, r, src - 1) = 0.0;
+        ++j;
+      }
+    }
+  }
+  for (int i = 0; i < n; ++i) {                      /* :93-96 descending */
+    eival[i] = eival8[n - 1 - i];
+    for (int r = 0; r < n; ++r) CM(eivec, n, r, i) = CM(eivec8, n, r, n - 1 - i);
+  }
+  if (nrank_eff) *nrank_eff = nr;
+done:
+  free(eivec8);
+  free(eival8);
+  free(wrk1);
+  return rc;
+}
+
+/* common/netlibblas.f:491-506 ('T','N'), alpha=1 beta=0 */
+static void gemm_tn(int m, int n, int k, const double *a, int lda, const double *b, int ldb,
+                    double *c, int ldc) {
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < m; ++i) {
+      double temp = 0.0;
+      for (int l = 0; l < k; ++l) temp += CM(a, lda, l, i) * CM(b, ldb, l, j);
+      CM(c, ldc, i, j) = temp;
+    }
+}
+
+/* common/netlibblas.f:510-530 ('N','T'), alpha=1 beta=0 */
+static void gemm_nt(int m, int n, int k, const double *a, int lda, const double *b, int ldb,
+                    double *c, int ldc) {
+  for (int j = 0; j < n; ++j) {
+    for (int i = 0; i < m; ++i) CM(c, ldc, i, j) = 0.0;
+    for (int l = 0; l < k; ++l) {
+      double temp = CM(b, ldb, j, l);
+      if (temp != 0.0)
+        for (int i = 0; i < m; ++i) CM(c, ldc, i, j) += temp * CM(a, lda, i, l);
+    }
+  }
+}
+
+/* common/common_letkf.f90:52-257 */
+int orc_letkf_core(int ne, int nobs, int nobsl, const double *hdxb, const double *rdiag,
+                   const double *rloc, const double *dep, double *parm_infl, double *trans,
+                   double *transm, double *pao, const int *rdiag_wloc, const int *infl_update,
+                   const double *depd, double *transmd) {
+  const double sigma_b = 0.04;                       /* :79 */
+  int wloc = rdiag_wloc ? (*rdiag_wloc != 0) : 0;    /* :84-87 */
+  int iupd = infl_update ? (*infl_update != 0) : 0;
+  size_t kk = (size_t)ne * (size_t)ne;
+
+  if (nobsl == 0) {                                  /* :89-107 */
+    memset(trans, 0, sizeof(double) * kk);
+    for (int i = 0; i < ne; ++i) CM(trans, ne, i, i) = sqrt(*parm_infl);
+    if (transm) memset(transm, 0, sizeof(double) * (size_t)ne);
+    if (transmd) memset(transmd, 0, sizeof(double) * (size_t)ne);
+    if (pao) {
+      memset(pao, 0, sizeof(double) * kk);
+      for (int i = 0; i < ne; ++i) CM(pao, ne, i, i) = *parm_infl / (double)(ne - 1);
+    }
+    return 0;
+  }
+
+  double *hdxb_rinv = (double *)malloc(sizeof(double) * (size_t)nobsl * (size_t)ne);
+  double *hsub = (double *)malloc(sizeof(double) * (size_t)nobsl * (size_t)ne);
+  double *eivec = (double *)malloc(sizeof(double) * kk);
+  double *eival = (double *)malloc(sizeof(double) * (size_t)ne);
+  double *pa = (double *)malloc(sizeof(double) * kk);
+  double *work1 = (double *)malloc(sizeof(double) * kk);
+  double *work2 = (double *)malloc(sizeof(double) * (size_t)ne * (size_t)nobsl);
+  double *work3 = (double *)malloc(sizeof(double) * (size_t)ne);
+  int rc = 0;
+
+  for (int j = 0; j < ne; ++j)                       /* :111-123 */
+    for (int i = 0; i < nobsl; ++i) {
+      double v = CM(hdxb, nobs, i, j) / rdiag[i];
+      if (!wloc) v = v * rloc[i];
+      CM(hdxb_rinv, nobsl, i, j) = v;
+      CM(hsub, nobsl, i, j) = CM(hdxb, nobs, i, j);  /* hdxb(1:nobsl,:) copy-in, :127 */
+    }
+  gemm_tn(ne, ne, nobsl, hdxb_rinv, nobsl, hsub, nobsl, work1, ne);   /* :127-128 */
+  double rho = 1.0 / *parm_infl;                     /* :140-143 */
+  for (int i = 0; i < ne; ++i) CM(work1, ne, i, i) += (double)(ne - 1) * rho;
+  int nrank;
+  rc = orc_mtx_eigen(ne, work1, eival, eivec, &nrank);     /* :147 */
+  if (rc != 0) goto done;
+  for (int j = 0; j < ne; ++j)                       /* :151-157 */
+    for (int i = 0; i < ne; ++i) CM(work1, ne, i, j) = CM(eivec, ne, i, j) / eival[j];
+  gemm_nt(ne, ne, ne, work1, ne, eivec, ne, pa, ne);
+  gemm_nt(ne, nobsl, ne, pa, ne, hdxb_rinv, nobsl, work2, ne);         /* :169-170 */
+  for (int i = 0; i < ne; ++i) {                     /* :182-187 */
+    double t = CM(work2, ne, i, 0) * dep[0];
+    for (int j = 1; j < nobsl; ++j) t += CM(work2, ne, i, j) * dep[j];
+    work3[i] = t;
+  }
+  if (depd && transmd) {                             /* :188-195 */
+    for (int i = 0; i < ne; ++i) {
+      double t = CM(work2, ne, i, 0) * depd[0];
+      for (int j = 1; j < nobsl; ++j) t += CM(work2, ne, i, j) * depd[j];
+      transmd[i] = t;
+    }
+  }
+  for (int j = 0; j < ne; ++j) {                     /* :199-206 */
+    double r = sqrt((double)(ne - 1) / eival[j]);
+    for (int i = 0; i < ne; ++i) CM(work1, ne, i, j) = CM(eivec, ne, i, j) * r;
+  }
+  gemm_nt(ne, ne, ne, work1, ne, eivec, ne, trans, ne);
+  if (transm) {                                      /* :218-226 */
+    memcpy(transm, work3, sizeof(double) * (size_t)ne);
+  } else {
+    for (int j = 0; j < ne; ++j)
+      for (int i = 0; i < ne; ++i) CM(trans, ne, i, j) += work3[i];
+  }
+  if (pao) memcpy(pao, pa, sizeof(double) * kk);     /* :227 */
+
+  if (iupd) {                                        /* :233-254 */
+    double parm[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < nobsl; ++i) {
+      double t = dep[i] * dep[i] / rdiag[i];
+      if (!wloc) t = t * rloc[i];
+      parm[0] += t;
+    }
+    for (int j = 0; j < ne; ++j)
+      for (int i = 0; i < nobsl; ++i) parm[1] += CM(hdxb_rinv, nobsl, i, j) * CM(hdxb, nobs, i, j);
+    parm[1] = parm[1] / (double)(ne - 1);
+    for (int i = 0; i < nobsl; ++i) parm[2] += rloc[i];
+    parm[3] = (parm[0] - parm[2]) / parm[1] - *parm_infl;
+    double t = (*parm_infl * parm[1] + parm[2]) / parm[1];
+    double sigma_o = 2.0 / parm[2] * (t * t);
+    double gain = sigma_b * sigma_b / (sigma_o + sigma_b * sigma_b);
+    *parm_infl = *parm_infl + gain * parm[3];
+  }
+done:
+  free(hdxb_rinv);
+  free(hsub);
+  free(eivec);
+  free(eival);
+  free(pa);
+  free(work1);
+  free(work2);
+  free(work3);
+  return rc;
+}
+
+/* scale/letkf/letkf_tools.f90:1911-1948 */
+double orc_relax_beta(const orc_beta_params *bp, double ri, double rj, double rz) {
+  double beta = 1.0;
+  if (bp->radar_only && rz > bp->radar_zmax + bp->vert_local_radar * ORC_DIST_ZERO_FAC) return 0.0;
+  if (bp->boundary_buffer_width > 0.0) {
+    double di = fmin(ri - bp->ihalo, bp->nlong + bp->ihalo + 1 - ri) * bp->dx;
+    double dj = fmin(rj - bp->jhalo, bp->nlatg + bp->jhalo + 1 - rj) * bp->dy;
+    double dist_bdy = fmin(di, dj) / bp->boundary_buffer_width;
+    if (dist_bdy < 1.0) beta = fmax(dist_bdy, 0.0);
+  }
+  return beta;
+}
+
+/* scale/letkf/letkf_tools.f90:1953-1966 */
+void orc_weight_rtpp(int k, double relax_alpha, const double *w, double infl, double *wrlx) {
+  for (size_t i = 0; i < (size_t)k * (size_t)k; ++i) wrlx[i] = (1.0 - relax_alpha) * w[i];
+  for (int m = 0; m < k; ++m) CM(wrlx, k, m, m) += relax_alpha * sqrt(infl);
+}
+
+/* scale/letkf/letkf_tools.f90:1971-2002 */
+void orc_weight_rtps(int k, double relax_alpha_spread, const double *w, const double *pa,
+                     const double *xb, double infl, double *wrlx, double *infl_out) {
+  double var_g = 0.0, var_a = 0.0;
+  for (int m = 0; m < k; ++m) {
+    var_g += xb[m] * xb[m];
+    for (int kk = 0; kk < k; ++kk) var_a += xb[kk] * CM(pa, k, kk, m) * xb[m];
+  }
+  size_t n2 = (size_t)k * (size_t)k;
+  if (var_g > 0.0 && var_a > 0.0) {
+    *infl_out = relax_alpha_spread * sqrt(var_g * infl / (var_a * (double)(k - 1))) -
+                relax_alpha_spread + 1.0;
+    for (size_t i = 0; i < n2; ++i) wrlx[i] = w[i] * (*infl_out);
+  } else {
+    for (size_t i = 0; i < n2; ++i) wrlx[i] = w[i];
+    *infl_out = 1.0;
+  }
+}
+
+/* scale/letkf/letkf_tools.f90:1793-1906 */
+double orc_obs_local_cal(double ri, double rj, double rlev, double rz, double varloc,
+                         int vmode, double hori_loc, double vert_loc, double rain_base,
+                         double ob_ri, double ob_rj, double ob_lev, double ob_dat, double ob_err,
+                         double dx, double dy, double *ndist, double *nrdiag) {
+  double nrloc = 0.0, nd_v, nd_h;
+  *nrdiag = -1.0;
+  *ndist = -1.0;
+  nrloc = varloc;                                    /* :1840 (nvar > 0) */
+  if (nrloc < DBL_MIN) return 0.0;                   /* :1843 tiny(var_local) */
+  if (vert_loc == 0.0) nd_v = 0.0;                   /* :1851-1865 */
+  else if (vmode == 2) nd_v = fabs(log(ob_dat) - log(rlev)) / vert_loc;
+  else if (vmode == 3) nd_v = fabs(log(rain_base) - log(rlev)) / vert_loc;
+  else if (vmode == 1) nd_v = fabs(ob_lev - rz) / vert_loc;
+  else nd_v = fabs(log(ob_lev) - log(rlev)) / vert_loc;
+  if (nd_v > ORC_DIST_ZERO_FAC) return 0.0;          /* :1869 */
+  double rdx = (ri - ob_ri) * dx;                    /* :1876-1878 */
+  double rdy = (rj - ob_rj) * dy;
+  nd_h = sqrt(rdx * rdx + rdy * rdy) / hori_loc;
+  if (nd_h > ORC_DIST_ZERO_FAC) return 0.0;          /* :1881 */
+  *ndist = nd_h * nd_h + nd_v * nd_v;                /* :1888 */
+  if (*ndist > ORC_DIST_ZERO_FAC_SQUARE) {           /* :1891 */
+    *ndist = -1.0;
+    return 0.0;
+  }
+  nrloc = nrloc * exp(-0.5 * (*ndist));              /* :1899 */
+  *nrdiag = ob_err * ob_err / nrloc;                 /* :1903 */
+  return nrloc;
+}
+
+/* scale/common/common_scale.f90:1513-1552 */
+void orc_ensmean(int k, int nv, int64_t npts, double *x, int64_t sp, int64_t sm, int64_t sv) {
+#pragma omp parallel for schedule(static)
+  for (int64_t pt = 0; pt < npts; ++pt)
+    for (int v = 0; v < nv; ++v) {
+      double *b = x + pt * sp + v * sv;
+      double s = b[0];
+      for (int m = 1; m < k; ++m) s += b[m * sm];
+      b[k * sm] = s / (double)k;
+    }
+}
+
+/* scale/letkf/letkf_tools.f90:209-230 */
+void orc_to_perturbations(int k, int nv, int64_t npts, double *x, int64_t sp, int64_t sm, int64_t sv) {
+#pragma omp parallel for schedule(static)
+  for (int64_t pt = 0; pt < npts; ++pt)
+    for (int v = 0; v < nv; ++v) {
+      double *b = x + pt * sp + v * sv;
+      double mean = b[k * sm];
+      for (int m = 0; m < k; ++m) b[m * sm] -= mean;
+    }
+}
+
+/* scale/letkf/letkf_tools.f90:313-527: one (ij, ilev) point, single
+ * variable-localisation class (the namelist default), nv2d = 0. */
+static int das_point(const orc_das_params *p, int64_t pt, int nobsl, const int32_t *idx,
+                     const double *rdiag, const double *rloc, const double *ensval, int64_t kld,
+                     const double *dep, double beta, double *infl, int64_t npts,
+                     const double *gues, double *anal, int64_t sp, int64_t sm, int64_t sv,
+                     double *trans_o, double *transm_o, double *pa_o,
+                     double *hdxf, double *rd, double *rl, double *dp, double *dpd,
+                     double *trans, double *transm, double *transmd, double *pa, double *wrlx) {
+  const int k = p->k, nv = p->nv;
+  const double *g0 = gues + pt * sp;
+  double *a0 = anal + pt * sp;
+  int rc = 0;
+
+  if (beta == 0.0) {                                 /* :333-359 */
+    for (int v = 0; v < nv; ++v) {
+      for (int m = 0; m < k; ++m) a0[m * sm + v * sv] = g0[k * sm + v * sv] + g0[m * sm + v * sv];
+      if (p->det_run) a0[(k + 1) * sm + v * sv] = g0[(k + 1) * sm + v * sv];
+    }
+    return 0;
+  }
+  int done = 0;
+  for (int v = 0; v < nv; ++v) {                     /* :366 */
+    double *infl_v = infl + pt + npts * v;
+    if (p->q_update_top > 0.0 && g0[k * sm + p->iv_p * sv] < p->q_update_top && v >= p->iv_q_first &&
+        v <= p->iv_q_last) {                         /* :371-385 */
+      for (int m = 0; m < k; ++m) a0[m * sm + v * sv] = g0[k * sm + v * sv] + g0[m * sm + v * sv];
+      if (p->det_run) a0[(k + 1) * sm + v * sv] = g0[(k + 1) * sm + v * sv];
+      continue;
+    }
+    double parm = p->relax_to_inflated_prior ? *infl_v : 1.0;   /* :387-391, read BEFORE the update */
+    if (done) {                                      /* :394-406 */
+      if (p->infl_adaptive) *infl_v = infl[pt + npts * (size_t)(done - 1)];
+    } else {                                         /* :409-439 */
+      for (int i = 0; i < nobsl; ++i) {              /* the obs_local copy-out :1463-1469 */
+        const double *row = ensval + (int64_t)idx[i] * kld;
+        for (int m = 0; m < k; ++m) CM(hdxf, nobsl > 0 ? nobsl : 1, i, m) = row[m];
+        rd[i] = rdiag[i];
+        rl[i] = rloc[i];
+        dp[i] = dep[idx[i]];
+        if (p->det_run) dpd[i] = row[k];            /* ensval(mmdetobs,iob) */
+      }
+      int one = 1, iu = p->infl_adaptive;
+      rc = orc_letkf_core(k, nobsl > 0 ? nobsl : 1, nobsl, hdxf, rd, rl, dp, infl_v, trans, transm,
+                          (p->relax_alpha_spread != 0.0) ? pa : NULL, &one, &iu,
+                          p->det_run ? dpd : NULL, p->det_run ? transmd : NULL);
+      if (rc != 0) return rc;
+      done = v + 1;
+      if (trans_o) memcpy(trans_o, trans, sizeof(double) * (size_t)k * (size_t)k);
+      if (transm_o) memcpy(transm_o, transm, sizeof(double) * (size_t)k);
+      if (pa_o && p->relax_alpha_spread != 0.0) memcpy(pa_o, pa, sizeof(double) * (size_t)k * (size_t)k);
+    }
+    if (p->relax_alpha != 0.0) {                     /* :457-469 */
+      orc_weight_rtpp(k, p->relax_alpha, trans, parm, wrlx);
+    } else if (p->relax_alpha_spread != 0.0) {
+      double xb[k], tmpinfl;
+      for (int m = 0; m < k; ++m) xb[m] = g0[m * sm + v * sv];
+      orc_weight_rtps(k, p->relax_alpha_spread, trans, pa, xb, parm, wrlx, &tmpinfl);
+    } else {
+      memcpy(wrlx, trans, sizeof(double) * (size_t)k * (size_t)k);
+    }
+    for (int m = 0; m < k; ++m) {                    /* :472-477 */
+      for (int kk = 0; kk < k; ++kk) CM(wrlx, k, kk, m) = (CM(wrlx, k, kk, m) + transm[kk]) * beta;
+      CM(wrlx, k, m, m) += (1.0 - beta);
+    }
+    for (int m = 0; m < k; ++m) {                    /* :480-486 */
+      double t = g0[k * sm + v * sv];
+      for (int kk = 0; kk < k; ++kk) t = t + g0[kk * sm + v * sv] * CM(wrlx, k, kk, m);
+      a0[m * sm + v * sv] = t;
+    }
+    if (p->det_run) {                                /* :489-497 */
+      double t = 0.0;
+      for (int kk = 0; kk < k; ++kk) t = t + g0[kk * sm + v * sv] * transmd[kk];
+      a0[(k + 1) * sm + v * sv] = g0[(k + 1) * sm + v * sv] + t * beta;
+    }
+    if (p->q_sprd_max > 0.0 && v == p->iv_q_first) { /* :500-513 */
+      double q_mean = 0.0, q_sprd = 0.0, q_anal[k];
+      for (int m = 0; m < k; ++m) q_mean += a0[m * sm + v * sv];
+      q_mean /= (double)k;
+      for (int m = 0; m < k; ++m) {
+        q_anal[m] = a0[m * sm + v * sv] - q_mean;
+        q_sprd += q_anal[m] * q_anal[m];
+      }
+      q_sprd = sqrt(q_sprd / (double)(k - 1)) / q_mean;
+      if (q_sprd > p->q_sprd_max)
+        for (int m = 0; m < k; ++m) a0[m * sm + v * sv] = q_mean + q_anal[m] * p->q_sprd_max / q_sprd;
+    }
+  }
+  return rc;
+}
+
+int orc_das_letkf_points(const orc_das_params *p, int64_t npts, const int64_t *obs_off,
+                         const int32_t *obs_idx, const double *rdiag_l, const double *rloc_l,
+                         const double *ensval, int64_t kld, const double *dep, const double *beta,
+                         double *infl, const double *gues, double *anal, int64_t sp, int64_t sm,
+                         int64_t sv, double *trans_out, double *transm_out, double *pa_out,
+                         int32_t *status) {
+  const int k = p->k;
+  int64_t nmax = 1;
+  for (int64_t pt = 0; pt < npts; ++pt) {
+    int64_t n = obs_off[pt + 1] - obs_off[pt];
+    if (n > nmax) nmax = n;
+  }
+  int worst = 0;
+#ifdef _OPENMP
+  int nth = p->nthreads > 0 ? p->nthreads : omp_get_max_threads();
+#else
+  int nth = 1;
+#endif
+  (void)nth;
+#pragma omp parallel num_threads(nth)
+  {
+    /* per-thread buffers, as letkf_tools.f90:292-302 (sized to the largest
+     * local list here instead of nobstotal) */
+    double *hdxf = (double *)malloc(sizeof(double) * (size_t)nmax * (size_t)k);
+    double *rd = (double *)malloc(sizeof(double) * (size_t)nmax * 4);
+    double *rl = rd + nmax, *dp = rl + nmax, *dpd = dp + nmax;
+    size_t kk = (size_t)k * (size_t)k;
+    double *trans = (double *)malloc(sizeof(double) * (3 * kk + 2 * (size_t)k));
+    double *pa = trans + kk, *wrlx = pa + kk, *transm = wrlx + kk, *transmd = transm + k;
+    /* dynamic schedule with small chunks: letkf_tools.f90:290,319 */
+#pragma omp for schedule(dynamic, 4)
+    for (int64_t pt = 0; pt < npts; ++pt) {
+      int64_t o = obs_off[pt];
+      int nobsl = (int)(obs_off[pt + 1] - o);
+      int rc = das_point(p, pt, nobsl, obs_idx + o, rdiag_l + o, rloc_l + o, ensval, kld, dep,
+                         beta ? beta[pt] : 1.0, infl, npts, gues, anal, sp, sm, sv,
+                         trans_out ? trans_out + (size_t)pt * kk : NULL,
+                         transm_out ? transm_out + (size_t)pt * (size_t)k : NULL,
+                         pa_out ? pa_out + (size_t)pt * kk : NULL, hdxf, rd, rl, dp, dpd, trans,
+                         transm, transmd, pa, wrlx);
+      if (status) status[pt] = rc;
+      if (rc != 0) {
+#pragma omp critical
+        if (rc > worst) worst = rc;
+      }
+    }
+    free(hdxf);
+    free(rd);
+    free(trans);
+  }
+  return worst;
+}
