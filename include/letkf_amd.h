@@ -1,0 +1,186 @@
+/*
+ * letkf_amd.h -- C ABI of the MI355X-native LETKF analysis core (libletkf_amd.so).
+ *
+ * Drop-in boundary for ONE path of gylien/scale-letkf: the per-grid-point
+ * ensemble transform  common/common_letkf.f90::letkf_core  and its driver loop
+ * scale/letkf/letkf_tools.f90::das_letkf (file:line below are relative to the
+ * reference tree).  The reference has no FFI layer; the call boundary is the
+ * Fortran module procedure itself, so every entry point here names the Fortran
+ * interface it replaces.  The Fortran-side binding (ISO_C_BINDING module that
+ * keeps the reference's letkf_core signature) is scale-letkf_amd/fortran/ and
+ * is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  All matrices are
+ * column-major (Fortran), reals are IEEE double (r_size = r_dble,
+ * common/common.f90:18-24), integers 32-bit unless typed otherwise.
+ * "dev" pointers are device (HBM) addresses valid on the context's GPU, "host"
+ * pointers are ordinary host memory.  Caller owns every buffer; the library
+ * keeps no pointer past a call (except the context's own workspace).
+ * Every function returns LETKF_OK (0) or a negative LETKF_E_* host-side error;
+ * per-problem numerical status codes (>0) are written to the status arrays.
+ * There is NO CPU fallback: without a usable gfx950 device every compute entry
+ * fails with LETKF_E_NO_DEVICE.
+ */
+#ifndef LETKF_AMD_H
+#define LETKF_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LETKF_AMD_ABI_VERSION 1
+
+/* host-side errors (function return values) */
+#define LETKF_OK 0
+#define LETKF_E_INVALID (-1)   /* bad argument (NULL, size, unsupported k) */
+#define LETKF_E_HIP (-2)       /* a HIP runtime call failed: see letkf_amd_last_error() */
+#define LETKF_E_NO_DEVICE (-3) /* no gfx950 device / context not bound to one */
+#define LETKF_E_NUMERIC (-4)   /* at least one problem returned a status > 0 (host-pointer entries only) */
+
+/* per-problem status (what the reference turns into WRITE + STOP 2,
+ * common/common_mtx.f90:61-64,75-78; SURVEY.md section 8(b) "Errors") */
+#define LETKF_ST_OK 0
+#define LETKF_ST_NOT_CONVERGED 1 /* eigensolve did not converge (reference: rs ierr /= 0) */
+#define LETKF_ST_NONPOSITIVE 2   /* largest eigenvalue <= 0 (reference: "All Eigenvalues are below 0") */
+#define LETKF_ST_ILLCOND 3       /* lambda_max/lambda_min > 1/sqrt(eps): the reference would zero modes
+                                    (common/common_mtx.f90:66-74) and then divide by zero; here the result
+                                    is still computed without truncation and the point is flagged */
+
+typedef struct letkf_ctx letkf_ctx;
+
+int letkf_amd_abi_version(void);
+const char *letkf_amd_last_error(void);
+
+/* Context = device + stream + reusable device workspace.  device_id < 0: current device. */
+int letkf_ctx_create(int device_id, letkf_ctx **ctx);
+int letkf_ctx_destroy(letkf_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the context's own. */
+int letkf_ctx_set_stream(letkf_ctx *ctx, void *hip_stream);
+int letkf_ctx_synchronize(letkf_ctx *ctx);
+
+/*---------------------------------------------------------------------------
+ * (1) Fine boundary, host pointers, one problem:
+ *     SUBROUTINE letkf_core(ne,nobs,nobsl,hdxb,rdiag,rloc,dep,parm_infl,trans,
+ *                           transm,pao,rdiag_wloc,infl_update,depd,transmd)
+ *     common/common_letkf.f90:52-68.  Absent OPTIONALs are NULL.  hdxb has
+ *     leading dimension nobs, only rows 1..nobsl are read (:35-37).  transmd
+ *     is computed only when depd AND transmd are given (:188); when transm is
+ *     NULL, w-bar is added to every column of trans (:218-226).
+ *     *status receives a LETKF_ST_* code (or a negative LETKF_E_*); NULL allowed.
+ *     Thread-safe (the reference is called from inside an OpenMP region,
+ *     scale/letkf/letkf_tools.f90:289): uses a per-thread context.
+ *-------------------------------------------------------------------------*/
+void letkf_core_c(int ne, int nobs, int nobsl, const double *hdxb, const double *rdiag,
+                  const double *rloc, const double *dep, double *parm_infl, double *trans,
+                  double *transm, double *pao, const int *rdiag_wloc, const int *infl_update,
+                  const double *depd, double *transmd, int *status);
+
+/*---------------------------------------------------------------------------
+ * (1b) Fine boundary, batched, device pointers: nbatch independent letkf_core
+ *      problems of identical (ne, nobs) with per-problem nobsl, laid out back
+ *      to back (problem b at offset b*ne*nobs, b*nobs, b*ne*ne, b*ne).
+ *-------------------------------------------------------------------------*/
+typedef struct {
+  int32_t ne, nobs;
+  int64_t nbatch;
+  const int32_t *nobsl;  /* dev [nbatch] */
+  const double *hdxb;    /* dev [nbatch][ne][nobs] column-major per problem */
+  const double *rdiag;   /* dev [nbatch][nobs] */
+  const double *rloc;    /* dev [nbatch][nobs] */
+  const double *dep;     /* dev [nbatch][nobs] */
+  const double *depd;    /* dev [nbatch][nobs] or NULL */
+  double *parm_infl;     /* dev [nbatch] INOUT */
+  double *trans;         /* dev [nbatch][ne*ne] */
+  double *transm;        /* dev [nbatch][ne] or NULL */
+  double *pao;           /* dev [nbatch][ne*ne] or NULL */
+  double *transmd;       /* dev [nbatch][ne] or NULL */
+  int32_t rdiag_wloc;    /* 0/1 (reference default .false.) */
+  int32_t infl_update;   /* 0/1 */
+  int32_t *status;       /* dev [nbatch] or NULL */
+  int32_t *nsweep;       /* dev [nbatch] or NULL: Jacobi sweeps used (diagnostic) */
+} letkf_core_batch_args;
+int letkf_core_batch_dev(letkf_ctx *ctx, const letkf_core_batch_args *args);
+
+/*---------------------------------------------------------------------------
+ * (2) Coarse boundary: the das_letkf main loop body for a batch of grid points,
+ *     scale/letkf/letkf_tools.f90:313-527 (single variable-localisation class,
+ *     nv2d = 0: the namelist defaults).  For every point:
+ *     local-obs gather by index -> letkf_core -> RTPP/RTPS relaxation (:457-469)
+ *     -> total weight with beta (:472-477) -> analysis of the k members and of
+ *     the deterministic member (:480-497) -> q-spread clamp (:500-513).
+ *
+ *     Observation table = obsda_sort (scale/common/common_obs_scale.f90:112-130):
+ *       ensval[iob*kld + m], m = 0..k-1 member perturbations in obs space
+ *       (member-fastest, as obsda_sort%ensval(1:MEMBER,iob)); slot m = k holds
+ *       the deterministic departure ensval(mmdetobs,iob) when det_run;
+ *       dep[iob] = obsda_sort%val(iob).
+ *     Local lists = what obs_local returns (:1325): for point p the entries
+ *       obs_off[p] .. obs_off[p+1]-1 of obs_idx (0-based rows of the table),
+ *       rdiag_l (= err^2/rloc, :1903) and rloc_l.
+ *     State: gues holds PERTURBATIONS in members 0..k-1, the ensemble mean in
+ *       slot k (mmean) and the deterministic member in slot k+1 (mmdet)
+ *       (:209-230, common_mpi_scale.f90:468-507).  Element (point p, member m,
+ *       variable v) lives at p*sp + m*sm + v*sv doubles, for gues and anal
+ *       alike; the reference's gues3d(nij1,nlev,nens,nv3d) is sp=1,
+ *       sm=nij1*nlev, sv=nij1*nlev*nens.  anal slot k (mean) is NOT written
+ *       (the reference fills it afterwards with ensmean_grd, letkf.f90:207).
+ *     infl: work3d(ij,ilev,n) at p + npts*v; INOUT when infl_adaptive.
+ *-------------------------------------------------------------------------*/
+typedef struct {
+  int32_t k;                 /* MEMBER */
+  int32_t nv;                /* nv3d (11 in the reference, common_nml.f90:19) */
+  int32_t det_run;           /* DET_RUN */
+  int32_t infl_adaptive;     /* INFL_MUL_ADAPTIVE */
+  int32_t relax_to_inflated_prior; /* RELAX_TO_INFLATED_PRIOR */
+  int32_t iv_p;              /* 0-based index of pressure (iv3d_p) for Q_UPDATE_TOP */
+  int32_t iv_q_first, iv_q_last;   /* 0-based inclusive iv3d_q .. iv3d_qg */
+  int32_t reserved0;
+  double relax_alpha;        /* RELAX_ALPHA (RTPP), 0 = off */
+  double relax_alpha_spread; /* RELAX_ALPHA_SPREAD (RTPS), 0 = off; RTPP wins when both set (:457) */
+  double q_update_top;       /* Q_UPDATE_TOP, <= 0 = off */
+  double q_sprd_max;         /* Q_SPRD_MAX, <= 0 = off */
+  int64_t npts;
+  const int64_t *obs_off;    /* dev [npts+1] */
+  const int32_t *obs_idx;    /* dev [obs_off[npts]] */
+  const double *rdiag_l;     /* dev, same length */
+  const double *rloc_l;      /* dev, same length */
+  const double *ensval;      /* dev [nobs_tot][kld] */
+  int64_t kld;               /* >= k (+1 when det_run) */
+  const double *dep;         /* dev [nobs_tot] */
+  const double *beta;        /* dev [npts] or NULL (= 1 everywhere) */
+  double *infl;              /* dev [npts*nv] */
+  const double *gues;        /* dev */
+  double *anal;              /* dev */
+  int64_t sp, sm, sv;        /* strides in doubles */
+  double *trans_out;         /* dev [npts][k*k] or NULL (diagnostic / parity) */
+  double *transm_out;        /* dev [npts][k] or NULL */
+  double *pa_out;            /* dev [npts][k*k] or NULL */
+  int32_t *status;           /* dev [npts] or NULL */
+  int32_t *nsweep;           /* dev [npts] or NULL */
+} letkf_das_args;
+int letkf_das_points_dev(letkf_ctx *ctx, const letkf_das_args *args);
+
+/*---------------------------------------------------------------------------
+ * (2b) Streaming passes either side of the loop, on the same strided layout:
+ *      the perturbation pass scale/letkf/letkf_tools.f90:209-230 and
+ *      ensmean_grd scale/common/common_scale.f90:1513-1552 (called at
+ *      scale/letkf/letkf.f90:207 on anal3d).  x: dev, element (p,m,v) at
+ *      p*sp + m*sm + v*sv; slot m = k is the mean.
+ *-------------------------------------------------------------------------*/
+int letkf_ens_to_perturbations_dev(letkf_ctx *ctx, int32_t k, int32_t nv, int64_t npts, double *x,
+                                   int64_t sp, int64_t sm, int64_t sv);
+int letkf_ens_mean_dev(letkf_ctx *ctx, int32_t k, int32_t nv, int64_t npts, double *x, int64_t sp,
+                       int64_t sm, int64_t sv);
+
+/* Kernel timing helper for bench.py: average duration (ms) of the last
+ * letkf_das_points_dev / letkf_core_batch_dev launches measured with HIP events on the
+ * context's stream since the previous reset; *nlaunch receives the count. */
+int letkf_ctx_timing_enable(letkf_ctx *ctx, int enable);
+int letkf_ctx_timing_read(letkf_ctx *ctx, double *avg_ms, int64_t *nlaunch, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LETKF_AMD_H */

@@ -1,0 +1,187 @@
+"""Python harness binding for libletkf_amd.so (the C ABI in include/letkf_amd.h).
+
+The product is the HIP library + the Fortran shim (scale-letkf_amd/fortran); this module is only the
+ctypes plumbing that tests/, bench.py and __graft_entry__.py use to drive the C ABI with torch-owned
+device memory.  It never computes anything itself and has no CPU fallback: if the library is missing
+or no gfx950 device is visible, every entry raises.
+
+Because the directory name carries a hyphen, load it with `load_package()` from __graft_entry__.py
+(importlib under the module name `scale_letkf_amd`).
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libletkf_amd.so")
+
+LETKF_OK = 0
+ST_OK, ST_NOT_CONVERGED, ST_NONPOSITIVE, ST_ILLCOND = 0, 1, 2, 3
+
+
+class LetkfError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))]
+    srcs.append(os.path.join(HERE, "..", "include", "letkf_amd.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", HERE] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+class CoreBatchArgs(C.Structure):
+    _fields_ = [("ne", C.c_int32), ("nobs", C.c_int32), ("nbatch", C.c_int64), ("nobsl", C.c_void_p),
+                ("hdxb", C.c_void_p), ("rdiag", C.c_void_p), ("rloc", C.c_void_p), ("dep", C.c_void_p),
+                ("depd", C.c_void_p), ("parm_infl", C.c_void_p), ("trans", C.c_void_p), ("transm", C.c_void_p),
+                ("pao", C.c_void_p), ("transmd", C.c_void_p), ("rdiag_wloc", C.c_int32),
+                ("infl_update", C.c_int32), ("status", C.c_void_p), ("nsweep", C.c_void_p)]
+
+
+class DasArgs(C.Structure):
+    _fields_ = [("k", C.c_int32), ("nv", C.c_int32), ("det_run", C.c_int32), ("infl_adaptive", C.c_int32),
+                ("relax_to_inflated_prior", C.c_int32), ("iv_p", C.c_int32), ("iv_q_first", C.c_int32),
+                ("iv_q_last", C.c_int32), ("reserved0", C.c_int32),
+                ("relax_alpha", C.c_double), ("relax_alpha_spread", C.c_double), ("q_update_top", C.c_double),
+                ("q_sprd_max", C.c_double), ("npts", C.c_int64), ("obs_off", C.c_void_p), ("obs_idx", C.c_void_p),
+                ("rdiag_l", C.c_void_p), ("rloc_l", C.c_void_p), ("ensval", C.c_void_p), ("kld", C.c_int64),
+                ("dep", C.c_void_p), ("beta", C.c_void_p), ("infl", C.c_void_p), ("gues", C.c_void_p),
+                ("anal", C.c_void_p), ("sp", C.c_int64), ("sm", C.c_int64), ("sv", C.c_int64),
+                ("trans_out", C.c_void_p), ("transm_out", C.c_void_p), ("pa_out", C.c_void_p),
+                ("status", C.c_void_p), ("nsweep", C.c_void_p)]
+
+
+EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", "letkf_ctx_destroy",
+           "letkf_ctx_set_stream", "letkf_ctx_synchronize", "letkf_core_c", "letkf_core_batch_dev",
+           "letkf_das_points_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
+           "letkf_ctx_timing_enable", "letkf_ctx_timing_read"]
+
+_lib = None
+
+
+def lib():
+    """dlopen the library.  `import torch` first when torch is in the process so both share one HIP runtime
+    (torch's libamdhip64.so and /opt/rocm's carry the same SONAME; the first one loaded wins)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LetkfError(f"{LIB_PATH} not built: run `make -C scale-letkf_amd` (no CPU fallback exists)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.letkf_amd_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            getattr(_lib, name)  # raises AttributeError when a declared symbol is missing
+    return _lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One device + stream + workspace (letkf_ctx)."""
+
+    def __init__(self, device=-1, stream=None):
+        self._l = lib()
+        self._c = C.c_void_p()
+        rc = self._l.letkf_ctx_create(C.c_int(device), C.byref(self._c))
+        self._check(rc)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def _check(self, rc):
+        if rc != LETKF_OK:
+            raise LetkfError(f"letkf_amd error {rc}: {self._l.letkf_amd_last_error().decode()}")
+
+    def close(self):
+        if self._c:
+            self._l.letkf_ctx_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        self._check(self._l.letkf_ctx_set_stream(self._c, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self._check(self._l.letkf_ctx_synchronize(self._c))
+
+    def timing_enable(self, on=True):
+        self._check(self._l.letkf_ctx_timing_enable(self._c, C.c_int(1 if on else 0)))
+
+    def timing_read(self, reset=True):
+        avg = C.c_double(0.0)
+        n = C.c_int64(0)
+        self._check(self._l.letkf_ctx_timing_read(self._c, C.byref(avg), C.byref(n), C.c_int(1 if reset else 0)))
+        return avg.value, n.value
+
+    # ---- (1b) batched letkf_core on device tensors
+    def core_batch(self, ne, nobs, nobsl, hdxb, rdiag, rloc, dep, parm_infl, trans, transm=None, pao=None,
+                   depd=None, transmd=None, rdiag_wloc=False, infl_update=False, status=None, nsweep=None):
+        a = CoreBatchArgs()
+        a.ne, a.nobs, a.nbatch = ne, nobs, nobsl.numel()
+        a.nobsl, a.hdxb, a.rdiag, a.rloc, a.dep = _ptr(nobsl), _ptr(hdxb), _ptr(rdiag), _ptr(rloc), _ptr(dep)
+        a.depd, a.parm_infl, a.trans, a.transm = _ptr(depd), _ptr(parm_infl), _ptr(trans), _ptr(transm)
+        a.pao, a.transmd = _ptr(pao), _ptr(transmd)
+        a.rdiag_wloc, a.infl_update = int(bool(rdiag_wloc)), int(bool(infl_update))
+        a.status, a.nsweep = _ptr(status), _ptr(nsweep)
+        self._check(self._l.letkf_core_batch_dev(self._c, C.byref(a)))
+
+    # ---- (2) das_letkf point update on device tensors
+    def das_points(self, k, nv, obs_off, obs_idx, rdiag_l, rloc_l, ensval, kld, dep, infl, gues, anal, sp, sm, sv,
+                   beta=None, det_run=False, infl_adaptive=False, relax_to_inflated_prior=False, relax_alpha=0.0,
+                   relax_alpha_spread=0.0, q_update_top=0.0, q_sprd_max=0.0, iv_p=4, iv_q_first=5, iv_q_last=10,
+                   trans_out=None, transm_out=None, pa_out=None, status=None, nsweep=None):
+        a = DasArgs()
+        a.k, a.nv, a.det_run, a.infl_adaptive = k, nv, int(bool(det_run)), int(bool(infl_adaptive))
+        a.relax_to_inflated_prior = int(bool(relax_to_inflated_prior))
+        a.iv_p, a.iv_q_first, a.iv_q_last = iv_p, iv_q_first, iv_q_last
+        a.relax_alpha, a.relax_alpha_spread = relax_alpha, relax_alpha_spread
+        a.q_update_top, a.q_sprd_max = q_update_top, q_sprd_max
+        a.npts = obs_off.numel() - 1
+        a.obs_off, a.obs_idx, a.rdiag_l, a.rloc_l = _ptr(obs_off), _ptr(obs_idx), _ptr(rdiag_l), _ptr(rloc_l)
+        a.ensval, a.kld, a.dep, a.beta, a.infl = _ptr(ensval), kld, _ptr(dep), _ptr(beta), _ptr(infl)
+        a.gues, a.anal, a.sp, a.sm, a.sv = _ptr(gues), _ptr(anal), sp, sm, sv
+        a.trans_out, a.transm_out, a.pa_out = _ptr(trans_out), _ptr(transm_out), _ptr(pa_out)
+        a.status, a.nsweep = _ptr(status), _ptr(nsweep)
+        self._check(self._l.letkf_das_points_dev(self._c, C.byref(a)))
+
+    def to_perturbations(self, k, nv, npts, x, sp, sm, sv):
+        self._check(self._l.letkf_ens_to_perturbations_dev(self._c, C.c_int32(k), C.c_int32(nv), C.c_int64(npts),
+                                                           _ptr(x), C.c_int64(sp), C.c_int64(sm), C.c_int64(sv)))
+
+    def ens_mean(self, k, nv, npts, x, sp, sm, sv):
+        self._check(self._l.letkf_ens_mean_dev(self._c, C.c_int32(k), C.c_int32(nv), C.c_int64(npts), _ptr(x),
+                                               C.c_int64(sp), C.c_int64(sm), C.c_int64(sv)))
+
+
+def letkf_core_host(ne, nobs, nobsl, hdxb, rdiag, rloc, dep, parm_infl, want_transm=True, want_pao=True,
+                    rdiag_wloc=None, infl_update=None, depd=None, want_transmd=False):
+    """The host-pointer drop-in letkf_core_c (what the Fortran shim calls), on numpy arrays."""
+    import numpy as np
+    l = lib()
+    dp = C.POINTER(C.c_double)
+    f = lambda a: None if a is None else a.ctypes.data_as(dp)
+    hdxb = np.asfortranarray(hdxb, dtype=np.float64)
+    trans = np.zeros((ne, ne), order="F")
+    transm = np.zeros(ne) if want_transm else None
+    pao = np.zeros((ne, ne), order="F") if want_pao else None
+    transmd = np.zeros(ne) if want_transmd else None
+    infl = C.c_double(parm_infl)
+    wl = C.c_int(1 if rdiag_wloc else 0)
+    iu = C.c_int(1 if infl_update else 0)
+    st = C.c_int(-99)
+    l.letkf_core_c(C.c_int(ne), C.c_int(nobs), C.c_int(nobsl), f(hdxb), f(rdiag), f(rloc), f(dep), C.byref(infl),
+                   f(trans), f(transm), f(pao), C.byref(wl) if rdiag_wloc is not None else None,
+                   C.byref(iu) if infl_update is not None else None, f(depd), f(transmd), C.byref(st))
+    return dict(trans=trans, transm=transm, pao=pao, transmd=transmd if depd is not None else None,
+                parm_infl=infl.value, status=st.value)

@@ -1,0 +1,470 @@
+// letkf_api.hip -- host side of the C ABI declared in include/letkf_amd.h.
+//
+// Thin by design: argument checking, launch planning (LDS carve, Jacobi variant, grid),
+// the large-k workspace, optional HIP-event timing for bench.py, and the host-pointer
+// compatibility entry letkf_core_c that the Fortran shim (scale-letkf_amd/fortran) calls.
+// There is no CPU fallback anywhere in this file: without a device every compute entry
+// returns LETKF_E_NO_DEVICE.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/letkf_amd.h"
+#include "letkf_device.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(LETKF_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+  } while (0)
+
+}  // namespace
+
+struct letkf_ctx {
+  int device = -1;
+  int num_cu = 256;
+  size_t lds_max = 160 * 1024;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  double* ws = nullptr;       // large-k workspace
+  size_t ws_bytes = 0;
+  char* scratch = nullptr;    // staging for the host-pointer entry
+  size_t scratch_bytes = 0;
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+
+namespace {
+
+int ensure_bytes(letkf_ctx* c, char** buf, size_t* have, size_t need) {
+  if (need <= *have) return LETKF_OK;
+  if (*buf) HIP_TRY(hipFree(*buf));
+  *buf = nullptr;
+  *have = 0;
+  size_t cap = need + need / 4 + 4096;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(buf), cap));
+  *have = cap;
+  (void)c;
+  return LETKF_OK;
+}
+
+struct Plan {
+  letkf::LaunchPlan lp;
+  int ldg, ldy, tn;
+  long ws_per_block;
+};
+
+// LDS carve in doubles; must mirror letkf_point_kernel's carve.
+size_t lds_doubles(bool big, int k, int nv, int ldg, int ldy, int tn) {
+  const int nb = nv + 2;
+  size_t fixed = 7 * (size_t)k + 6 * (size_t)nv + 16 + 3 * (size_t)tn + 1;
+  if (big) return fixed + (size_t)tn * ldy;
+  size_t g = (size_t)k * ldg;
+  g += g & 1;
+  size_t tile = (size_t)tn * ldy;
+  size_t ux = (size_t)k * nb + (size_t)nv * k;
+  return fixed + g + (tile > ux ? tile : ux);
+}
+
+int make_plan(const letkf_ctx* c, int k, int nv, long npts, Plan* p) {
+  if (k < 2) return fail(LETKF_E_INVALID, "ensemble size must be >= 2");
+  if (nv < 0 || npts < 0) return fail(LETKF_E_INVALID, "negative size");
+  p->ldg = k | 1;
+  p->ldy = (k + 3) & ~3;
+  bool big = k > 128;
+  if (!big) {
+    p->tn = 32;
+    size_t bytes = 8 * lds_doubles(false, k, nv, p->ldg, p->ldy, p->tn);
+    if (bytes > c->lds_max) big = true;
+    else {
+      p->lp.big = false;
+      p->lp.rmax = (k <= 32) ? 4 : (k <= 56) ? 7 : (k <= 64) ? 8 : (k <= 104) ? 13 : 16;
+      p->lp.block = 256;
+      p->lp.lds_bytes = bytes;
+      long g = (long)c->num_cu * 32;
+      p->lp.grid = (int)(npts < g ? (npts > 0 ? npts : 1) : g);
+      p->ws_per_block = 0;
+      return LETKF_OK;
+    }
+  }
+  // large-k spill path: G, U, X in a per-workgroup HBM workspace, obs tile sized to what LDS is left
+  p->lp.big = true;
+  p->lp.rmax = 0;
+  p->lp.block = 1024;
+  const size_t budget = 64 * 1024 / 8;   // doubles of LDS we allow ourselves (keeps 2 workgroups per CU)
+  size_t fixed = lds_doubles(true, k, nv, p->ldg, p->ldy, 0);
+  long tn = fixed < budget ? (long)((budget - fixed) / (p->ldy + 3)) : 0;
+  if (tn > 32) tn = 32;
+  if (tn < 4) tn = 4;
+  p->tn = (int)tn;
+  p->lp.lds_bytes = 8 * lds_doubles(true, k, nv, p->ldg, p->ldy, p->tn);
+  if (p->lp.lds_bytes > c->lds_max) return fail(LETKF_E_INVALID, "ensemble size too large for the LDS vectors");
+  long g = (long)c->num_cu;
+  p->lp.grid = (int)(npts < g ? (npts > 0 ? npts : 1) : g);
+  const int nb = nv + 2;
+  long w = (long)k * p->ldg + (long)k * nb + (long)nv * k;
+  p->ws_per_block = (w + 1) & ~1L;
+  return LETKF_OK;
+}
+
+int ensure_ws(letkf_ctx* c, const Plan& p) {
+  if (!p.lp.big) return LETKF_OK;
+  size_t need = (size_t)p.lp.grid * (size_t)p.ws_per_block * sizeof(double);
+  if (need <= c->ws_bytes) return LETKF_OK;
+  if (c->ws) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(c->ws));
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+  }
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws), need));
+  c->ws_bytes = need;
+  return LETKF_OK;
+}
+
+int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p) {
+  a.ldg = p.ldg;
+  a.ldy = p.ldy;
+  a.tn = p.tn;
+  a.ws = c->ws;
+  a.ws_per_block = p.ws_per_block;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->timing) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, c->stream));
+  }
+  HIP_TRY(letkf::launch_point_kernel(a, p.lp, c->stream));
+  if (c->timing) {
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    c->events.emplace_back(e0, e1);
+  }
+  return LETKF_OK;
+}
+
+int check_ctx(letkf_ctx* c) {
+  if (!c || c->device < 0) return fail(LETKF_E_NO_DEVICE, "context is not bound to a device");
+  HIP_TRY(hipSetDevice(c->device));
+  return LETKF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int letkf_amd_abi_version(void) { return LETKF_AMD_ABI_VERSION; }
+
+const char* letkf_amd_last_error(void) { return g_last_error.c_str(); }
+
+int letkf_ctx_create(int device_id, letkf_ctx** out) {
+  if (!out) return fail(LETKF_E_INVALID, "ctx out pointer is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(LETKF_E_NO_DEVICE, "no HIP device visible: this library has no CPU path");
+  int dev = device_id;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  if (dev >= ndev) return fail(LETKF_E_INVALID, "device id out of range");
+  HIP_TRY(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(LETKF_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 only");
+  letkf_ctx* c = new letkf_ctx();
+  c->device = dev;
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->lds_max = prop.sharedMemPerBlock >= 64 * 1024 ? (size_t)prop.sharedMemPerBlock : 64 * 1024;
+  {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+      c->lds_max = (size_t)v;
+  }
+  hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(LETKF_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return LETKF_OK;
+}
+
+int letkf_ctx_destroy(letkf_ctx* c) {
+  if (!c) return LETKF_OK;
+  if (c->device >= 0) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& ev : c->events) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  }
+  delete c;
+  return LETKF_OK;
+}
+
+int letkf_ctx_set_stream(letkf_ctx* c, void* hip_stream) {
+  if (int rc = check_ctx(c)) return rc;
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return LETKF_OK;
+}
+
+int letkf_ctx_synchronize(letkf_ctx* c) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LETKF_OK;
+}
+
+int letkf_ctx_timing_enable(letkf_ctx* c, int enable) {
+  if (int rc = check_ctx(c)) return rc;
+  c->timing = enable != 0;
+  return LETKF_OK;
+}
+
+int letkf_ctx_timing_read(letkf_ctx* c, double* avg_ms, int64_t* nlaunch, int reset) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  double tot = 0.0;
+  for (auto& ev : c->events) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+    tot += ms;
+  }
+  if (nlaunch) *nlaunch = (int64_t)c->events.size();
+  if (avg_ms) *avg_ms = c->events.empty() ? 0.0 : tot / (double)c->events.size();
+  if (reset) {
+    for (auto& ev : c->events) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    c->events.clear();
+  }
+  return LETKF_OK;
+}
+
+int letkf_core_batch_dev(letkf_ctx* c, const letkf_core_batch_args* g) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!g) return fail(LETKF_E_INVALID, "args is NULL");
+  if (g->nbatch == 0) return LETKF_OK;
+  if (g->ne < 2 || g->nobs < 1 || g->nbatch < 0) return fail(LETKF_E_INVALID, "bad ne/nobs/nbatch");
+  if (!g->nobsl || !g->hdxb || !g->rdiag || !g->rloc || !g->dep || !g->parm_infl || !g->trans)
+    return fail(LETKF_E_INVALID, "a required device pointer is NULL");
+  Plan p;
+  if (int rc = make_plan(c, g->ne, 0, g->nbatch, &p)) return rc;
+  if (int rc = ensure_ws(c, p)) return rc;
+  letkf::PointArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.k = g->ne;
+  a.nv = 0;
+  a.mode = 1;
+  a.npts = g->nbatch;
+  a.nobsl = g->nobsl;
+  a.hdxb = g->hdxb;
+  a.rdiag = g->rdiag;
+  a.rloc = g->rloc;
+  a.depv = g->dep;
+  a.depd = (g->depd && g->transmd) ? g->depd : nullptr;       // common_letkf.f90:188
+  a.nobs = g->nobs;
+  a.rdiag_wloc = g->rdiag_wloc;
+  a.infl_adaptive = g->infl_update;
+  a.det_run = 0;
+  a.infl = g->parm_infl;
+  a.trans_out = g->trans;
+  a.transm_out = g->transm;
+  a.transmd_out = (g->depd && g->transmd) ? g->transmd : nullptr;
+  a.pa_out = g->pao;
+  a.add_wbar_to_trans = g->transm ? 0 : 1;                    // common_letkf.f90:218-226
+  a.status = g->status;
+  a.nsweep = g->nsweep;
+  return launch(c, a, p);
+}
+
+int letkf_das_points_dev(letkf_ctx* c, const letkf_das_args* g) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!g) return fail(LETKF_E_INVALID, "args is NULL");
+  if (g->npts == 0) return LETKF_OK;
+  if (g->k < 2 || g->nv < 1 || g->npts < 0) return fail(LETKF_E_INVALID, "bad k/nv/npts");
+  if (!g->obs_off || !g->gues || !g->anal || !g->infl) return fail(LETKF_E_INVALID, "a required device pointer is NULL");
+  if (g->kld < g->k + (g->det_run ? 1 : 0)) return fail(LETKF_E_INVALID, "kld too small for k (+1 with det_run)");
+  if (g->iv_p < 0 || g->iv_p >= g->nv) {
+    if (g->q_update_top > 0.0) return fail(LETKF_E_INVALID, "iv_p out of range");
+  }
+  Plan p;
+  if (int rc = make_plan(c, g->k, g->nv, g->npts, &p)) return rc;
+  if (int rc = ensure_ws(c, p)) return rc;
+  letkf::PointArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.k = g->k;
+  a.nv = g->nv;
+  a.mode = 0;
+  a.npts = g->npts;
+  a.obs_off = reinterpret_cast<const long*>(g->obs_off);
+  a.obs_idx = g->obs_idx;
+  a.rdiag_l = g->rdiag_l;
+  a.rloc_l = g->rloc_l;
+  a.ensval = g->ensval;
+  a.kld = g->kld;
+  a.dep = g->dep;
+  a.det_run = g->det_run;
+  a.infl_adaptive = g->infl_adaptive;
+  a.relax_to_inflated_prior = g->relax_to_inflated_prior;
+  a.iv_p = g->iv_p;
+  a.iv_q_first = g->iv_q_first;
+  a.iv_q_last = g->iv_q_last;
+  a.relax_alpha = g->relax_alpha;
+  a.relax_alpha_spread = g->relax_alpha_spread;
+  a.q_update_top = g->q_update_top;
+  a.q_sprd_max = g->q_sprd_max;
+  a.beta = g->beta;
+  a.infl = g->infl;
+  a.gues = g->gues;
+  a.anal = g->anal;
+  a.sp = g->sp;
+  a.sm = g->sm;
+  a.sv = g->sv;
+  a.trans_out = g->trans_out;
+  a.transm_out = g->transm_out;
+  a.pa_out = g->pa_out;
+  a.status = g->status;
+  a.nsweep = g->nsweep;
+  return launch(c, a, p);
+}
+
+int letkf_ens_to_perturbations_dev(letkf_ctx* c, int32_t k, int32_t nv, int64_t npts, double* x, int64_t sp,
+                                   int64_t sm, int64_t sv) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!x || k < 1 || nv < 1 || npts < 0) return fail(LETKF_E_INVALID, "bad argument");
+  if (npts == 0) return LETKF_OK;
+  HIP_TRY(letkf::launch_ens_to_pert(k, nv, npts, x, sp, sm, sv, c->stream));
+  return LETKF_OK;
+}
+
+int letkf_ens_mean_dev(letkf_ctx* c, int32_t k, int32_t nv, int64_t npts, double* x, int64_t sp, int64_t sm,
+                       int64_t sv) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!x || k < 1 || nv < 1 || npts < 0) return fail(LETKF_E_INVALID, "bad argument");
+  if (npts == 0) return LETKF_OK;
+  HIP_TRY(letkf::launch_ens_mean(k, nv, npts, x, sp, sm, sv, c->stream));
+  return LETKF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fine boundary on host pointers: the drop-in for common/common_letkf.f90:52 used by the Fortran shim.
+// One context per calling thread (the reference calls letkf_core from inside !$OMP PARALLEL).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct TlsCtx {
+  letkf_ctx* c = nullptr;
+  ~TlsCtx() {
+    if (c) letkf_ctx_destroy(c);
+  }
+};
+thread_local TlsCtx g_tls;
+
+int core_host(int ne, int nobs, int nobsl, const double* hdxb, const double* rdiag, const double* rloc,
+              const double* dep, double* parm_infl, double* trans, double* transm, double* pao,
+              const int* rdiag_wloc, const int* infl_update, const double* depd, double* transmd, int* st_out) {
+  if (ne < 2 || nobs < 0 || nobsl < 0 || nobsl > nobs) return fail(LETKF_E_INVALID, "bad ne/nobs/nobsl");
+  if (!parm_infl || !trans) return fail(LETKF_E_INVALID, "parm_infl/trans is NULL");
+  if (nobsl > 0 && (!hdxb || !rdiag || !rloc || !dep)) return fail(LETKF_E_INVALID, "an input array is NULL");
+  if (!g_tls.c) {
+    if (int rc = letkf_ctx_create(-1, &g_tls.c)) return rc;
+  }
+  letkf_ctx* c = g_tls.c;
+  if (int rc = check_ctx(c)) return rc;
+  const size_t k = (size_t)ne, n = (size_t)(nobsl > 0 ? nobsl : 1);
+  const bool det = depd && transmd;
+  // scratch layout (doubles): hdxb[n*k] rdiag[n] rloc[n] dep[n] depd[n] infl[1] trans[k*k] pao[k*k] transm[k] transmd[k] | ints: nobsl, status
+  const size_t nd = n * k + 4 * n + 1 + 2 * k * k + 2 * k;
+  const size_t bytes = nd * sizeof(double) + 4 * sizeof(int);
+  if (int rc = ensure_bytes(c, &c->scratch, &c->scratch_bytes, bytes)) return rc;
+  double* d = reinterpret_cast<double*>(c->scratch);
+  double* d_h = d;
+  double* d_rdiag = d_h + n * k;
+  double* d_rloc = d_rdiag + n;
+  double* d_dep = d_rloc + n;
+  double* d_depd = d_dep + n;
+  double* d_infl = d_depd + n;
+  double* d_trans = d_infl + 1;
+  double* d_pao = d_trans + k * k;
+  double* d_transm = d_pao + k * k;
+  double* d_transmd = d_transm + k;
+  int* d_i = reinterpret_cast<int*>(d_transmd + k);
+  hipStream_t s = c->stream;
+  if (nobsl > 0) {
+    // only rows 1..nobsl of hdxb(nobs, ne) are meaningful (common_letkf.f90:35-37): compact while copying
+    HIP_TRY(hipMemcpy2DAsync(d_h, (size_t)nobsl * sizeof(double), hdxb, (size_t)nobs * sizeof(double),
+                             (size_t)nobsl * sizeof(double), k, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_rdiag, rdiag, (size_t)nobsl * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_rloc, rloc, (size_t)nobsl * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_dep, dep, (size_t)nobsl * sizeof(double), hipMemcpyHostToDevice, s));
+    if (det) HIP_TRY(hipMemcpyAsync(d_depd, depd, (size_t)nobsl * sizeof(double), hipMemcpyHostToDevice, s));
+  }
+  int hi[2] = {nobsl, 0};
+  HIP_TRY(hipMemcpyAsync(d_i, hi, sizeof(hi), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_infl, parm_infl, sizeof(double), hipMemcpyHostToDevice, s));
+  letkf_core_batch_args g;
+  std::memset(&g, 0, sizeof(g));
+  g.ne = ne;
+  g.nobs = (int)n;
+  g.nbatch = 1;
+  g.nobsl = d_i;
+  g.hdxb = d_h;
+  g.rdiag = d_rdiag;
+  g.rloc = d_rloc;
+  g.dep = d_dep;
+  g.depd = det ? d_depd : nullptr;
+  g.parm_infl = d_infl;
+  g.trans = d_trans;
+  g.transm = transm ? d_transm : nullptr;
+  g.pao = pao ? d_pao : nullptr;
+  g.transmd = det ? d_transmd : nullptr;
+  g.rdiag_wloc = rdiag_wloc ? (*rdiag_wloc != 0) : 0;      // common_letkf.f90:84-85
+  g.infl_update = infl_update ? (*infl_update != 0) : 0;   // :86-87
+  g.status = d_i + 1;
+  if (int rc = letkf_core_batch_dev(c, &g)) return rc;
+  HIP_TRY(hipMemcpyAsync(trans, d_trans, k * k * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (transm) HIP_TRY(hipMemcpyAsync(transm, d_transm, k * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (pao) HIP_TRY(hipMemcpyAsync(pao, d_pao, k * k * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (transmd && depd) HIP_TRY(hipMemcpyAsync(transmd, d_transmd, k * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(parm_infl, d_infl, sizeof(double), hipMemcpyDeviceToHost, s));
+  int hst = 0;
+  HIP_TRY(hipMemcpyAsync(&hst, d_i + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *st_out = hst;
+  return LETKF_OK;
+}
+}  // namespace
+
+void letkf_core_c(int ne, int nobs, int nobsl, const double* hdxb, const double* rdiag, const double* rloc,
+                  const double* dep, double* parm_infl, double* trans, double* transm, double* pao,
+                  const int* rdiag_wloc, const int* infl_update, const double* depd, double* transmd, int* status) {
+  int st = 0;
+  int rc = core_host(ne, nobs, nobsl, hdxb, rdiag, rloc, dep, parm_infl, trans, transm, pao, rdiag_wloc,
+                     infl_update, depd, transmd, &st);
+  if (rc != LETKF_OK) {
+    std::fprintf(stderr, "!!! ERROR (letkf_core_c): %s\n", g_last_error.c_str());
+    st = rc;
+  }
+  if (status) *status = st;
+}
+
+}  // extern "C"

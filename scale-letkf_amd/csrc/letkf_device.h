@@ -1,0 +1,65 @@
+// letkf_device.h -- POD argument block shared by the host API (letkf_api.hip) and the device code
+// (letkf_kernels.hip).  Internal: the public C ABI is include/letkf_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace letkf {
+
+struct PointArgs {
+  int k, nv;
+  int mode;            // 0: CSR gather from the obs table (das_letkf body); 1: dense hdxb batch (letkf_core)
+  int ldg, ldy, tn;    // leading dims of G / obs tile, obs rows per LDS tile
+  long npts;
+  // mode 0 observations
+  const long* obs_off;
+  const int* obs_idx;
+  const double* rdiag_l;
+  const double* rloc_l;
+  const double* ensval;
+  long kld;
+  const double* dep;
+  // mode 1 observations
+  const int* nobsl;
+  const double* hdxb;
+  const double* rdiag;
+  const double* rloc;
+  const double* depv;
+  const double* depd;
+  int nobs;
+  int rdiag_wloc;
+  // switches
+  int det_run, infl_adaptive, relax_to_inflated_prior;
+  int iv_p, iv_q_first, iv_q_last;
+  int add_wbar_to_trans;
+  double relax_alpha, relax_alpha_spread, q_update_top, q_sprd_max;
+  // state
+  const double* beta;
+  double* infl;
+  const double* gues;
+  double* anal;
+  long sp, sm, sv;
+  // optional outputs
+  double* trans_out;
+  double* transm_out;
+  double* transmd_out;
+  double* pa_out;
+  int* status;
+  int* nsweep;
+  // large-k workspace
+  double* ws;
+  long ws_per_block;   // doubles
+};
+
+struct LaunchPlan {
+  bool big;
+  int rmax;
+  int grid, block;
+  size_t lds_bytes;
+};
+
+hipError_t launch_point_kernel(const PointArgs& a, const LaunchPlan& p, hipStream_t st);
+hipError_t launch_ens_to_pert(int k, int nv, long npts, double* x, long sp, long sm, long sv, hipStream_t st);
+hipError_t launch_ens_mean(int k, int nv, long npts, double* x, long sp, long sm, long sv, hipStream_t st);
+
+}  // namespace letkf

@@ -1,0 +1,702 @@
+// letkf_kernels.hip -- gfx950 (MI355X / CDNA4) device code of the LETKF analysis core.
+//
+// One workgroup solves one grid point end to end (the reference does the same work in
+// common/common_letkf.f90:52-257 + scale/letkf/letkf_tools.f90:457-513, one OpenMP
+// thread per point):
+//
+//   1. gather the point's local observations (rows of obsda_sort%ensval, member-fastest)
+//      through LDS tiles, scaled by sqrt(1/rdiag)              [letkf_tools.f90:1463, common_letkf.f90:111-123]
+//   2. A = Ys^T Ys + (k-1)/rho I in LDS, r = Ys^T (sqrt(w) dep) [common_letkf.f90:127-143, 169-195 folded]
+//   3. eigen-decomposition of A by a wavefront-cooperative one-sided (Hestenes) Jacobi
+//      iteration on G = A held in LDS: columns of G converge to v_j * lambda_j
+//      (replaces common_mtx.f90:41 -> EISPACK rs/tred2/tql2, netlib.f:524)
+//   4. w-bar = V L^-1 V^T r, T = V sqrt((k-1)/L) V^T, Pa = V L^-1 V^T applied directly to the
+//      k x nv perturbation slab (T/Pa are only materialised when the caller asks for them)
+//      + RTPP / RTPS relaxation, beta blending, deterministic member, q-spread clamp
+//                                                               [common_letkf.f90:151-227, letkf_tools.f90:457-513]
+//
+// No k x k matrix ever touches HBM on the production path; per point the kernel streams
+// n*k*8 B of obs rows + 2*k*nv*8 B of state.
+//
+// Template parameters:
+//   BIG   false: every per-point array lives in LDS (k <= 128);  true: G, U, X live in a
+//         per-workgroup HBM/L2 workspace (large-k spill path, any k).
+//   RMAX  rows of a column pair cached in registers per lane in the Jacobi step
+//         (8 lanes per pair: RMAX >= ceil(k/8));  0 selects the streaming variant
+//         (64 lanes per pair, nothing cached) used by the BIG path.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "letkf_device.h"
+
+namespace letkf {
+
+// ------------------------------------------------------------------ small helpers
+__device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, 64); }
+
+template <int W>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int m = 1; m < W; m <<= 1) v += shfl_xor_d(v, m);
+  return v;
+}
+
+// Bijective XCD-aware remap (blocks b and b+8 share an XCD and its L2): consecutive logical
+// work items go to the same XCD so neighbouring grid points, which read almost the same obs
+// rows, hit the same L2.  Speed only, never correctness.
+__device__ __forceinline__ long xcd_remap(long orig, long n) {
+  const long q = n >> 3, r = n & 7;
+  const long xcd = orig & 7, j = orig >> 3;
+  const long base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + j;
+}
+
+// round-robin (circle method) tournament: player m-1 fixed, step s in [0, m-1)
+__device__ __forceinline__ void rr_pair(int m, int s, int pi, int& p, int& q) {
+  const int mm = m - 1;
+  if (pi == 0) {
+    p = mm;
+    q = s;
+  } else {
+    p = s + pi;
+    if (p >= mm) p -= mm;
+    q = s - pi;
+    if (q < 0) q += mm;
+  }
+}
+
+// Hestenes rotation that orthogonalises two columns with squared norms a, b and inner product g.
+__device__ __forceinline__ void hestenes_cs(double a, double b, double g, double& c, double& s) {
+  const double zeta = (b - a) / (2.0 * g);
+  const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  c = 1.0 / sqrt(1.0 + t * t);
+  s = c * t;
+}
+
+constexpr double kRotTol2 = 1e-30;   // rotate when gamma^2 > kRotTol2 * alpha * beta  (|cos| > 1e-15)
+constexpr double kStopTol2 = 1e-18;  // converged when a whole sweep saw only |cos| <= 1e-9 (quadratic phase)
+constexpr int kMaxSweep = 60;
+
+// ------------------------------------------------------------------ Jacobi, 8 lanes per pair, rows in registers
+template <int RMAX>
+__device__ __forceinline__ int jacobi_cached(double* __restrict__ G, const int ldg, const int k, int* flag_lds) {
+  const int tid = threadIdx.x;
+  const int l8 = tid & 7;
+  const int grp = tid >> 3;
+  const int ngrp = blockDim.x >> 3;
+  const int m = k + (k & 1);
+  const int npairs = m >> 1;
+  int sweep = 0;
+  for (; sweep < kMaxSweep; ++sweep) {
+    int notconv = 0;
+    for (int s = 0; s < m - 1; ++s) {
+      for (int pi = grp; pi < npairs; pi += ngrp) {
+        int p, q;
+        rr_pair(m, s, pi, p, q);
+        if (p < k && q < k) {
+          double* gp = G + (size_t)p * ldg;
+          double* gq = G + (size_t)q * ldg;
+          double a[RMAX], b[RMAX];
+          double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) {
+            const int row = l8 + 8 * r;
+            const bool ok = row < k;
+            a[r] = ok ? gp[row] : 0.0;
+            b[r] = ok ? gq[row] : 0.0;
+            al = fma(a[r], a[r], al);
+            be = fma(b[r], b[r], be);
+            ga = fma(a[r], b[r], ga);
+          }
+          al = group_sum<8>(al);
+          be = group_sum<8>(be);
+          ga = group_sum<8>(ga);
+          const double g2 = ga * ga, ab = al * be;
+          if (g2 > kStopTol2 * ab) notconv = 1;
+          if (g2 > kRotTol2 * ab) {
+            double c, sn;
+            hestenes_cs(al, be, ga, c, sn);
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+              const int row = l8 + 8 * r;
+              if (row < k) {
+                gp[row] = c * a[r] - sn * b[r];
+                gq[row] = sn * a[r] + c * b[r];
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (!__syncthreads_or(notconv)) {
+      ++sweep;
+      break;
+    }
+  }
+  (void)flag_lds;
+  return sweep;
+}
+
+// ------------------------------------------------------------------ Jacobi, one wave per pair, streaming (any k, G anywhere)
+__device__ __forceinline__ int jacobi_stream(double* __restrict__ G, const int ldg, const int k) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int grp = tid >> 6;
+  const int ngrp = blockDim.x >> 6;
+  const int m = k + (k & 1);
+  const int npairs = m >> 1;
+  int sweep = 0;
+  for (; sweep < kMaxSweep; ++sweep) {
+    int notconv = 0;
+    for (int s = 0; s < m - 1; ++s) {
+      for (int pi = grp; pi < npairs; pi += ngrp) {
+        int p, q;
+        rr_pair(m, s, pi, p, q);
+        if (p < k && q < k) {
+          double* gp = G + (size_t)p * ldg;
+          double* gq = G + (size_t)q * ldg;
+          double al = 0.0, be = 0.0, ga = 0.0;
+          for (int row = lane; row < k; row += 64) {
+            const double x = gp[row], y = gq[row];
+            al = fma(x, x, al);
+            be = fma(y, y, be);
+            ga = fma(x, y, ga);
+          }
+          al = group_sum<64>(al);
+          be = group_sum<64>(be);
+          ga = group_sum<64>(ga);
+          const double g2 = ga * ga, ab = al * be;
+          if (g2 > kStopTol2 * ab) notconv = 1;
+          if (g2 > kRotTol2 * ab) {
+            double c, sn;
+            hestenes_cs(al, be, ga, c, sn);
+            for (int row = lane; row < k; row += 64) {
+              const double x = gp[row], y = gq[row];
+              gp[row] = c * x - sn * y;
+              gq[row] = sn * x + c * y;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (!__syncthreads_or(notconv)) {
+      ++sweep;
+      break;
+    }
+  }
+  return sweep;
+}
+
+// ------------------------------------------------------------------ the per-point kernel
+constexpr int kTile = 4;   // Gram register tile (kTile x kTile per thread)
+
+// kMaxT = Gram tiles per thread per pass (1 covers k <= 64 with 256 threads)
+template <bool BIG, int RMAX, int kMaxT>
+__global__ void __launch_bounds__(BIG ? 1024 : 256) letkf_point_kernel(const PointArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
+  const int k = A.k;
+  const int nv = A.nv;
+  const int nb = nv + 2;             // right-hand sides: r, r_det, x'_1..x'_nv
+  const int ldg = A.ldg;
+  const int ldy = A.ldy;
+  const int tn = A.tn;
+  const double km1 = (double)(k - 1);
+
+  // ---- carve
+  double* lds = smem;
+  double* vec = lds;                 // 8 vectors of length k
+  double* rvec = vec;                // Ys^T sqrt(w) dep
+  double* rdvec = vec + k;           // same with depd
+  double* lam = vec + 2 * k;
+  double* wbar = vec + 3 * k;
+  double* wbard = vec + 4 * k;
+  double* sc1 = vec + 5 * k;         // (k-1)^.5 * lam^-.5   (T spectrum)
+  double* sc2 = vec + 6 * k;         // 1/lam                (Pa spectrum)
+  double* xsm = vec + 7 * k;         // 6*nv + 16 small per-variable scalars
+  double* xmean = xsm;
+  double* xdet = xsm + nv;
+  double* cfac = xsm + 2 * nv;       // relaxation factor on T per variable
+  double* cdiag = xsm + 3 * nv;      // relaxation diagonal term per variable (RTPP)
+  double* sdot = xsm + 4 * nv;       // x_v . wbar
+  double* sdotd = xsm + 5 * nv;      // x_v . wbar_det
+  double* red = xsm + 6 * nv;        // 16 scalars
+  double* wrow = red + 16;           // tn * 3: sqrt(w), sqrt(w)*dep, sqrt(w)*depd
+  double* dyn = wrow + 3 * tn;
+  if ((reinterpret_cast<uintptr_t>(dyn) & 15) != 0) dyn += 1;   // keep b128-able tiles 16-B aligned
+  double* G;
+  double* Yt;
+  double* U;
+  double* X;
+  if constexpr (BIG) {
+    double* ws = A.ws + (size_t)blockIdx.x * A.ws_per_block;
+    G = ws;
+    U = G + (size_t)k * ldg;
+    X = U + (size_t)k * nb;
+    Yt = dyn;
+  } else {
+    G = dyn;
+    Yt = G + (size_t)k * ldg + (((size_t)k * ldg) & 1);
+    U = Yt;                          // U and X alias the obs tile: it is dead after the Gram phase
+    X = U + (size_t)k * nb;
+  }
+
+  const int ntile = (k + kTile - 1) / kTile;
+  const int ntile2 = ntile * ntile;
+
+  for (long it = blockIdx.x; it < A.npts; it += gridDim.x) {
+    const long pt = xcd_remap(it, A.npts);
+
+    // ---------------- per-point header
+    long o0 = 0;
+    int n = 0;
+    double beta = 1.0;
+    if (A.mode == 0) {
+      o0 = A.obs_off[pt];
+      n = (int)(A.obs_off[pt + 1] - o0);
+      if (A.beta) beta = A.beta[pt];
+    } else {
+      n = A.nobsl[pt];
+    }
+    const double* g0 = A.gues ? A.gues + pt * A.sp : nullptr;
+    double* a0 = A.anal ? A.anal + pt * A.sp : nullptr;
+
+    if (A.mode == 0 && beta == 0.0) {            // letkf_tools.f90:333-359
+      for (int e = tid; e < nv * k; e += nthr) {
+        const int v = e / k, mm = e - v * k;
+        a0[mm * A.sm + v * A.sv] = g0[k * A.sm + v * A.sv] + g0[mm * A.sm + v * A.sv];
+      }
+      if (A.det_run)
+        for (int v = tid; v < nv; v += nthr) a0[(k + 1) * A.sm + v * A.sv] = g0[(k + 1) * A.sm + v * A.sv];
+      if (tid == 0) {
+        if (A.status) A.status[pt] = 0;
+        if (A.nsweep) A.nsweep[pt] = 0;
+      }
+      continue;
+    }
+
+    // variable skip mask for Q_UPDATE_TOP (letkf_tools.f90:371) and the solve's inflation slot
+    bool qskip = false;
+    if (A.mode == 0 && A.q_update_top > 0.0) qskip = g0[k * A.sm + A.iv_p * A.sv] < A.q_update_top;
+    int v0 = 0;                                  // first variable that is actually updated
+    if (qskip)
+      while (v0 < nv && v0 >= A.iv_q_first && v0 <= A.iv_q_last) ++v0;
+    double* infl_p = nullptr;
+    if (A.mode == 0) infl_p = (v0 < nv) ? &A.infl[pt + A.npts * (long)v0] : nullptr;
+    else infl_p = &A.infl[pt];
+    const double infl_old = infl_p ? *infl_p : 1.0;
+
+    __syncthreads();                             // previous point's LDS fully consumed
+
+    // ---------------- phase 1+2: A = Ys^T Ys (+ shift), r = Ys^T sqrt(w) dep
+    for (int j = tid; j < 2 * k; j += nthr) vec[j] = 0.0;        // rvec, rdvec
+    if (tid < 16) red[tid] = 0.0;
+    double p1 = 0.0, p3 = 0.0;                   // adaptive inflation sums (common_letkf.f90:233-249)
+    int sweeps = 0;
+
+    if (n > 0) {
+      for (int tile0 = 0; tile0 < ntile2; tile0 += nthr * kMaxT) {
+        double acc[kMaxT][kTile * kTile];
+#pragma unroll
+        for (int t = 0; t < kMaxT; ++t)
+#pragma unroll
+          for (int e = 0; e < kTile * kTile; ++e) acc[t][e] = 0.0;
+        double racc = 0.0, rdacc = 0.0;          // thread j < k: r_j ; thread k <= j < 2k: rd_j
+
+        for (int i0 = 0; i0 < n; i0 += tn) {
+          const int ni = min(tn, n - i0);
+          __syncthreads();
+          // weights of this tile
+          if (tid < ni) {
+            double w, d, dd = 0.0, rl;
+            if (A.mode == 0) {
+              const long e = o0 + i0 + tid;
+              const int iob = A.obs_idx[e];
+              rl = A.rloc_l[e];
+              w = 1.0 / A.rdiag_l[e];
+              d = A.dep[iob];
+              if (A.det_run) dd = A.ensval[(long)iob * A.kld + k];
+            } else {
+              const long e = pt * (long)A.nobs + i0 + tid;
+              rl = A.rloc[e];
+              w = A.rdiag_wloc ? 1.0 / A.rdiag[e] : rl / A.rdiag[e];
+              d = A.depv[e];
+              if (A.depd) dd = A.depd[e];
+            }
+            const double sw = sqrt(w);
+            wrow[tid] = sw;
+            wrow[tn + tid] = sw * d;
+            wrow[2 * tn + tid] = sw * dd;
+            if (tile0 == 0) {
+              p1 = fma(d * d, w, p1);
+              p3 += rl;
+            }
+          }
+          __syncthreads();
+          // stage the tile: Yt[i][m] = sqrt(w_i) * y_i[m], zero padded to ldy
+          if (A.mode == 0) {
+            for (int e = tid; e < ni * ldy; e += nthr) {
+              const int i = e / ldy, mm = e - i * ldy;
+              double y = 0.0;
+              if (mm < k) y = A.ensval[(long)A.obs_idx[o0 + i0 + i] * A.kld + mm] * wrow[i];
+              Yt[e] = y;
+            }
+          } else {
+            // dense column-major hdxb(nobs, ne): consecutive threads walk down a column (unit stride)
+            const double* H = A.hdxb + (size_t)pt * (size_t)A.nobs * (size_t)k + i0;
+            for (int e = tid; e < ni * ldy; e += nthr) {
+              const int mm = e / ni, i = e - mm * ni;
+              double y = 0.0;
+              if (mm < k) y = H[(size_t)mm * A.nobs + i] * wrow[i];
+              if (mm < ldy) Yt[i * ldy + mm] = y;
+            }
+          }
+          __syncthreads();
+          // Gram update, kTile x kTile register tiles
+#pragma unroll
+          for (int t = 0; t < kMaxT; ++t) {
+            const int tl = tile0 + tid + t * nthr;
+            if (tl < ntile2) {
+              const int ti = tl / ntile, tj = tl - ti * ntile;
+              const double* ya = Yt + ti * kTile;
+              const double* yb = Yt + tj * kTile;
+              for (int i = 0; i < ni; ++i) {
+                double av[kTile], bv[kTile];
+#pragma unroll
+                for (int e = 0; e < kTile; ++e) {
+                  av[e] = ya[i * ldy + e];
+                  bv[e] = yb[i * ldy + e];
+                }
+#pragma unroll
+                for (int ea = 0; ea < kTile; ++ea)
+#pragma unroll
+                  for (int eb = 0; eb < kTile; ++eb) acc[t][ea * kTile + eb] = fma(av[ea], bv[eb], acc[t][ea * kTile + eb]);
+              }
+            }
+          }
+          if (tile0 == 0) {
+            for (int j = tid; j < 2 * k; j += nthr) {   // (k <= nthr/2 on the LDS path: one j per thread)
+              const int col = (j < k) ? j : j - k;
+              const double* wd = wrow + ((j < k) ? tn : 2 * tn);
+              double sacc = 0.0;
+              for (int i = 0; i < ni; ++i) sacc = fma(Yt[i * ldy + col], wd[i], sacc);
+              if (2 * k <= nthr) {
+                if (j < k) racc += sacc; else rdacc += sacc;
+              } else {
+                vec[j] += sacc;                  // large k: several j per thread, accumulate in place
+              }
+            }
+          }
+        }
+        // write the finished tiles of this pass into G (column-major) with the inflation shift
+        const double shift = km1 / infl_old;     // common_letkf.f90:140-143
+        double trp = 0.0;                        // trace(Ys^T Ys) before the shift -> parm(2), :243-248
+#pragma unroll
+        for (int t = 0; t < kMaxT; ++t) {
+          const int tl = tile0 + tid + t * nthr;
+          if (tl < ntile2) {
+            const int ti = tl / ntile, tj = tl - ti * ntile;
+#pragma unroll
+            for (int ea = 0; ea < kTile; ++ea)
+#pragma unroll
+              for (int eb = 0; eb < kTile; ++eb) {
+                const int r = ti * kTile + ea, c = tj * kTile + eb;
+                if (r < k && c < k) {
+                  G[(size_t)c * ldg + r] = acc[t][ea * kTile + eb] + ((r == c) ? shift : 0.0);
+                  if (r == c) trp += acc[t][ea * kTile + eb];
+                }
+              }
+          }
+        }
+        if (A.infl_adaptive && trp != 0.0) atomicAdd(&red[2], trp);
+        if (tile0 == 0 && 2 * k <= nthr) {
+          if (tid < k) rvec[tid] = racc;
+          else if (tid < 2 * k) rdvec[tid - k] = rdacc;
+        }
+      }
+      // adaptive-inflation sums: p1 = sum dep^2 w, p3 = sum rloc (threads < tn hold partials)
+      if (A.infl_adaptive) {
+        p1 = group_sum<64>(p1);
+        p3 = group_sum<64>(p3);
+        if ((tid & 63) == 0) {
+          atomicAdd(&red[0], p1);
+          atomicAdd(&red[1], p3);
+        }
+      }
+      __syncthreads();
+
+      // ---------------- phase 3: eigen-decomposition (one-sided Jacobi on G = A)
+      if constexpr (RMAX > 0) sweeps = jacobi_cached<RMAX>(G, ldg, k, nullptr);
+      else sweeps = jacobi_stream(G, ldg, k);
+
+      // lambda_j = |g_j|, V = G / lambda
+      {
+        const int lane = tid & 63, grp = tid >> 6, ngrp = nthr >> 6;
+        for (int j = grp; j < k; j += ngrp) {
+          double* gj = G + (size_t)j * ldg;
+          double ss = 0.0;
+          for (int r = lane; r < k; r += 64) ss = fma(gj[r], gj[r], ss);
+          ss = group_sum<64>(ss);
+          const double l = sqrt(ss);
+          const double il = 1.0 / l;
+          for (int r = lane; r < k; r += 64) gj[r] *= il;
+          if (lane == 0) lam[j] = l;
+        }
+      }
+      __syncthreads();
+    } else {
+      // nobsl == 0 (common_letkf.f90:89-107): T = sqrt(rho) I, Pa = rho/(k-1) I, w-bar = 0
+      for (int e = tid; e < k * ldg; e += nthr) {
+        const int c = e / ldg, r = e - c * ldg;
+        G[e] = (r == c) ? 1.0 : 0.0;
+      }
+      for (int j = tid; j < k; j += nthr) lam[j] = km1 / infl_old;
+      __syncthreads();
+    }
+
+    // ---------------- status: spectrum checks (common_mtx.f90:66-78)
+    int st = 0;
+    {
+      double lmx = 0.0, lmn = 1e300;
+      for (int j = tid & 63; j < k; j += 64) {
+        lmx = fmax(lmx, lam[j]);
+        lmn = fmin(lmn, lam[j]);
+      }
+#pragma unroll
+      for (int mk = 1; mk < 64; mk <<= 1) {
+        lmx = fmax(lmx, shfl_xor_d(lmx, mk));
+        lmn = fmin(lmn, shfl_xor_d(lmn, mk));
+      }
+      if (sweeps >= kMaxSweep) st = 1;
+      else if (!(lmx > 0.0)) st = 2;
+      else if (lmn < lmx * 1.4901161193847656e-08) st = 3;       // sqrt(DBL_EPSILON)
+    }
+    for (int j = tid; j < k; j += nthr) {
+      const double l = lam[j];
+      sc1[j] = sqrt(km1 / l);
+      sc2[j] = 1.0 / l;
+    }
+
+    // ---------------- phase 4a: stage perturbations X[v][m], means, det member
+    if (A.mode == 0) {
+      for (int e = tid; e < nv * k; e += nthr) {
+        const int v = e / k, mm = e - v * k;
+        X[e] = g0[mm * A.sm + v * A.sv];
+      }
+      for (int v = tid; v < nv; v += nthr) {
+        xmean[v] = g0[k * A.sm + v * A.sv];
+        xdet[v] = A.det_run ? g0[(k + 1) * A.sm + v * A.sv] : 0.0;
+      }
+    }
+    __syncthreads();
+
+    // ---------------- phase 4b: U[j][b] = v_j . B_b,  B = [r, r_det, x'_1 .. x'_nv]
+    for (int e = tid; e < k * nb; e += nthr) {
+      const int j = e / nb, b = e - j * nb;
+      const double* vj = G + (size_t)j * ldg;
+      const double* bb = (b == 0) ? rvec : (b == 1) ? rdvec : X + (size_t)(b - 2) * k;
+      double sacc = 0.0;
+      for (int r = 0; r < k; ++r) sacc = fma(vj[r], bb[r], sacc);
+      U[e] = sacc;
+    }
+    __syncthreads();
+
+    // ---------------- phase 4c: w-bar = V (U_r / lam), w-bar_det, per-variable relaxation scalars
+    for (int e = tid; e < 2 * k; e += nthr) {
+      const int mm = (e < k) ? e : e - k, b = (e < k) ? 0 : 1;
+      double sacc = 0.0;
+      for (int j = 0; j < k; ++j) sacc = fma(G[(size_t)j * ldg + mm], U[j * nb + b] * sc2[j], sacc);
+      (b == 0 ? wbar : wbard)[mm] = sacc;
+    }
+    if (A.mode == 0) {
+      // RTPS needs var_g = |x'|^2 and var_a = x'^T Pa x' = sum_j U_jv^2 / lam_j (letkf_tools.f90:1982-1989)
+      for (int v = tid; v < nv; v += nthr) {
+        const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391
+        double cf = 1.0, cd = 0.0;
+        if (A.relax_alpha != 0.0) {              // RTPP :1960-1963
+          cf = 1.0 - A.relax_alpha;
+          cd = A.relax_alpha * sqrt(parm);
+        } else if (A.relax_alpha_spread != 0.0) { // RTPS :1990-1999
+          double var_g = 0.0, var_a = 0.0;
+          for (int mm = 0; mm < k; ++mm) var_g = fma(X[v * k + mm], X[v * k + mm], var_g);
+          for (int j = 0; j < k; ++j) var_a = fma(U[j * nb + 2 + v] * U[j * nb + 2 + v], sc2[j], var_a);
+          if (var_g > 0.0 && var_a > 0.0)
+            cf = A.relax_alpha_spread * sqrt(var_g * parm / (var_a * km1)) - A.relax_alpha_spread + 1.0;
+        }
+        cfac[v] = cf;
+        cdiag[v] = cd;
+      }
+    }
+    __syncthreads();
+    if (A.mode == 0) {
+      for (int e = tid; e < 2 * nv; e += nthr) {
+        const int v = (e < nv) ? e : e - nv;
+        const double* wv = (e < nv) ? wbar : wbard;
+        double sacc = 0.0;
+        for (int mm = 0; mm < k; ++mm) sacc = fma(X[v * k + mm], wv[mm], sacc);
+        (e < nv ? sdot : sdotd)[v] = sacc;
+      }
+    }
+    __syncthreads();
+
+    // ---------------- adaptive inflation (common_letkf.f90:233-254); uses the OLD rho above
+    double infl_new = infl_old;
+    if (A.infl_adaptive && n > 0) {
+      const double parm1 = red[0], parm3 = red[1], parm2 = red[2] / km1;
+      const double parm4 = (parm1 - parm3) / parm2 - infl_old;
+      const double tq = (infl_old * parm2 + parm3) / parm2;
+      const double sigma_o = 2.0 / parm3 * (tq * tq);
+      const double gain = 0.04 * 0.04 / (sigma_o + 0.04 * 0.04);
+      infl_new = infl_old + gain * parm4;
+    }
+
+    // ---------------- phase 5: analysis members  (letkf_tools.f90:472-513)
+    if (A.mode == 0) {
+      for (int e = tid; e < nv * k; e += nthr) {
+        const int v = e / k, mm = e - v * k;
+        const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
+        double out;
+        if (skip) {
+          out = xmean[v] + X[e];
+        } else {
+          double tx = 0.0;                       // (T x'_v)[mm] = sum_j V[mm][j] sqrt((k-1)/lam_j) U[j][v]
+          for (int j = 0; j < k; ++j) tx = fma(G[(size_t)j * ldg + mm], sc1[j] * U[j * nb + 2 + v], tx);
+          const double pert = cfac[v] * tx + cdiag[v] * X[e];
+          out = xmean[v] + beta * (pert + sdot[v]) + (1.0 - beta) * X[e];
+        }
+        if (A.q_sprd_max > 0.0 && v == A.iv_q_first && !skip) X[e] = out;   // keep for the clamp
+        else a0[mm * A.sm + v * A.sv] = out;
+      }
+      if (A.det_run) {
+        for (int v = tid; v < nv; v += nthr) {
+          const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
+          a0[(k + 1) * A.sm + v * A.sv] = skip ? xdet[v] : xdet[v] + sdotd[v] * beta;   // :489-497
+        }
+      }
+      if (A.q_sprd_max > 0.0 && !(qskip)) {      // :500-513, variable iv3d_q only
+        __syncthreads();
+        const int v = A.iv_q_first;
+        if (tid < 64) {
+          double sm_ = 0.0;
+          for (int mm = tid; mm < k; mm += 64) sm_ += X[v * k + mm];
+          sm_ = group_sum<64>(sm_);
+          const double q_mean = sm_ / (double)k;
+          double ss = 0.0;
+          for (int mm = tid; mm < k; mm += 64) {
+            const double d = X[v * k + mm] - q_mean;
+            ss = fma(d, d, ss);
+          }
+          ss = group_sum<64>(ss);
+          const double q_sprd = sqrt(ss / km1) / q_mean;
+          for (int mm = tid; mm < k; mm += 64) {
+            double val = X[v * k + mm];
+            if (q_sprd > A.q_sprd_max) val = q_mean + (val - q_mean) * A.q_sprd_max / q_sprd;
+            a0[mm * A.sm + v * A.sv] = val;
+          }
+        }
+      }
+      if (A.infl_adaptive && n > 0) {            // :396-398: every updated variable gets the new value
+        for (int v = tid; v < nv; v += nthr) {
+          const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
+          if (!skip) A.infl[pt + A.npts * (long)v] = infl_new;
+        }
+      }
+    } else if (A.infl_adaptive && n > 0 && tid == 0) {
+      A.infl[pt] = infl_new;
+    }
+
+    // ---------------- optional k x k outputs (fine boundary, parity, diagnostics)
+    if (A.trans_out || A.pa_out) {
+      double* To = A.trans_out ? A.trans_out + (size_t)pt * k * k : nullptr;
+      double* Po = A.pa_out ? A.pa_out + (size_t)pt * k * k : nullptr;
+      for (int e = tid; e < k * k; e += nthr) {
+        const int c = e / k, r = e - c * k;      // column-major, coalesced over r
+        double t = 0.0, pp = 0.0;
+        for (int j = 0; j < k; ++j) {
+          const double vv = G[(size_t)j * ldg + r] * G[(size_t)j * ldg + c];
+          t = fma(vv, sc1[j], t);
+          pp = fma(vv, sc2[j], pp);
+        }
+        if (To) To[e] = A.add_wbar_to_trans ? t + wbar[r] : t;   // common_letkf.f90:218-226
+        if (Po) Po[e] = pp;
+      }
+    }
+    if (A.transm_out)
+      for (int j = tid; j < k; j += nthr) A.transm_out[(size_t)pt * k + j] = wbar[j];
+    if (A.transmd_out)
+      for (int j = tid; j < k; j += nthr) A.transmd_out[(size_t)pt * k + j] = wbard[j];
+    if (tid == 0) {
+      if (A.status) A.status[pt] = st;
+      if (A.nsweep) A.nsweep[pt] = sweeps;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ streaming passes either side of the loop
+// scale/letkf/letkf_tools.f90:209-230: members 0..k-1 -= mean (slot k)
+__global__ void ens_to_pert_kernel(int k, int nv, long npts, double* x, long sp, long sm, long sv) {
+  const long total = npts * nv;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long v = e / npts, pt = e - v * npts;
+    double* b = x + pt * sp + v * sv;
+    const double mean = b[k * sm];
+    for (int m = 0; m < k; ++m) b[m * sm] -= mean;
+  }
+}
+
+// scale/common/common_scale.f90:1513-1552: slot k = (sum_{m<k} x_m) / k, summed in member order
+__global__ void ens_mean_kernel(int k, int nv, long npts, double* x, long sp, long sm, long sv) {
+  const long total = npts * nv;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long v = e / npts, pt = e - v * npts;
+    double* b = x + pt * sp + v * sv;
+    double s = b[0];
+    for (int m = 1; m < k; ++m) s += b[m * sm];
+    b[k * sm] = s / (double)k;
+  }
+}
+
+// ------------------------------------------------------------------ host-callable launchers
+template <bool BIG, int RMAX, int MAXT>
+static hipError_t launch_one(const PointArgs& a, int grid, int block, size_t lds, hipStream_t st) {
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_point_kernel<BIG, RMAX, MAXT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((letkf_point_kernel<BIG, RMAX, MAXT>), dim3(grid), dim3(block), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_point_kernel(const PointArgs& a, const LaunchPlan& p, hipStream_t st) {
+  if (p.big) return launch_one<true, 0, 1>(a, p.grid, p.block, p.lds_bytes, st);
+  switch (p.rmax) {
+    case 4: return launch_one<false, 4, 1>(a, p.grid, p.block, p.lds_bytes, st);
+    case 7: return launch_one<false, 7, 1>(a, p.grid, p.block, p.lds_bytes, st);
+    case 8: return launch_one<false, 8, 1>(a, p.grid, p.block, p.lds_bytes, st);
+    case 13: return launch_one<false, 13, 4>(a, p.grid, p.block, p.lds_bytes, st);
+    default: return launch_one<false, 16, 4>(a, p.grid, p.block, p.lds_bytes, st);
+  }
+}
+
+hipError_t launch_ens_to_pert(int k, int nv, long npts, double* x, long sp, long sm, long sv, hipStream_t st) {
+  const long total = npts * nv;
+  const int block = 256;
+  const int grid = (int)((total + block - 1) / block < 65535L * 16 ? (total + block - 1) / block : 65535L * 16);
+  hipLaunchKernelGGL(ens_to_pert_kernel, dim3(grid > 0 ? grid : 1), dim3(block), 0, st, k, nv, npts, x, sp, sm, sv);
+  return hipGetLastError();
+}
+
+hipError_t launch_ens_mean(int k, int nv, long npts, double* x, long sp, long sm, long sv, hipStream_t st) {
+  const long total = npts * nv;
+  const int block = 256;
+  const int grid = (int)((total + block - 1) / block < 65535L * 16 ? (total + block - 1) / block : 65535L * 16);
+  hipLaunchKernelGGL(ens_mean_kernel, dim3(grid > 0 ? grid : 1), dim3(block), 0, st, k, nv, npts, x, sp, sm, sv);
+  return hipGetLastError();
+}
+
+}  // namespace letkf

@@ -1,0 +1,33 @@
+"""GPU parity, fine boundary: letkf_core_c (the host-pointer drop-in the Fortran shim calls) against the golden
+vectors produced by the reference's own letkf_core.  Tolerances: SURVEY.md section 8(c) -- FP64 max-norm relative
+1e-11 on T, Pa, w-bar, w-bar_det; 1e-12 absolute on the adaptive inflation; loosened by cond(A)*eps for the
+ill-conditioned fixtures (cond ~ 1e6: both the reference's QL and the Jacobi solve are only accurate to
+cond*eps there)."""
+import pytest
+
+from _cases import golden_case_list, golden_inputs
+from test_oracle_golden import check_against_golden
+
+pytestmark = pytest.mark.gpu
+
+CASES = golden_case_list()
+
+
+def tol_for(c):
+    if c["cond"] == "ill":
+        return 2e-9      # cond(A) ~ 1e6..1e7  ->  cond * eps ~ 1e-9
+    return 1e-11
+
+
+@pytest.mark.parametrize("c", CASES, ids=[c["name"] for c in CASES])
+def test_letkf_core_c_matches_reference_golden(golden, c):
+    from _gpu import pkg, ctx
+    ctx()
+    inp = golden_inputs(c)
+    r = pkg.letkf_core_host(c["k"], inp["nobs"], c["n"], inp["hdxb"], inp["rdiag"], inp["rloc"], inp["dep"],
+                            inp["infl"], want_transm=c["transm"], want_pao=c["pao"], rdiag_wloc=c["rdiag_wloc"],
+                            infl_update=c["infl_update"], depd=inp["depd"], want_transmd=c["det"])
+    expect_status = 3 if c["cond"] == "ill" and c["k"] == 50 else None
+    if expect_status is None:
+        assert r["status"] in (0, 3), r["status"]
+    check_against_golden(golden, c, r, tol_for(c), tol_infl=1e-12 if c["cond"] != "ill" else 1e-9)

@@ -1,0 +1,119 @@
+"""GPU parity, coarse boundary: letkf_das_points_dev (the das_letkf loop body, scale/letkf/letkf_tools.f90:313-527)
+against the oracle's restatement on the same seeded inputs.  Tolerance:
+|d xa| <= 1e-10 * max(|x-bar|, |x'|) per variable; adaptive inflation 1e-12."""
+import numpy as np
+import pytest
+import torch
+
+import _oracle
+from _cases import das_case
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "rtps": dict(relax_alpha_spread=0.95),
+    "rtpp": dict(relax_alpha=0.7, relax_to_inflated_prior=1),
+    "norelax": dict(),
+    "rtps_det": dict(relax_alpha_spread=0.95, det_run=1),
+    "rtps_adaptive_det": dict(relax_alpha_spread=0.8, det_run=1, infl_adaptive=1, relax_to_inflated_prior=1),
+    "rtpp_qclamp": dict(relax_alpha=0.5, q_sprd_max=0.05),
+    "rtps_qtop": dict(relax_alpha_spread=0.95, q_update_top=49.0, det_run=1, infl_adaptive=1),
+}
+
+
+def run_both(k, nv, npts, nobs_tot, n_mean, seed, cfg, want_trans=False):
+    from _gpu import ctx, dev
+    det = bool(cfg.get("det_run", 0))
+    c = das_case(k=k, nv=nv, npts=npts, nobs_tot=nobs_tot, n_mean=n_mean, seed=seed, det_run=det, infl0=1.07)
+    prm = _oracle.DasParams(k=k, nv=nv, det_run=int(det), infl_adaptive=cfg.get("infl_adaptive", 0),
+                            relax_to_inflated_prior=cfg.get("relax_to_inflated_prior", 0),
+                            relax_alpha=cfg.get("relax_alpha", 0.0),
+                            relax_alpha_spread=cfg.get("relax_alpha_spread", 0.0),
+                            q_update_top=cfg.get("q_update_top", 0.0), q_sprd_max=cfg.get("q_sprd_max", 0.0),
+                            iv_p=4, iv_q_first=5, iv_q_last=min(10, nv - 1), nthreads=4)
+    ref = _oracle.das_points(prm, c["obs_off"], c["obs_idx"], c["rdiag"], c["rloc"], c["ensval"], c["dep"],
+                             c["beta"], c["infl"], c["gues"], c["sp"], c["sm"], c["sv"], want_trans=want_trans,
+                             want_pa=want_trans and cfg.get("relax_alpha_spread", 0.0) != 0.0)
+    assert ref["rc"] == 0
+    anal = torch.full((c["gues"].size,), float("nan"), dtype=torch.float64, device="cuda")
+    infl = dev(c["infl"])
+    status = torch.full((npts,), -1, dtype=torch.int32, device="cuda")
+    trans = torch.zeros(npts, k * k, dtype=torch.float64, device="cuda") if want_trans else None
+    transm = torch.zeros(npts, k, dtype=torch.float64, device="cuda") if want_trans else None
+    ctx().das_points(k, nv, dev(c["obs_off"]), dev(c["obs_idx"]), dev(c["rdiag"]), dev(c["rloc"]), dev(c["ensval"]),
+                     c["kld"], dev(c["dep"]), infl, dev(c["gues"]), anal, c["sp"], c["sm"], c["sv"],
+                     beta=dev(c["beta"]), det_run=det, infl_adaptive=cfg.get("infl_adaptive", 0),
+                     relax_to_inflated_prior=cfg.get("relax_to_inflated_prior", 0),
+                     relax_alpha=cfg.get("relax_alpha", 0.0), relax_alpha_spread=cfg.get("relax_alpha_spread", 0.0),
+                     q_update_top=cfg.get("q_update_top", 0.0), q_sprd_max=cfg.get("q_sprd_max", 0.0),
+                     iv_p=4, iv_q_first=5, iv_q_last=min(10, nv - 1), trans_out=trans, transm_out=transm,
+                     status=status)
+    torch.cuda.synchronize()
+    return c, ref, anal.cpu().numpy(), infl.cpu().numpy(), status.cpu().numpy(), trans, transm
+
+
+def compare_anal(c, ref, got, k, nv, det):
+    nens, npts = c["nens"], c["npts"]
+    g = got.reshape(nv, nens, npts)
+    e = ref["anal"].reshape(nv, nens, npts)
+    x = c["gues"].reshape(nv, nens, npts)
+    members = list(range(k)) + ([k + 1] if det else [])
+    for v in range(nv):
+        scale = max(np.abs(x[v, k]).max(), np.abs(x[v, :k]).max())
+        err = np.abs(g[v, members] - e[v, members]).max()
+        assert np.isfinite(g[v, members]).all()
+        assert err <= 1e-10 * scale, (v, err, scale)
+    # slot k (the mean) is not written by the path: the reference fills it later with ensmean_grd (letkf.f90:207)
+    assert np.isnan(g[:, k]).all()
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("k,npts,nobs_tot,n_mean", [(20, 48, 400, 60), (50, 40, 900, 200)])
+def test_das_points_vs_oracle(name, k, npts, nobs_tot, n_mean):
+    cfg = CONFIGS[name]
+    c, ref, got, infl, status, _, _ = run_both(k, 11, npts, nobs_tot, n_mean, seed=31 + k, cfg=cfg)
+    assert (status == 0).all(), status
+    compare_anal(c, ref, got, k, 11, bool(cfg.get("det_run", 0)))
+    assert np.abs(infl - ref["infl"]).max() <= 1e-12
+
+
+def test_das_points_weights_match():
+    """the optional per-point trans / transm outputs equal what letkf_core returns inside the oracle"""
+    cfg = CONFIGS["rtps"]
+    k = 50
+    c, ref, got, infl, status, trans, transm = run_both(k, 11, 24, 600, 150, seed=5, cfg=cfg, want_trans=True)
+    T = trans.cpu().numpy()
+    W = transm.cpu().numpy()
+    for p in range(24):
+        if c["beta"][p] == 0.0:
+            continue
+        den = np.abs(ref["trans"][p]).max()
+        assert np.abs(T[p] - ref["trans"][p]).max() <= 1e-11 * den
+        assert np.abs(W[p] - ref["transm"][p]).max() <= 1e-11 * max(1.0, np.abs(ref["transm"][p]).max())
+
+
+def test_das_points_odd_k_and_other_nv():
+    c, ref, got, infl, status, _, _ = run_both(33, 5, 20, 300, 50, seed=9, cfg=dict(relax_alpha_spread=0.9))
+    assert (status == 0).all()
+    compare_anal(c, ref, got, 33, 5, False)
+
+
+def test_das_points_k100():
+    c, ref, got, infl, status, _, _ = run_both(100, 11, 12, 700, 150, seed=3, cfg=dict(relax_alpha_spread=0.95))
+    assert (status == 0).all()
+    compare_anal(c, ref, got, 100, 11, False)
+
+
+def test_empty_batch_and_all_beta_zero():
+    from _gpu import ctx, dev
+    k, nv = 20, 11
+    c = das_case(k=k, nv=nv, npts=8, nobs_tot=50, n_mean=10, seed=1)
+    c["beta"][:] = 0.0
+    anal = torch.zeros(c["gues"].size, dtype=torch.float64, device="cuda")
+    ctx().das_points(k, nv, dev(c["obs_off"]), dev(c["obs_idx"]), dev(c["rdiag"]), dev(c["rloc"]), dev(c["ensval"]),
+                     c["kld"], dev(c["dep"]), dev(c["infl"]), dev(c["gues"]), anal, c["sp"], c["sm"], c["sv"],
+                     beta=dev(c["beta"]))
+    torch.cuda.synchronize()
+    x = c["gues"].reshape(nv, c["nens"], 8)
+    a = anal.cpu().numpy().reshape(nv, c["nens"], 8)
+    assert np.array_equal(a[:, :k], x[:, :k] + x[:, k:k + 1])   # letkf_tools.f90:333-341, bit exact
