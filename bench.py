@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- grid-point LETKF solves/s of the batched das_letkf body on MI355X (BASELINE.json metric).
+
+One "step" = one full analysis of the workload grid (every (ij, ilev) point: local-obs gather by index +
+k x k eigen-solve + relaxation + transform of the nv=11 variables), through the C ABI
+(letkf_das_points_dev), inputs resident in HBM.  At N=1 the workload is BASELINE.json configs[1]
+(240x240x60 grid, k=50, ~200 local obs/point).  For N>1 (torchrun, one rank per GPU, RCCL) every rank owns a
+tile of that size (weak scaling) and each step starts with the path's one exchange: the all-gather of the
+observation table shards (the localisation-halo exchange of scale/letkf/letkf_obs.f90:1036-1046).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--relax", default="rtps", choices=["rtps", "rtpp", "none"])
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(affinity, cgroup quota, 16 = the box's CPU share)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    import bench_workload as bw
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    n_gpus = world
+
+    pkg = load_package()
+    pkg.build()
+    stream = torch.cuda.current_stream()
+    ctx = pkg.Context(local_rank, stream.cuda_stream)
+
+    w = bw.build(args.workload, dev, rank=rank, world=world)
+    k, nv, npts = w["k"], w["nv"], w["npts"]
+    # the streaming passes either side of the loop: mean into slot k, members -> perturbations
+    ctx.ens_mean(k, nv, npts, w["gues"], w["sp"], w["sm"], w["sv"])
+    ctx.to_perturbations(k, nv, npts, w["gues"], w["sp"], w["sm"], w["sv"])
+    anal = torch.empty_like(w["gues"])
+    infl = torch.ones(npts * nv, dtype=torch.float64, device=dev)
+    status = torch.zeros(npts, dtype=torch.int32, device=dev)
+    nsweep = torch.zeros(npts, dtype=torch.int32, device=dev)
+    relax = dict(rtps=dict(relax_alpha_spread=0.95), rtpp=dict(relax_alpha=0.7), none=dict())[args.relax]
+
+    # N>1: each rank contributes a 1/N shard of its obs table rows; the step all-gathers them (RCCL over xGMI)
+    shard = None
+    if world > 1:
+        rows = w["ensval"].shape[0]
+        per = (rows + world - 1) // world
+        pad = per * world
+        full = torch.zeros(pad, w["kld"], dtype=torch.float64, device=dev)
+        full[:rows] = w["ensval"]
+        shard = full[rank * per:(rank + 1) * per].clone()
+        gathered = torch.empty_like(full)
+
+    def step():
+        ens = w["ensval"]
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, shard)
+            ens = gathered
+        ctx.das_points(k, nv, w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"], ens, w["kld"], w["dep"], infl,
+                       w["gues"], anal, w["sp"], w["sm"], w["sv"], status=status, nsweep=nsweep, **relax)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timing_enable(True)
+    ctx.timing_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    kern_ms, nlaunch = ctx.timing_read(reset=True)
+    ctx.timing_enable(False)
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    bad = int((status != 0).sum().item())
+    sweeps_mean = float(nsweep.double().mean().item())
+    solves = npts * args.steps * world
+    value = solves / elapsed
+
+    out = None
+    if rank == 0:
+        n_mean = w["n_mean"]
+        b_alg = bw.alg_bytes_per_solve(n_mean, k, nv)
+        f_alg = bw.alg_flops_per_solve(n_mean, k, nv, rtps=(args.relax == "rtps"))
+        kern_s = kern_ms * 1e-3
+        achieved = b_alg * npts / kern_s / 1e9 if kern_s > 0 else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
+                    "kernel": "letkf_point_kernel", "kernel_ms": kern_ms, "launches": nlaunch,
+                    "alg_bytes_per_solve": b_alg, "alg_flops_per_solve": f_alg,
+                    "fp64_tflops": (f_alg * npts / kern_s / 1e12) if kern_s > 0 else None,
+                    "fp64_frac_of_78.6": (f_alg * npts / kern_s / 78.6e12) if kern_s > 0 else None}
+        cpu = None
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(w, relax, args.cpu_seconds, args.cpu_threads)
+        out = {"metric": "grid-point LETKF solves/sec", "value": value, "unit": "solves/s", "n_gpus": n_gpus,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic",
+               "config": {"workload": f"{args.workload}: {w['cfg']['nx']}x{w['cfg']['ny']}x{w['cfg']['nz']} grid, "
+                                      f"k={k} members, nv={nv}, mean {n_mean:.1f} (max {w['n_max']}) local obs/point, "
+                                      f"relax={args.relax}", "points_per_gpu": npts, "obs_table_rows": w["nobs"],
+                          "parallelism": f"grid-point shard x{n_gpus}" + (" + RCCL obs all-gather" if world > 1 else "")},
+               "analysis_wall_s": elapsed / args.steps, "nonzero_status_points": bad,
+               "jacobi_sweeps_mean": sweeps_mean, "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def host_threads(requested):
+    if requested > 0:
+        return requested
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return min(n, 16)   # a one-GPU box's CPU share is 16 cores
+
+
+def cpu_baseline(w, relax, seconds, threads=0):
+    """The oracle's OpenMP restatement of the same loop body on a bounded sample of the same points (kind "port"),
+    timed on this box's host cores.  A reported baseline, not the target."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle
+    ncores = host_threads(threads)
+    k, nv, npts = w["k"], w["nv"], w["npts"]
+    ens = w["ensval"].cpu().numpy()
+    dep = w["dep"].cpu().numpy()
+    off_all = w["obs_off"].cpu().numpy()
+    rng = np.random.default_rng(1)
+
+    def sample(ns):
+        pts = np.sort(rng.choice(npts, size=ns, replace=False))
+        cnt = off_all[pts + 1] - off_all[pts]
+        off = np.zeros(ns + 1, dtype=np.int64)
+        np.cumsum(cnt, out=off[1:])
+        sel = np.concatenate([np.arange(off_all[p], off_all[p + 1]) for p in pts]) if ns else np.zeros(0, np.int64)
+        st = torch_index(w, sel)
+        gv = w["gues"].view(nv, w["nens"], npts)[:, :, pts].contiguous().cpu().numpy().reshape(-1)
+        return off, st, gv, ns
+
+    def torch_index(w, sel):
+        import torch
+        s = torch.from_numpy(sel).to(w["obs_idx"].device)
+        return (w["obs_idx"][s].cpu().numpy(), w["rdiag"][s].cpu().numpy(), w["rloc"][s].cpu().numpy())
+
+    def run(ns):
+        off, (idx, rd, rl), gv, ns = sample(ns)
+        prm = _oracle.DasParams(k=k, nv=nv, det_run=0, infl_adaptive=0, relax_to_inflated_prior=0,
+                                relax_alpha=relax.get("relax_alpha", 0.0),
+                                relax_alpha_spread=relax.get("relax_alpha_spread", 0.0), q_update_top=0.0,
+                                q_sprd_max=0.0, iv_p=4, iv_q_first=5, iv_q_last=10, nthreads=ncores)
+        t0 = time.perf_counter()
+        r = _oracle.das_points(prm, off, idx, rd, rl, ens, dep, None, np.ones(ns * nv), gv, 1, ns, ns * w["nens"])
+        dt = time.perf_counter() - t0
+        assert r["rc"] == 0
+        return ns / dt
+
+    rate0 = run(min(npts, 64 * ncores))
+    ns = int(min(npts, max(64 * ncores, rate0 * seconds)))
+    rate = run(ns)
+    return {"value": rate, "unit": "solves/s", "cores": ncores, "kind": "port",
+            "sample": f"{ns} randomly chosen grid points of the same workload (all {nv} variables, same relaxation), "
+                      f"oracle/letkf_oracle.c orc_das_letkf_points, OpenMP dynamic over points"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""Synthetic SCALE-LETKF analysis workloads for bench.py, built on the device with torch.
+
+Only plumbing lives here: random state, a radar-like observation lattice, and the per-point local-observation
+lists that the reference's obs_local (scale/letkf/letkf_tools.f90:1325, no-limit mode :1438-1476) would hand to
+letkf_core -- same cut-off tests and localisation weights as obs_local_cal (:1793-1906) with the float32-literal
+cut-offs of letkf_obs.f90:27-28.  The hot path itself is only ever run through the C ABI.
+"""
+import math
+
+import numpy as np
+import torch
+
+DIST_ZERO_FAC = float(np.float32(3.651483717))
+DIST_ZERO_FAC_SQUARE = float(np.float32(13.33333333))
+
+CONFIGS = {
+    # BASELINE.json configs[1]: 240x240x60, k=50, ~200 local obs/point
+    "C2": dict(nx=240, ny=240, nz=60, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2800.0, err=3.0,
+               ztop=18000.0, seed=20240609),
+    # small stand-ins for tests / smoke-sized benches
+    "C2-mini": dict(nx=48, ny=48, nz=12, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
+                    ztop=18000.0, seed=20240610),
+    "C1": dict(nx=40, ny=40, nz=30, k=20, dx=15000.0, hloc=120000.0, vloc=4000.0, spacing=30000.0, err=3.0,
+               ztop=18000.0, seed=20240608),
+}
+
+
+def level_heights(nz, ztop):
+    """stretched levels 50 m .. ztop (flat terrain)"""
+    s = np.linspace(0.0, 1.0, nz)
+    return 50.0 + (ztop - 50.0) * s ** 1.6
+
+
+def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1):
+    cfg = CONFIGS[cfg_name]
+    nx, ny, nz, k = cfg["nx"], cfg["ny"], cfg["nz"], cfg["k"]
+    dx, hloc, vloc, sp_o, err = cfg["dx"], cfg["hloc"], cfg["vloc"], cfg["spacing"], cfg["err"]
+    g = torch.Generator(device=device)
+    g.manual_seed(cfg["seed"] + 7919 * rank)
+    f64 = torch.float64
+    # ---- observation lattice (type-22 radar-like: vertical localisation in z, letkf_tools.f90:1857)
+    ox = torch.arange(0.5 * sp_o, nx * dx, sp_o, device=device, dtype=f64)
+    oy = torch.arange(0.5 * sp_o, ny * dx, sp_o, device=device, dtype=f64)
+    oz = torch.arange(0.5 * sp_o, cfg["ztop"], sp_o, device=device, dtype=f64)
+    nox, noy, noz = len(ox), len(oy), len(oz)
+    nobs = nox * noy * noz
+    kld = k + 1
+    ensval = torch.randn(nobs, kld, generator=g, device=device, dtype=f64) * 2.0
+    ensval[:, :k] -= ensval[:, :k].mean(dim=1, keepdim=True)
+    dep = torch.randn(nobs, generator=g, device=device, dtype=f64) * math.sqrt(err * err + 4.0)
+    # ---- per-point local lists, one level slab at a time.  Point index pt = ij + nij*ilev (point-fastest, as
+    #      gues3d(nij1,nlev,...)); obs index = (iz*noy + iy)*nox + ix.
+    zlev = torch.from_numpy(level_heights(nz, cfg["ztop"])).to(device)
+    gx = (torch.arange(nx, device=device, dtype=f64) + 0.5) * dx
+    gy = (torch.arange(ny, device=device, dtype=f64) + 0.5) * dx
+    px = gx.repeat(ny)                      # ij = i + nx*j
+    py = gy.repeat_interleave(nx)
+    rh = int(math.ceil(hloc * DIST_ZERO_FAC / sp_o))
+    rv = int(math.ceil(vloc * DIST_ZERO_FAC / sp_o))
+    offs = torch.arange(-rh, rh + 1, device=device)
+    offv = torch.arange(-rv, rv + 1, device=device)
+    nij = nx * ny
+    cix = torch.floor(px / sp_o).long()
+    ciy = torch.floor(py / sp_o).long()
+    counts_all, idx_all, rloc_all = [], [], []
+    for lev in range(nz):
+        ciz = int(math.floor(float(zlev[lev]) / sp_o))
+        ix = cix[:, None] + offs[None, :]                                   # [nij, nh]
+        iy = ciy[:, None] + offs[None, :]
+        iz = ciz + offv                                                     # [nvv]
+        okx = (ix >= 0) & (ix < nox)
+        oky = (iy >= 0) & (iy < noy)
+        okz = (iz >= 0) & (iz < noz)
+        ddx = (px[:, None] - ox[ix.clamp(0, nox - 1)])                      # metres
+        ddy = (py[:, None] - oy[iy.clamp(0, noy - 1)])
+        ndv = (zlev[lev] - oz[iz.clamp(0, noz - 1)]).abs() / vloc           # [nvv]
+        # candidate order: z, then y, then x (ascending obs index)
+        d2h = (ddy[:, None, :, None] ** 2 + ddx[:, None, None, :] ** 2)     # [nij,1,nh,nh]
+        ndh = torch.sqrt(d2h) / hloc
+        nd2 = ndh * ndh + (ndv * ndv)[None, :, None, None]
+        ok = (okz & (ndv <= DIST_ZERO_FAC))[None, :, None, None] & oky[:, None, :, None] & okx[:, None, None, :]
+        ok = ok & (ndh <= DIST_ZERO_FAC) & (nd2 <= DIST_ZERO_FAC_SQUARE)
+        oidx = (iz[None, :, None, None] * noy + iy[:, None, :, None]) * nox + ix[:, None, None, :]
+        okf = ok.reshape(nij, -1)
+        counts_all.append(okf.sum(dim=1))
+        sel = okf.reshape(-1).nonzero(as_tuple=False).squeeze(1)
+        idx_all.append(oidx.reshape(-1)[sel].to(torch.int32))
+        rloc_all.append(torch.exp(-0.5 * nd2.reshape(-1)[sel]))
+        del d2h, ndh, nd2, ok, oidx, okf, sel
+    counts = torch.cat(counts_all)
+    obs_off = torch.zeros(nij * nz + 1, dtype=torch.int64, device=device)
+    obs_off[1:] = torch.cumsum(counts, 0)
+    obs_idx = torch.cat(idx_all)
+    rloc = torch.cat(rloc_all)
+    rdiag = (err * err) / rloc                                              # letkf_tools.f90:1903
+    del counts_all, idx_all, rloc_all
+    # ---- ensemble state gues3d(nij*nz, nens, nv): members, then mean slot k, det slot k+1
+    npts = nij * nz
+    nens = k + 1 + (1 if det_run else 0)
+    gues = torch.empty(nv * nens * npts, dtype=f64, device=device)
+    gv = gues.view(nv, nens, npts)
+    sig = [2.0, 2.0, 2.0, 1.0, 50.0] + [1e-3] * (nv - 5)
+    mean0 = [10.0, 5.0, 0.1, 280.0, 8.0e4] + [5e-3] * (nv - 5)
+    for v in range(nv):
+        gv[v].normal_(mean0[v], sig[v], generator=g)
+    return dict(cfg=cfg, name=cfg_name, k=k, nv=nv, npts=npts, nens=nens, kld=kld, nobs=nobs, ensval=ensval, dep=dep,
+                obs_off=obs_off, obs_idx=obs_idx, rdiag=rdiag, rloc=rloc, gues=gues, sp=1, sm=npts, sv=npts * nens,
+                n_mean=float(counts.double().mean()), n_max=int(counts.max()), det_run=det_run)
+
+
+def alg_bytes_per_solve(n, k, nv, det=False):
+    """every solve streams its own local-obs slice once; no k x k matrix touches HBM."""
+    return 8.0 * (n * k + 3 * n + (n if det else 0) + k * nv + nv + k * nv + 1)
+
+
+def alg_flops_per_solve(n, k, nv, rtps=True):
+    f = 2.0 * n * k * k + 2.0 * n * k + 9.0 * k ** 3 + 2.0 * k ** 3 + 2.0 * k * k + 2.0 * nv * k * k
+    if rtps:
+        f += 2.0 * k ** 3 + 2.0 * nv * k * k
+    return f

@@ -75,7 +75,7 @@ __device__ __forceinline__ void hestenes_cs(double a, double b, double g, double
 }
 
 constexpr double kRotTol2 = 1e-30;   // rotate when gamma^2 > kRotTol2 * alpha * beta  (|cos| > 1e-15)
-constexpr double kStopTol2 = 1e-18;  // converged when a whole sweep saw only |cos| <= 1e-9 (quadratic phase)
+constexpr double kStopTol2 = 1e-22;  // converged when a whole sweep saw only |cos| <= 1e-11 (measured: 1e-9 leaves 5e-12 in T when n < k)
 constexpr int kMaxSweep = 60;
 
 // ------------------------------------------------------------------ Jacobi, 8 lanes per pair, rows in registers
