@@ -15,7 +15,7 @@ DIST_ZERO_FAC_SQUARE = float(np.float32(13.33333333))
 
 CONFIGS = {
     # BASELINE.json configs[1]: 240x240x60, k=50, ~200 local obs/point
-    "C2": dict(nx=240, ny=240, nz=60, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2800.0, err=3.0,
+    "C2": dict(nx=240, ny=240, nz=60, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2900.0, err=3.0,
                ztop=18000.0, seed=20240609),
     # small stand-ins for tests / smoke-sized benches
     "C2-mini": dict(nx=48, ny=48, nz=12, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -143,13 +144,24 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p) {
   a.tn = p.tn;
   a.ws = c->ws;
   a.ws_per_block = p.ws_per_block;
+  a.max_sweep = 60;
+  if (const char* e = std::getenv("LETKF_AMD_MAX_SWEEP")) {   // profiling knob: time the non-eigensolve phases
+    int v = std::atoi(e);
+    if (v > 0 && v < 60) a.max_sweep = v;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, c->stream));
   }
-  HIP_TRY(letkf::launch_point_kernel(a, p.lp, c->stream));
+  // k <= 64: one wavefront per grid point, matrix in registers (letkf_wave.hip); otherwise one workgroup per
+  // point with the matrix in LDS, or in the HBM workspace for large k (letkf_kernels.hip)
+  static const bool force_block = std::getenv("LETKF_AMD_FORCE_BLOCK") != nullptr;
+  if (!force_block && letkf::wave_kernel_supports(a.k, a.nv, a.mode))
+    HIP_TRY(letkf::launch_wave_kernel(a, c->num_cu, c->stream));
+  else
+    HIP_TRY(letkf::launch_point_kernel(a, p.lp, c->stream));
   if (c->timing) {
     HIP_TRY(hipEventRecord(e1, c->stream));
     c->events.emplace_back(e0, e1);

@@ -32,6 +32,7 @@ struct PointArgs {
   int det_run, infl_adaptive, relax_to_inflated_prior;
   int iv_p, iv_q_first, iv_q_last;
   int add_wbar_to_trans;
+  int max_sweep;       // Jacobi sweep cap (60); lowered only by the LETKF_AMD_MAX_SWEEP profiling knob
   double relax_alpha, relax_alpha_spread, q_update_top, q_sprd_max;
   // state
   const double* beta;
@@ -59,6 +60,8 @@ struct LaunchPlan {
 };
 
 hipError_t launch_point_kernel(const PointArgs& a, const LaunchPlan& p, hipStream_t st);
+bool wave_kernel_supports(int k, int nv, int mode);
+hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st);
 hipError_t launch_ens_to_pert(int k, int nv, long npts, double* x, long sp, long sm, long sv, hipStream_t st);
 hipError_t launch_ens_mean(int k, int nv, long npts, double* x, long sp, long sm, long sv, hipStream_t st);
 

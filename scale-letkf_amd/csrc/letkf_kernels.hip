@@ -80,7 +80,7 @@ constexpr int kMaxSweep = 60;
 
 // ------------------------------------------------------------------ Jacobi, 8 lanes per pair, rows in registers
 template <int RMAX>
-__device__ __forceinline__ int jacobi_cached(double* __restrict__ G, const int ldg, const int k, int* flag_lds) {
+__device__ __forceinline__ int jacobi_cached(double* __restrict__ G, const int ldg, const int k, const int max_sweep) {
   const int tid = threadIdx.x;
   const int l8 = tid & 7;
   const int grp = tid >> 3;
@@ -88,7 +88,7 @@ __device__ __forceinline__ int jacobi_cached(double* __restrict__ G, const int l
   const int m = k + (k & 1);
   const int npairs = m >> 1;
   int sweep = 0;
-  for (; sweep < kMaxSweep; ++sweep) {
+  for (; sweep < max_sweep; ++sweep) {
     int notconv = 0;
     for (int s = 0; s < m - 1; ++s) {
       for (int pi = grp; pi < npairs; pi += ngrp) {
@@ -135,12 +135,11 @@ __device__ __forceinline__ int jacobi_cached(double* __restrict__ G, const int l
       break;
     }
   }
-  (void)flag_lds;
   return sweep;
 }
 
 // ------------------------------------------------------------------ Jacobi, one wave per pair, streaming (any k, G anywhere)
-__device__ __forceinline__ int jacobi_stream(double* __restrict__ G, const int ldg, const int k) {
+__device__ __forceinline__ int jacobi_stream(double* __restrict__ G, const int ldg, const int k, const int max_sweep) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int grp = tid >> 6;
@@ -148,7 +147,7 @@ __device__ __forceinline__ int jacobi_stream(double* __restrict__ G, const int l
   const int m = k + (k & 1);
   const int npairs = m >> 1;
   int sweep = 0;
-  for (; sweep < kMaxSweep; ++sweep) {
+  for (; sweep < max_sweep; ++sweep) {
     int notconv = 0;
     for (int s = 0; s < m - 1; ++s) {
       for (int pi = grp; pi < npairs; pi += ngrp) {
@@ -430,8 +429,8 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) letkf_point_kernel(const Poi
       __syncthreads();
 
       // ---------------- phase 3: eigen-decomposition (one-sided Jacobi on G = A)
-      if constexpr (RMAX > 0) sweeps = jacobi_cached<RMAX>(G, ldg, k, nullptr);
-      else sweeps = jacobi_stream(G, ldg, k);
+      if constexpr (RMAX > 0) sweeps = jacobi_cached<RMAX>(G, ldg, k, A.max_sweep);
+      else sweeps = jacobi_stream(G, ldg, k, A.max_sweep);
 
       // lambda_j = |g_j|, V = G / lambda
       {
@@ -471,7 +470,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) letkf_point_kernel(const Poi
         lmx = fmax(lmx, shfl_xor_d(lmx, mk));
         lmn = fmin(lmn, shfl_xor_d(lmn, mk));
       }
-      if (sweeps >= kMaxSweep) st = 1;
+      if (sweeps >= A.max_sweep && A.max_sweep >= kMaxSweep) st = 1;
       else if (!(lmx > 0.0)) st = 2;
       else if (lmn < lmx * 1.4901161193847656e-08) st = 3;       // sqrt(DBL_EPSILON)
     }

@@ -1,0 +1,677 @@
+// letkf_wave.hip -- wavefront-per-grid-point LETKF kernel for k <= 64 (gfx950).
+//
+// One 64-lane wavefront solves one grid point; the 4 waves of a workgroup are fully
+// independent (no workgroup barrier anywhere), so a CU keeps 8 points in flight.
+//
+// Data layout inside the wave: lane j owns column j of the k x k work matrix
+//   G = A = Ys^T Ys + (k-1)/rho I      (common/common_letkf.f90:127-143)
+// as KR doubles in VGPRs.  The symmetric eigenproblem (reference: common_mtx.f90:41 ->
+// EISPACK rs, netlib.f:524) is solved by one-sided (Hestenes) Jacobi directly on those
+// registers with an odd-even transposition pair ordering: every lane only ever pairs with a
+// neighbouring lane, fetches that column with DPP moves on the VALU, and both lanes of a pair
+// apply the same plane rotation (see jacobi_regs).  No LDS traffic, no barriers, all control
+// flow wave-uniform.  Columns converge to lambda_j v_j, so lambda_j = |g_j| and V needs no
+// accumulation.
+//
+// Afterwards (lane j still holds v_j):
+//   U[j][b] = v_j . B_b        B = [Ys^T d, Ys^T d_det, x'_1 .. x'_nv]  (LDS broadcast reads)
+//   Out = V (D U)              through 8-column LDS transposition chunks, lane m gets row m
+//   -> w-bar, w-bar_det, T x'_v;  RTPP/RTPS, beta, det member, q clamp as
+//      scale/letkf/letkf_tools.f90:457-513.  T / Pa themselves are only formed on request.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "letkf_device.h"
+
+namespace letkf {
+
+namespace {
+
+__device__ __forceinline__ double wshfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
+
+// DPP cross-lane move of a double (two 32-bit VALU movs, no LDS crossbar).  CTRL is a gfx9 dpp_ctrl code:
+// 0xB1 quad_perm[1,0,3,2] (lane^1), 0x4E quad_perm[2,3,0,1] (lane^2), 0x1B quad_perm[3,2,1,0] (lane^3),
+// 0x141 row_half_mirror (lane^7), 0x140 row_mirror (lane^15).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += wshfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = fmax(v, wshfl_xor(v, m));
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = fmin(v, wshfl_xor(v, m));
+  return v;
+}
+
+// a value known to be identical in every lane -> SGPR pair (frees VGPRs, lets FMAs take a scalar operand)
+__device__ __forceinline__ double uniform(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// Scheduling pin: makes every accumulator an in/out operand of an empty asm with a memory clobber.  The FMAs that
+// produce the accumulators must then retire before it and the next LDS loads issue after it, which stops the
+// compiler from issuing all unrolled broadcast loads first and spilling them (measured: 5 KB of scratch per lane).
+template <int NB>
+__device__ __forceinline__ void pin_acc(double (&c)[NB]) {
+  if constexpr (NB == 2) {
+    asm volatile("" : "+v"(c[0]), "+v"(c[1])::"memory");
+  } else if constexpr (NB == 13) {
+    asm volatile(""
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]),
+                   "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12])::"memory");
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(c[b])::"memory");
+  }
+}
+
+// LDS written by some lanes of this wave, read by others: DS instructions of one wave execute in
+// order, so only the compiler has to be kept from reordering across the hand-off.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ long xcd_remap_w(long orig, long n) {
+  const long q = n >> 3, r = n & 7;
+  const long xcd = orig & 7, j = orig >> 3;
+  const long base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + j;
+}
+
+constexpr double kRotTol2W = 1e-30;   // rotate when cos^2 > 1e-30
+constexpr double kStopTol2W = 1e-22;  // sweep counts as converged when every visited pair had |cos| <= 1e-11
+constexpr int kTnW = 8;               // obs rows per LDS tile (per wave)
+constexpr int kChunk = 8;             // columns per LDS transposition chunk
+constexpr int kVld = kChunk + 2;      // row stride of the transposition buffer (doubles, even)
+
+// 1/sqrt(x) and 1/x from the hardware seeds (v_rsq_f64 / v_rcp_f64, ~2^-23) + two Newton steps each: full
+// double precision without the IEEE division / sqrt expansions (~25 instructions each), which were 1/3 of
+// the Jacobi step's FP64 issue slots.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * y, y, 1.0);
+  y = fma(y * 0.5, e, y);
+  e = fma(-x * y, y, 1.0);
+  return fma(y * 0.5, e, y);
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One-sided (Hestenes) Jacobi on register-resident columns.  Returns sweeps used.
+//
+// Pair ordering = odd-even transposition on the lane line: even steps pair lanes (0,1)(2,3)..., odd steps
+// (1,2)(3,4)...; after its rotation a pair SWAPS places (each lane simply computes the partner's new column
+// instead of its own).  After k steps every one of the k(k-1)/2 column pairs has met exactly once, for any k,
+// and the only partners a lane ever has are its two neighbours -- so the 2*KR-dword column fetch is a DPP
+// move on the VALU (quad_perm[1,0,3,2] / wave_shl:1 / wave_shr:1) instead of ds_bpermute through the LDS
+// crossbar, which at 4 LDS cycles per dword-move and 4 SIMDs per CU was what bounded the XOR-tournament
+// version (measured 1.6 ms -> 0.7 ms per sweep on the C2-mini workload).
+//
+// The rotation itself is a "fast" scaled rotation G' = H + coef * G (KR FMAs): the cosine is not multiplied
+// into the column but accumulated in a per-column inverse scale `is`, and the squared norms alpha follow the
+// rotation identities alpha' = alpha -/+ t*gamma.  Both are refreshed once per sweep.
+// ---------------------------------------------------------------------------------------------
+template <int KR>
+__device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const int max_sweep) {
+  const int lane = threadIdx.x & 63;
+  const bool oddlane = (lane & 1) != 0;
+  int sweep = 0;
+  double is = 1.0, sc = 1.0;     // true column = is * g ; sc = 1/is
+  for (; sweep < max_sweep; ++sweep) {
+    // refresh: fold the scale back, recompute the squared norm
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < KR; r += 2) {
+      g[r] *= is;
+      g[r + 1] *= is;
+      a0 = fma(g[r], g[r], a0);
+      a1 = fma(g[r + 1], g[r + 1], a1);
+    }
+    double al = a0 + a1;
+    is = 1.0;
+    sc = 1.0;
+    bool notconv = false;
+    for (int t = 0; t < k; ++t) {
+      const bool oddstep = (t & 1) != 0;
+      const int pl = oddstep ? (oddlane ? lane + 1 : lane - 1) : (lane ^ 1);
+      const bool has = (lane < k) && (pl >= 0) && (pl < k);
+      double h[KR];
+      double be, isq, scq;
+      double ga0 = 0.0, ga1 = 0.0;
+      if (!oddstep) {
+#pragma unroll
+        for (int r = 0; r < KR; r += 2) {
+          h[r] = dpp_mov<0xB1>(g[r]);
+          h[r + 1] = dpp_mov<0xB1>(g[r + 1]);
+          ga0 = fma(g[r], h[r], ga0);
+          ga1 = fma(g[r + 1], h[r + 1], ga1);
+        }
+        be = dpp_mov<0xB1>(al);
+        isq = dpp_mov<0xB1>(is);
+        scq = dpp_mov<0xB1>(sc);
+      } else {
+#pragma unroll
+        for (int r = 0; r < KR; r += 2) {
+          const double u0 = dpp_mov<0x130>(g[r]), d0 = dpp_mov<0x138>(g[r]);          // lane+1 / lane-1
+          const double u1 = dpp_mov<0x130>(g[r + 1]), d1 = dpp_mov<0x138>(g[r + 1]);
+          h[r] = oddlane ? u0 : d0;
+          h[r + 1] = oddlane ? u1 : d1;
+          ga0 = fma(g[r], h[r], ga0);
+          ga1 = fma(g[r + 1], h[r + 1], ga1);
+        }
+        const double bu = dpp_mov<0x130>(al), bd = dpp_mov<0x138>(al);
+        const double iu = dpp_mov<0x130>(is), id = dpp_mov<0x138>(is);
+        const double su = dpp_mov<0x130>(sc), sd = dpp_mov<0x138>(sc);
+        be = oddlane ? bu : bd;
+        isq = oddlane ? iu : id;
+        scq = oddlane ? su : sd;
+      }
+      const double ga = (ga0 + ga1) * (is * isq);          // true inner product
+      const bool lo = lane < pl;
+      const double a = lo ? al : be, b = lo ? be : al;     // both lanes of a pair see the same (a, b, ga)
+      const double g2 = ga * ga, ab = a * b;
+      notconv = notconv || (has && g2 > kStopTol2W * ab);
+      const bool rot = has && g2 > kRotTol2W * ab;
+      // tan(2 theta) = 2 ga / (b - a);  t = 2 ga sgn(d) / (|d| + sqrt(d^2 + 4 ga^2))
+      const double d = b - a;
+      const double x = fma(d, d, 4.0 * g2);
+      const double hh = x * fast_rsqrt(x);
+      double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp(fabs(d) + hh);
+      tt = rot ? tt : 0.0;
+      const double w = fma(tt, tt, 1.0);
+      const double c = fast_rsqrt(w);                      // cos
+      if (has) {
+        // rotate and swap: this lane takes over the PARTNER's new column.  True columns g_p' = c (g_p - t g_q),
+        // g_q' = c (g_q + t g_p); in the partner's scaled storage that is  G' = H +/- t (is_own / is_partner) G.
+        const double tg = tt * ga;
+        al = lo ? b + tg : a - tg;
+        const double coef = (lo ? tt : -tt) * (is * scq);
+        is = isq * c;
+        sc = scq * (w * c);                                // 1/cos = sqrt(1 + t^2)
+#pragma unroll
+        for (int r = 0; r < KR; ++r) g[r] = fma(coef, g[r], h[r]);
+      }
+    }
+    if (!__any(notconv)) {
+      ++sweep;
+      break;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < KR; ++r) g[r] *= is;
+  return sweep;
+}
+
+// Out[b] (lane m: row m of V C) += sum over the wave's columns j of V[m][j] * C[j][b], b < NB.
+// V[:, j] is lane j's register column vcol[], C[j][:] is lane j's crow[].  Done in chunks of
+// kChunk columns through LDS:  vbuf[KR][kVld], cbuf[kChunk][NBP].
+template <int KR, int NB>
+__device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const double (&crow)[NB], double (&out)[NB],
+                                             const int k, double* vbuf, double* cbuf) {
+  constexpr int NBP = (NB + 1) & ~1;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) out[b] = 0.0;
+  for (int j0 = 0; j0 < k; j0 += kChunk) {
+    wave_lds_sync();
+    if (lane >= j0 && lane < j0 + kChunk) {
+      const int jj = lane - j0;
+#pragma unroll
+      for (int r = 0; r < KR; ++r) vbuf[r * kVld + jj] = vcol[r];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) cbuf[jj * NBP + b] = crow[b];
+      if (NBP > NB) cbuf[jj * NBP + NB] = 0.0;
+    }
+    wave_lds_sync();
+    const int mrow = lane < KR ? lane : KR - 1;
+    double vv[kChunk];
+#pragma unroll
+    for (int jj = 0; jj < kChunk; jj += 2) {
+      const double2 t2 = *reinterpret_cast<const double2*>(&vbuf[mrow * kVld + jj]);
+      vv[jj] = t2.x;
+      vv[jj + 1] = t2.y;
+    }
+    const int nj = min(kChunk, k - j0);
+#pragma unroll
+    for (int jj = 0; jj < kChunk; ++jj) {
+      if (jj < nj) {
+#pragma unroll
+        for (int b = 0; b < NBP; b += 2) {
+          const double2 c2 = *reinterpret_cast<const double2*>(&cbuf[jj * NBP + b]);   // wave-uniform: broadcast
+          out[b] = fma(vv[jj], c2.x, out[b]);
+          if (b + 1 < NB) out[b + 1] = fma(vv[jj], c2.y, out[b + 1]);
+        }
+      }
+      pin_acc<NB>(out);
+    }
+  }
+  wave_lds_sync();
+}
+
+}  // namespace
+
+// per-wave LDS slice (doubles); mirrored by wave_lds_doubles() in letkf_api.hip
+__host__ __device__ inline int wave_slice_doubles(int KR, int nv) {
+  const int nb = nv + 2;
+  int tile = kTnW * 64;                       // obs tile, also reused as vbuf (KR * kVld) and kk-output C chunk
+  const int vb = KR * kVld;
+  if (vb > tile) tile = vb;
+  int bmat = ((nb + 1) & ~1) * KR;            // B vectors [KR][NBP]; reused as the T/Pa C chunk (kChunk * KR)
+  if (kChunk * KR > bmat) bmat = kChunk * KR;
+  const int cb = kChunk * ((nb + 1) & ~1);
+  const int small = 3 * kTnW + 8 * nv + 16;
+  int tot = tile + bmat + cb + small;
+  return (tot + 1) & ~1;
+}
+
+// KKOUT: also materialise T / Pa (fine boundary, parity, diagnostics) -- a separate instantiation so that the
+// production kernel carries neither the code nor the registers for it.
+template <int KR, int NV, bool KKOUT>
+__global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int NB = NV + 2;
+  constexpr int NBP = (NB + 1) & ~1;
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int k = A.k;
+  const int nv = A.nv;                        // == NV on the das path, 0 on the letkf_core batch path
+  const double km1 = (double)(k - 1);
+
+  double* slice = smem + (size_t)wv * wave_slice_doubles(KR, NV);
+  int tile_sz = kTnW * 64;
+  if (KR * kVld > tile_sz) tile_sz = KR * kVld;
+  int bmat_sz = NBP * KR;
+  if (kChunk * KR > bmat_sz) bmat_sz = kChunk * KR;
+  double* ytile = slice;                      // [kTnW][64]
+  double* vbuf = slice;                       // [KR][kVld]          (after the Gram phase)
+  double* bmat = slice + tile_sz;             // [KR][NBP]
+  double* cbuf = bmat + bmat_sz;              // [kChunk][NBP]
+  double* wrow = cbuf + kChunk * NBP;         // 3 * kTnW
+  double* xsm = wrow + 3 * kTnW;              // 8 * NV + 16
+  double* xmean = xsm;
+  double* xdet = xsm + NV;
+
+  // 4 consecutive points share a workgroup; workgroups are dealt over the XCDs so that neighbouring
+  // points (which gather almost the same obs rows) hit the same L2
+  const long nB = (A.npts + 3) >> 2;
+  for (long B = blockIdx.x; B < nB; B += gridDim.x) {
+    const long pt = xcd_remap_w(B, nB) * 4 + wv;
+    if (pt >= A.npts) continue;
+    long o0 = 0;
+    int n = 0;
+    double beta = 1.0;
+    if (A.mode == 0) {
+      o0 = A.obs_off[pt];
+      n = (int)(A.obs_off[pt + 1] - o0);
+      if (A.beta) beta = A.beta[pt];
+    } else {
+      n = A.nobsl[pt];
+    }
+    // per-lane member offset, laundered so that LICM does not park 2*NV hoisted 64-bit offsets in VGPRs
+    long moff = (long)lane * A.sm;
+    asm volatile("" : "+v"(moff));
+    const double* g0 = A.gues ? A.gues + pt * A.sp : nullptr;
+    double* a0 = A.anal ? A.anal + pt * A.sp : nullptr;
+
+    if (A.mode == 0 && beta == 0.0) {          // letkf_tools.f90:333-359
+      for (int v = 0; v < nv; ++v) {
+        if (lane < k) a0[moff + v * A.sv] = g0[k * A.sm + v * A.sv] + g0[moff + v * A.sv];
+      }
+      if (A.det_run && lane < nv) a0[(k + 1) * A.sm + lane * A.sv] = g0[(k + 1) * A.sm + lane * A.sv];
+      if (lane == 0) {
+        if (A.status) A.status[pt] = 0;
+        if (A.nsweep) A.nsweep[pt] = 0;
+      }
+      continue;
+    }
+
+    bool qskip = false;
+    if (A.mode == 0 && A.q_update_top > 0.0) qskip = g0[k * A.sm + A.iv_p * A.sv] < A.q_update_top;
+    int v0 = 0;
+    if (qskip)
+      while (v0 < nv && v0 >= A.iv_q_first && v0 <= A.iv_q_last) ++v0;
+    double* infl_p = (A.mode == 0) ? ((v0 < nv) ? &A.infl[pt + A.npts * (long)v0] : nullptr) : &A.infl[pt];
+    const double infl_old = infl_p ? *infl_p : 1.0;
+
+    // ------------------------------------------------------------ Gram: lane j accumulates column j of Ys^T Ys
+    double g[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) g[r] = 0.0;
+    double racc = 0.0, rdacc = 0.0, p1 = 0.0, p3 = 0.0;
+    int sweeps = 0;
+    double lam = km1 / infl_old;               // n == 0: T = sqrt(rho) I, Pa = rho/(k-1) I (common_letkf.f90:89-107)
+
+    if (n > 0) {
+      for (int i0 = 0; i0 < n; i0 += kTnW) {
+        const int ni = min(kTnW, n - i0);
+        wave_lds_sync();
+        if (lane < ni) {
+          double w, d, dd = 0.0, rl;
+          if (A.mode == 0) {
+            const long e = o0 + i0 + lane;
+            const int iob = A.obs_idx[e];
+            rl = A.rloc_l[e];
+            w = 1.0 / A.rdiag_l[e];
+            d = A.dep[iob];
+            if (A.det_run) dd = A.ensval[(long)iob * A.kld + k];
+          } else {
+            const long e = pt * (long)A.nobs + i0 + lane;
+            rl = A.rloc[e];
+            w = A.rdiag_wloc ? 1.0 / A.rdiag[e] : rl / A.rdiag[e];
+            d = A.depv[e];
+            if (A.depd) dd = A.depd[e];
+          }
+          const double sw = sqrt(w);
+          wrow[lane] = sw;
+          wrow[kTnW + lane] = sw * d;
+          wrow[2 * kTnW + lane] = sw * dd;
+          p1 = fma(d * d, w, p1);
+          p3 += rl;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < kTnW; ++i) {
+          double y = 0.0;
+          if (i < ni && lane < k) {
+            if (A.mode == 0) y = A.ensval[(long)A.obs_idx[o0 + i0 + i] * A.kld + lane];
+            else y = A.hdxb[(size_t)pt * (size_t)A.nobs * (size_t)k + (size_t)lane * A.nobs + i0 + i];
+            y *= wrow[i];
+          }
+          ytile[i * 64 + lane] = y;
+        }
+        wave_lds_sync();
+#pragma unroll 1
+        for (int i = 0; i < ni; ++i) {
+          const double yo = ytile[i * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < KR; r += 2) {
+            const double2 y2 = *reinterpret_cast<const double2*>(&ytile[i * 64 + r]);   // broadcast
+            g[r] = fma(yo, y2.x, g[r]);
+            g[r + 1] = fma(yo, y2.y, g[r + 1]);
+          }
+          racc = fma(yo, wrow[kTnW + i], racc);
+          rdacc = fma(yo, wrow[2 * kTnW + i], rdacc);
+        }
+      }
+      // diagonal: trace for the adaptive inflation, then the shift (common_letkf.f90:140-143)
+      const double shift = km1 / infl_old;
+      double diag = 0.0;
+#pragma unroll
+      for (int r = 0; r < KR; ++r) {
+        if (r == lane && lane < k) {
+          diag = g[r];
+          g[r] += shift;
+        }
+      }
+      double parm1 = 0.0, parm2 = 0.0, parm3 = 0.0;
+      if (A.infl_adaptive) {
+        parm1 = wave_sum(p1);
+        parm3 = wave_sum(p3);
+        parm2 = wave_sum(lane < k ? diag : 0.0) / km1;
+      }
+
+      // ------------------------------------------------------------ eigen-decomposition in registers
+      sweeps = jacobi_regs<KR>(g, k, A.max_sweep);
+
+      double ss = 0.0;
+#pragma unroll
+      for (int r = 0; r < KR; ++r) ss = fma(g[r], g[r], ss);
+      lam = sqrt(ss);
+      const double il = (lane < k) ? 1.0 / lam : 0.0;
+#pragma unroll
+      for (int r = 0; r < KR; ++r) g[r] *= il;
+
+      // adaptive inflation (common_letkf.f90:233-254), old rho everywhere above
+      if (A.infl_adaptive) {
+        const double parm4 = (parm1 - parm3) / parm2 - infl_old;
+        const double tq = (infl_old * parm2 + parm3) / parm2;
+        const double sigma_o = 2.0 / parm3 * (tq * tq);
+        const double gain = 0.04 * 0.04 / (sigma_o + 0.04 * 0.04);
+        p1 = infl_old + gain * parm4;            // reuse p1 as infl_new
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < KR; ++r) g[r] = (r == lane && lane < k) ? 1.0 : 0.0;
+    }
+    const double infl_new = (A.infl_adaptive && n > 0) ? p1 : infl_old;
+
+    // ------------------------------------------------------------ status (common_mtx.f90:66-78)
+    int st = 0;
+    {
+      const double lmx = wave_max(lane < k ? lam : 0.0);
+      const double lmn = wave_min(lane < k ? lam : 1e300);
+      if (sweeps >= A.max_sweep && A.max_sweep >= 60) st = 1;
+      else if (!(lmx > 0.0)) st = 2;
+      else if (lmn < lmx * 1.4901161193847656e-08) st = 3;
+    }
+    const double sc1 = (lane < k) ? sqrt(km1 / lam) : 0.0;    // T spectrum
+    const double sc2 = (lane < k) ? 1.0 / lam : 0.0;          // Pa spectrum
+
+    // ------------------------------------------------------------ B = [r, r_det, x'_v] as bmat[m][NBP]; U = V^T B
+    wave_lds_sync();
+    if (lane < KR) {
+      bmat[lane * NBP + 0] = (lane < k) ? racc : 0.0;
+      bmat[lane * NBP + 1] = (lane < k) ? rdacc : 0.0;
+      if (NBP > NB) bmat[lane * NBP + NB] = 0.0;
+    }
+    if (NV > 0) {
+      const double* gp = g0 + moff;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const double x = (lane < k) ? *gp : 0.0;
+        gp += A.sv;
+        if (lane < KR) bmat[lane * NBP + 2 + v] = x;
+      }
+      if (lane < NV) {
+        xmean[lane] = g0[k * A.sm + lane * A.sv];
+        xdet[lane] = A.det_run ? g0[(k + 1) * A.sm + lane * A.sv] : 0.0;
+      }
+    }
+    wave_lds_sync();
+    double crow[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) crow[b] = 0.0;
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+#pragma unroll
+      for (int b = 0; b < NBP; b += 2) {
+        const double2 b2 = *reinterpret_cast<const double2*>(&bmat[r * NBP + b]);   // broadcast
+        crow[b] = fma(g[r], b2.x, crow[b]);
+        if (b + 1 < NB) crow[b + 1] = fma(g[r], b2.y, crow[b + 1]);
+      }
+      if ((r & 1) == 1) pin_acc<NB>(crow);
+    }
+    // RTPS factor per variable (letkf_tools.f90:1982-1999), kept in SGPRs: var_a = x'^T Pa x' = sum_j U_jv^2 / lam_j
+    double cf[NV > 0 ? NV : 1];
+    const int mrow_l = lane < KR ? lane : KR - 1;
+    if (NV > 0) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        double cfv = 1.0;
+        if (A.relax_alpha != 0.0) {
+          cfv = 1.0 - A.relax_alpha;
+        } else if (A.relax_alpha_spread != 0.0) {
+          const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391
+          const double x = (lane < k) ? bmat[mrow_l * NBP + 2 + v] : 0.0;
+          const double var_g = wave_sum(x * x);
+          const double var_a = wave_sum(crow[2 + v] * crow[2 + v] * sc2);
+          if (var_g > 0.0 && var_a > 0.0)
+            cfv = A.relax_alpha_spread * sqrt(var_g * parm / (var_a * km1)) - A.relax_alpha_spread + 1.0;
+        }
+        cf[v] = uniform(cfv);
+      }
+    }
+    // C = D U : w-bar spectrum 1/lam, T spectrum sqrt((k-1)/lam)
+    crow[0] *= sc2;
+    crow[1] *= sc2;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) crow[2 + v] *= sc1;
+
+    double out[NB];
+    rows_times_c<KR, NB>(g, crow, out, k, vbuf, cbuf);   // lane m: out[0] = w-bar_m, out[1] = w-bar_det_m, out[2+v] = (T x'_v)_m
+
+    // ------------------------------------------------------------ analysis members (letkf_tools.f90:472-513)
+    if (NV > 0 && A.mode == 0) {
+      double* ap = a0 + moff;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
+        const double x = (lane < k) ? bmat[mrow_l * NBP + 2 + v] : 0.0;
+        const double sdot = wave_sum(x * out[0]);
+        const double sdotd = A.det_run ? wave_sum(x * out[1]) : 0.0;
+        const double xm = xmean[v];
+        double val;
+        if (skip) {
+          val = xm + x;
+        } else {
+          double cdv = 0.0;
+          if (A.relax_alpha != 0.0) {              // RTPP diagonal term alpha*sqrt(parm), parm read before the update
+            const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;
+            cdv = A.relax_alpha * sqrt(parm);
+          }
+          const double pert = cf[v] * out[2 + v] + cdv * x;
+          val = xm + beta * (pert + sdot) + (1.0 - beta) * x;
+          if (A.q_sprd_max > 0.0 && v == A.iv_q_first) {      // :500-513
+            const double q_mean = wave_sum(lane < k ? val : 0.0) / (double)k;
+            const double dq = (lane < k) ? val - q_mean : 0.0;
+            const double q_sprd = sqrt(wave_sum(dq * dq) / km1) / q_mean;
+            if (q_sprd > A.q_sprd_max) val = q_mean + dq * A.q_sprd_max / q_sprd;
+          }
+        }
+        if (lane < k) *ap = val;
+        ap += A.sv;
+        if (A.det_run && lane == 0)
+          a0[(k + 1) * A.sm + v * A.sv] = skip ? xdet[v] : xdet[v] + sdotd * beta;     // :489-497
+      }
+      if (A.infl_adaptive && n > 0) {              // :396-398, after every parm read above
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
+          if (!skip && lane == 0) A.infl[pt + A.npts * (long)v] = infl_new;
+        }
+      }
+    } else if (A.infl_adaptive && n > 0 && lane == 0) {
+      A.infl[pt] = infl_new;
+    }
+
+    // ------------------------------------------------------------ optional outputs
+    if (A.transm_out && lane < k) A.transm_out[(size_t)pt * k + lane] = out[0];
+    if (A.transmd_out && lane < k) A.transmd_out[(size_t)pt * k + lane] = out[1];
+    if (KKOUT && (A.trans_out || A.pa_out)) {
+      // T = V diag(sc1) V^T and Pa = V diag(sc2) V^T: same row-gather with C[j][:] = sc * v_j
+      #pragma unroll 1
+      for (int which = 0; which < 2; ++which) {
+        double* dst = which == 0 ? A.trans_out : A.pa_out;
+        if (!dst) continue;
+        dst += (size_t)pt * k * k;
+        const double sc = which == 0 ? sc1 : sc2;
+        double kk[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) kk[r] = 0.0;
+        double* ckk = bmat;                       // [kChunk][KR], B vectors are dead by now
+        for (int j0 = 0; j0 < k; j0 += kChunk) {
+          wave_lds_sync();
+          if (lane >= j0 && lane < j0 + kChunk) {
+            const int jj = lane - j0;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+              vbuf[r * kVld + jj] = g[r];
+              ckk[jj * KR + r] = sc * g[r];
+            }
+          }
+          wave_lds_sync();
+          const int mrow = lane < KR ? lane : KR - 1;
+          const int nj = min(kChunk, k - j0);
+          for (int jj = 0; jj < nj; ++jj) {
+            const double vv = vbuf[mrow * kVld + jj];
+#pragma unroll
+            for (int r = 0; r < KR; r += 2) {
+              const double2 c2 = *reinterpret_cast<const double2*>(&ckk[jj * KR + r]);
+              kk[r] = fma(vv, c2.x, kk[r]);
+              kk[r + 1] = fma(vv, c2.y, kk[r + 1]);
+            }
+          }
+        }
+        wave_lds_sync();
+        // lane m holds row m; the matrices are symmetric, so write it as column m (coalescing is irrelevant here)
+        if (lane < k) {
+          const double add = (which == 0 && A.add_wbar_to_trans) ? 1.0 : 0.0;
+          // trans(i,j) += w-bar(i) (common_letkf.f90:221-225): row i gets w-bar_i in every column
+#pragma unroll
+          for (int r = 0; r < KR; ++r)
+            if (r < k) dst[(size_t)r * k + lane] = kk[r] + add * out[0];
+        }
+      }
+    }
+    if (lane == 0) {
+      if (A.status) A.status[pt] = st;
+      if (A.nsweep) A.nsweep[pt] = sweeps;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host launcher
+template <int KR, int NV, bool KKOUT>
+static hipError_t launch_wave(const PointArgs& a, int grid, hipStream_t st) {
+  const size_t lds = (size_t)4 * wave_slice_doubles(KR, NV) * sizeof(double);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_wave_kernel<KR, NV, KKOUT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((letkf_wave_kernel<KR, NV, KKOUT>), dim3(grid), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+bool wave_kernel_supports(int k, int nv, int mode) {
+  if (k > 64) return false;
+  if (mode == 0) return nv == 11;
+  return nv == 0;
+}
+
+hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st) {
+  const long nwg = (a.npts + 3) / 4;
+  long g = (long)num_cu * 16;
+  const int grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
+  const int k = a.k;
+  const bool kkout = a.trans_out || a.pa_out;
+#define LETKF_WAVE_CASE(KR)                                                            \
+  if (k <= KR) {                                                                       \
+    if (a.mode == 0)                                                                   \
+      return kkout ? launch_wave<KR, 11, true>(a, grid, st) : launch_wave<KR, 11, false>(a, grid, st); \
+    return launch_wave<KR, 0, true>(a, grid, st);                                      \
+  }
+  LETKF_WAVE_CASE(16)
+  LETKF_WAVE_CASE(32)
+  LETKF_WAVE_CASE(48)
+  LETKF_WAVE_CASE(50)
+  LETKF_WAVE_CASE(64)
+#undef LETKF_WAVE_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace letkf
