@@ -67,22 +67,20 @@ def main():
     nsweep = torch.zeros(npts, dtype=torch.int32, device=dev)
     relax = dict(rtps=dict(relax_alpha_spread=0.95), rtpp=dict(relax_alpha=0.7), none=dict())[args.relax]
 
-    # N>1: each rank contributes a 1/N shard of its obs table rows; the step all-gathers them (RCCL over xGMI)
+    # N>1: each rank owns a ragged 1/N shard of the rows of its obs table; every step starts with the path's one
+    # exchange, the ALLGATHERV of those shards over RCCL (scale-letkf_amd/sharding.py, covered by the gloo test)
     shard = None
     if world > 1:
+        import importlib
+        sharding = importlib.import_module("scale_letkf_amd.sharding")
         rows = w["ensval"].shape[0]
-        per = (rows + world - 1) // world
-        pad = per * world
-        full = torch.zeros(pad, w["kld"], dtype=torch.float64, device=dev)
-        full[:rows] = w["ensval"]
-        shard = full[rank * per:(rank + 1) * per].clone()
-        gathered = torch.empty_like(full)
+        cuts = [round(rows * r / world) for r in range(world + 1)]
+        shard = w["ensval"][cuts[rank]:cuts[rank + 1]].clone()
 
     def step():
         ens = w["ensval"]
         if world > 1:
-            dist.all_gather_into_tensor(gathered, shard)
-            ens = gathered
+            ens, _ = sharding.allgatherv_rows(shard)
         ctx.das_points(k, nv, w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"], ens, w["kld"], w["dep"], infl,
                        w["gues"], anal, w["sp"], w["sm"], w["sv"], status=status, nsweep=nsweep, **relax)
 
@@ -131,7 +129,7 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
-                    "kernel": "letkf_point_kernel", "kernel_ms": kern_ms, "launches": nlaunch,
+                    "kernel": "letkf_wave_kernel<50,11>" if k <= 64 else "letkf_point_kernel", "kernel_ms": kern_ms, "launches": nlaunch,
                     "alg_bytes_per_solve": b_alg, "alg_flops_per_solve": f_alg,
                     "fp64_tflops": (f_alg * npts / kern_s / 1e12) if kern_s > 0 else None,
                     "fp64_frac_of_78.6": (f_alg * npts / kern_s / 78.6e12) if kern_s > 0 else None}

@@ -1,0 +1,67 @@
+"""Grid-point sharding across the GPUs of one node and the one exchange the path has.
+
+The analysis is embarrassingly parallel over grid points (scale/letkf/letkf_tools.f90:313-686 has no communication
+inside the loop); what the reference exchanges BEFORE the loop is the QC-passed observation table, with
+MPI_ALLGATHERV over the subdomain communicator (scale/letkf/letkf_obs.f90:1036-1046), after which every rank keeps
+the rows that fall into its extended (halo) region (:1059-1109).  Here: one process per GPU, torch.distributed
+(backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests), the same two partitions the reference
+offers -- horizontal tiles (MPI_COMM_d) and cyclic dealing of points (MPI_COMM_e, common_mpi_scale.f90:1428-1455).
+Plumbing only: no numerics live here.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def tile_grid(world):
+    """px x py process lattice, as square as possible (PRC_NUM_X x PRC_NUM_Y)."""
+    px = int(math.sqrt(world))
+    while world % px:
+        px -= 1
+    return world // px, px
+
+
+def tile_partition(nx, ny, world):
+    """Horizontal tiles [i0, i1) x [j0, j1) per rank, rank = ix + px*iy."""
+    px, py = tile_grid(world)
+    xs = [round(nx * i / px) for i in range(px + 1)]
+    ys = [round(ny * j / py) for j in range(py + 1)]
+    return [(xs[r % px], xs[r % px + 1], ys[r // px], ys[r // px + 1]) for r in range(world)]
+
+
+def cyclic_points(nij, rank, world):
+    """The reference's cyclic dealing: local point i of ensemble-rank m is subdomain point m + world*i
+    (scale/common/common_mpi_scale.f90:1428-1455, grd_to_buf)."""
+    return torch.arange(rank, nij, world, dtype=torch.int64)
+
+
+def allgatherv_rows(shard, group=None):
+    """ALLGATHERV of row blocks with different row counts per rank (letkf_obs.f90:1036-1046): all ranks end up
+    with the rows of rank 0, then rank 1, ... .  Implemented as one all_gather of the counts and one
+    all_gather_into_tensor on max-padded blocks (a single large collective per array: on xGMI a ring is per-link
+    bound, so fewer, larger messages win), then a compaction on the receiving side."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([shard.shape[0]], dtype=torch.int64, device=shard.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    nmax = max(counts) if counts else 0
+    if nmax == 0:
+        return shard.new_zeros((0,) + tuple(shard.shape[1:])), counts
+    padded = shard.new_zeros((nmax,) + tuple(shard.shape[1:]))
+    padded[: shard.shape[0]] = shard
+    out = shard.new_empty((world * nmax,) + tuple(shard.shape[1:]))
+    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    if all(c == nmax for c in counts):
+        return out, counts
+    keep = torch.cat([torch.arange(r * nmax, r * nmax + counts[r], device=shard.device) for r in range(world)])
+    return out.index_select(0, keep), counts
+
+
+def halo_rows(ri, rj, tile, halo_i, halo_j):
+    """Indices of the gathered rows whose fractional grid position (ri, rj) lies in the tile extended by the
+    localisation halo (the reference's extended subdomain, letkf_obs.f90:922-976, 1059-1109)."""
+    i0, i1, j0, j1 = tile
+    ok = (ri >= i0 - halo_i) & (ri < i1 + halo_i) & (rj >= j0 - halo_j) & (rj < j1 + halo_j)
+    return ok.nonzero(as_tuple=False).squeeze(1)
