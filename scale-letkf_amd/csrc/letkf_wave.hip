@@ -28,7 +28,10 @@ namespace letkf {
 
 namespace {
 
+typedef double v4d __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ double wshfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ double wshfl(double v, int src) { return __shfl(v, src, 64); }
 
 // DPP cross-lane move of a double (two 32-bit VALU movs, no LDS crossbar).  CTRL is a gfx9 dpp_ctrl code:
 // 0xB1 quad_perm[1,0,3,2] (lane^1), 0x4E quad_perm[2,3,0,1] (lane^2), 0x1B quad_perm[3,2,1,0] (lane^3),
@@ -97,7 +100,8 @@ __device__ __forceinline__ long xcd_remap_w(long orig, long n) {
 }
 
 constexpr double kRotTol2W = 1e-30;   // rotate when cos^2 > 1e-30
-constexpr double kStopTol2W = 1e-22;  // sweep counts as converged when every visited pair had |cos| <= 1e-11
+constexpr double kStopTol2W = 1e-20;  // sweep counts as converged when every visited pair had |cos| <= 1e-10 (all of them were
+                                      // still rotated away in that sweep, so what is left is second order)
 constexpr int kTnW = 8;               // obs rows per LDS tile (per wave)
 constexpr int kChunk = 8;             // columns per LDS transposition chunk
 constexpr int kVld = kChunk + 2;      // row stride of the transposition buffer (doubles, even)
@@ -111,6 +115,17 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   y = fma(y * 0.5, e, y);
   e = fma(-x * y, y, 1.0);
   return fma(y * 0.5, e, y);
+}
+// one Newton step (~2^-46): enough for the rotation ANGLE, whose error only leaves a second-order residual
+__device__ __forceinline__ double fast_rsqrt1(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y, y, 1.0);
+  return fma(y * 0.5, e, y);
+}
+__device__ __forceinline__ double fast_rcp1(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, r, 1.0);
+  return fma(r, e, r);
 }
 __device__ __forceinline__ double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
@@ -136,7 +151,7 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // rotation identities alpha' = alpha -/+ t*gamma.  Both are refreshed once per sweep.
 // ---------------------------------------------------------------------------------------------
 template <int KR>
-__device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const int max_sweep) {
+__device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const int max_sweep, double* xbuf, const int jmix) {
   const int lane = threadIdx.x & 63;
   const bool oddlane = (lane & 1) != 0;
   int sweep = 0;
@@ -162,7 +177,8 @@ __device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const i
       double h[KR];
       double be, isq, scq;
       double ga0 = 0.0, ga1 = 0.0;
-      if (!oddstep) {
+      const bool use_lds = oddstep ? (jmix & 1) != 0 : ((jmix & 4) != 0 || ((jmix & 2) != 0 && (t & 2) != 0));
+      if (!oddstep && !use_lds) {
 #pragma unroll
         for (int r = 0; r < KR; r += 2) {
           h[r] = dpp_mov<0xB1>(g[r]);
@@ -173,7 +189,8 @@ __device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const i
         be = dpp_mov<0xB1>(al);
         isq = dpp_mov<0xB1>(is);
         scq = dpp_mov<0xB1>(sc);
-      } else {
+      } else if (!use_lds) {
+        // odd step on the VALU: wave_shl:1 / wave_shr:1 + select
 #pragma unroll
         for (int r = 0; r < KR; r += 2) {
           const double u0 = dpp_mov<0x130>(g[r]), d0 = dpp_mov<0x138>(g[r]);          // lane+1 / lane-1
@@ -189,6 +206,44 @@ __device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const i
         be = oddlane ? bu : bd;
         isq = oddlane ? iu : id;
         scq = oddlane ? su : sd;
+      } else {
+        // odd steps: partner is lane+1 (odd lanes) / lane-1 (even lanes).  On the VALU that costs two DPP moves and
+        // a select per dword (300 ops); instead the columns go through a small LDS buffer in row chunks with
+        // b128 accesses (2*KR/ (2) LDS instructions, conflict-free at a lane stride of 10 doubles), which moves this
+        // half of the exchange from the saturated VALU to the otherwise idle LDS pipe.
+        constexpr int CR = (KR % 10 == 0) ? 10 : 8;          // rows per chunk
+        constexpr int LS = 10;                                // lane stride in doubles
+        const int plc = pl < 0 ? 0 : (pl > 63 ? 63 : pl);
+        double* mine = xbuf + lane * LS;
+        const double* theirs = xbuf + plc * LS;
+        double* smine = xbuf + 64 * LS + lane * 4;
+        const double* stheirs = xbuf + 64 * LS + plc * 4;
+        smine[0] = al;
+        smine[1] = is;
+        smine[2] = sc;
+#pragma unroll
+        for (int c0 = 0; c0 < KR; c0 += CR) {
+          wave_lds_sync();
+#pragma unroll
+          for (int e = 0; e < CR; e += 2) {
+            if (c0 + e < KR) *reinterpret_cast<double2*>(&mine[e]) = double2{g[c0 + e], g[c0 + e + 1]};
+          }
+          wave_lds_sync();
+#pragma unroll
+          for (int e = 0; e < CR; e += 2) {
+            if (c0 + e < KR) {
+              const double2 t2 = *reinterpret_cast<const double2*>(&theirs[e]);
+              h[c0 + e] = t2.x;
+              h[c0 + e + 1] = t2.y;
+              ga0 = fma(g[c0 + e], t2.x, ga0);
+              ga1 = fma(g[c0 + e + 1], t2.y, ga1);
+            }
+          }
+        }
+        be = stheirs[0];
+        isq = stheirs[1];
+        scq = stheirs[2];
+        wave_lds_sync();
       }
       const double ga = (ga0 + ga1) * (is * isq);          // true inner product
       const bool lo = lane < pl;
@@ -199,8 +254,8 @@ __device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const i
       // tan(2 theta) = 2 ga / (b - a);  t = 2 ga sgn(d) / (|d| + sqrt(d^2 + 4 ga^2))
       const double d = b - a;
       const double x = fma(d, d, 4.0 * g2);
-      const double hh = x * fast_rsqrt(x);
-      double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp(fabs(d) + hh);
+      const double hh = x * fast_rsqrt1(x);
+      double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
       tt = rot ? tt : 0.0;
       const double w = fma(tt, tt, 1.0);
       const double c = fast_rsqrt(w);                      // cos
@@ -284,6 +339,7 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv) {
   if (kChunk * KR > bmat) bmat = kChunk * KR;
   const int cb = kChunk * ((nb + 1) & ~1);
   const int small = 3 * kTnW + 8 * nv + 16;
+  if (tile + bmat < 64 * 18) bmat = 64 * 18 - tile;   // the Gram transposition buffer abuf[64][18] spans tile + bmat
   int tot = tile + bmat + cb + small;
   return (tot + 1) & ~1;
 }
@@ -306,6 +362,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
   if (KR * kVld > tile_sz) tile_sz = KR * kVld;
   int bmat_sz = NBP * KR;
   if (kChunk * KR > bmat_sz) bmat_sz = kChunk * KR;
+  if (tile_sz + bmat_sz < 64 * 18) bmat_sz = 64 * 18 - tile_sz;
   double* ytile = slice;                      // [kTnW][64]
   double* vbuf = slice;                       // [KR][kVld]          (after the Gram phase)
   double* bmat = slice + tile_sz;             // [KR][NBP]
@@ -357,66 +414,139 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
     double* infl_p = (A.mode == 0) ? ((v0 < nv) ? &A.infl[pt + A.npts * (long)v0] : nullptr) : &A.infl[pt];
     const double infl_old = infl_p ? *infl_p : 1.0;
 
-    // ------------------------------------------------------------ Gram: lane j accumulates column j of Ys^T Ys
+    // ------------------------------------------------------------ Gram on the FP64 matrix cores
+    // A_aug = Ya^T Ya with Ya = sqrt(w) * [y_1 .. y_k | dep | dep_det]  (n x (k+2)), v_mfma_f64_16x16x4:
+    // 4 obs per step.  Lane l supplies, for member block I, Ya[obs0 + (l>>4)][16 I + (l&15)] -- the SAME register
+    // is the A operand of tile (I,*) and the B operand of tile (*,I), so the rows are loaded straight from the obs
+    // table into MFMA operand layout (128-B coalesced segments), no LDS staging, no broadcast reads; only the
+    // tiles I <= J are accumulated.  Column k of A_aug is r = Ys^T sqrt(w) dep, column k+1 the deterministic one,
+    // entry (k,k) = sum w dep^2 (parm(1) of the adaptive inflation, common_letkf.f90:233-237).
     double g[KR];
-#pragma unroll
-    for (int r = 0; r < KR; ++r) g[r] = 0.0;
     double racc = 0.0, rdacc = 0.0, p1 = 0.0, p3 = 0.0;
     int sweeps = 0;
     double lam = km1 / infl_old;               // n == 0: T = sqrt(rho) I, Pa = rho/(k-1) I (common_letkf.f90:89-107)
 
     if (n > 0) {
-      for (int i0 = 0; i0 < n; i0 += kTnW) {
-        const int ni = min(kTnW, n - i0);
-        wave_lds_sync();
-        if (lane < ni) {
-          double w, d, dd = 0.0, rl;
+      constexpr int NBLK = (KR + 2 + 15) / 16;                 // member blocks incl. the 2 augmented columns
+      constexpr int NTILE = NBLK * (NBLK + 1) / 2;
+      v4d acc[NTILE];
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+      const int q = lane >> 4, c16 = lane & 15;
+
+      // software pipeline: meta (index, weights) two chunks ahead, rows one chunk ahead
+      auto load_meta = [&](int i0, long& rowbase, double& sw, double& d, double& dd, double& rl, bool& ok) {
+        const int i = i0 + q;
+        ok = i < n;
+        rowbase = 0;
+        sw = 0.0; d = 0.0; dd = 0.0; rl = 0.0;
+        if (ok) {
+          double w;
           if (A.mode == 0) {
-            const long e = o0 + i0 + lane;
+            const long e = o0 + i;
             const int iob = A.obs_idx[e];
             rl = A.rloc_l[e];
             w = 1.0 / A.rdiag_l[e];
             d = A.dep[iob];
-            if (A.det_run) dd = A.ensval[(long)iob * A.kld + k];
+            rowbase = (long)iob * A.kld;
+            if (A.det_run) dd = A.ensval[rowbase + k];
           } else {
-            const long e = pt * (long)A.nobs + i0 + lane;
+            const long e = pt * (long)A.nobs + i;
             rl = A.rloc[e];
             w = A.rdiag_wloc ? 1.0 / A.rdiag[e] : rl / A.rdiag[e];
             d = A.depv[e];
             if (A.depd) dd = A.depd[e];
+            rowbase = pt * (long)A.nobs * (long)k + i;
           }
-          const double sw = sqrt(w);
-          wrow[lane] = sw;
-          wrow[kTnW + lane] = sw * d;
-          wrow[2 * kTnW + lane] = sw * dd;
-          p1 = fma(d * d, w, p1);
-          p3 += rl;
+          sw = sqrt(w);
         }
-        wave_lds_sync();
+      };
+      auto load_rows = [&](long rowbase, bool ok, double (&f)[NBLK]) {
 #pragma unroll
-        for (int i = 0; i < kTnW; ++i) {
+        for (int I = 0; I < NBLK; ++I) {
+          const int m = 16 * I + c16;
           double y = 0.0;
-          if (i < ni && lane < k) {
-            if (A.mode == 0) y = A.ensval[(long)A.obs_idx[o0 + i0 + i] * A.kld + lane];
-            else y = A.hdxb[(size_t)pt * (size_t)A.nobs * (size_t)k + (size_t)lane * A.nobs + i0 + i];
-            y *= wrow[i];
+          if (ok && m < k) y = (A.mode == 0) ? A.ensval[rowbase + m] : A.hdxb[rowbase + (long)m * A.nobs];
+          f[I] = y;
+        }
+      };
+
+      long rb0, rb1;
+      double sw0, d0, dd0, rl0, sw1, d1, dd1, rl1;
+      bool ok0, ok1;
+      double f0[NBLK], f1[NBLK];
+      load_meta(0, rb0, sw0, d0, dd0, rl0, ok0);
+      load_rows(rb0, ok0, f0);
+      load_meta(4, rb1, sw1, d1, dd1, rl1, ok1);
+      for (int i0 = 0; i0 < n; i0 += 4) {
+        // issue the next chunk's rows and the meta of the chunk after it before touching this chunk's data
+        load_rows(rb1, ok1, f1);
+        long rb2;
+        double sw2, d2, dd2, rl2;
+        bool ok2;
+        load_meta(i0 + 8, rb2, sw2, d2, dd2, rl2, ok2);
+        // augmented columns and scaling of the current chunk
+#pragma unroll
+        for (int I = 0; I < NBLK; ++I) {
+          const int m = 16 * I + c16;
+          double y = f0[I];
+          if (m == k) y = d0;
+          if (m == k + 1) y = dd0;
+          f0[I] = y * sw0;
+        }
+        if (c16 == 0) p3 += rl0;
+        int t = 0;
+#pragma unroll
+        for (int I = 0; I < NBLK; ++I)
+#pragma unroll
+          for (int J = I; J < NBLK; ++J) {
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[I], f0[J], acc[t], 0, 0, 0);
+            ++t;
           }
-          ytile[i * 64 + lane] = y;
+        // rotate the pipeline
+#pragma unroll
+        for (int I = 0; I < NBLK; ++I) f0[I] = f1[I];
+        rb1 = rb2; sw0 = sw1; d0 = d1; dd0 = dd1; rl0 = rl1; ok0 = ok1;
+        sw1 = sw2; d1 = d2; dd1 = dd2; rl1 = rl2; ok1 = ok2;
+      }
+
+      // accumulator tiles -> "lane j owns column j": 16 rows at a time through LDS.  C/D layout of the f64 MFMA:
+      // lane l holds rows (l>>4) + 4*reg, column l&15 of its 16x16 tile.
+      constexpr int LDA = 18;
+      double* abuf = slice;                                    // [64][LDA], spans the tile + bmat regions
+#pragma unroll
+      for (int I = 0; I < NBLK; ++I) {
+        wave_lds_sync();
+#pragma unroll
+        for (int J = 0; J < NBLK; ++J) {
+          const int ti = I <= J ? I : J, tj = I <= J ? J : I;
+          const int t = ti * NBLK - ti * (ti - 1) / 2 + (tj - ti);
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int a = q + 4 * reg, b = c16;                // tile-local (row, col) of this element
+            // rows of block I, columns of block J: element (I:a, J:b) directly, or the mirror of tile (J, I)
+            if (I <= J) abuf[(16 * J + b) * LDA + a] = acc[t][reg];
+            else abuf[(16 * J + a) * LDA + b] = acc[t][reg];
+          }
         }
         wave_lds_sync();
-#pragma unroll 1
-        for (int i = 0; i < ni; ++i) {
-          const double yo = ytile[i * 64 + lane];
 #pragma unroll
-          for (int r = 0; r < KR; r += 2) {
-            const double2 y2 = *reinterpret_cast<const double2*>(&ytile[i * 64 + r]);   // broadcast
-            g[r] = fma(yo, y2.x, g[r]);
-            g[r + 1] = fma(yo, y2.y, g[r + 1]);
+        for (int e = 0; e < 16; e += 2) {
+          if (16 * I + e < KR) {
+            const double2 v2 = *reinterpret_cast<const double2*>(&abuf[lane * LDA + e]);
+            g[16 * I + e] = v2.x;
+            g[16 * I + e + 1] = v2.y;
           }
-          racc = fma(yo, wrow[kTnW + i], racc);
-          rdacc = fma(yo, wrow[2 * kTnW + i], rdacc);
         }
+        if ((k >> 4) == I) racc = abuf[lane * LDA + (k & 15)];
+        if (((k + 1) >> 4) == I) rdacc = abuf[lane * LDA + ((k + 1) & 15)];
       }
+      wave_lds_sync();
+      p1 = wshfl(racc, k);                                     // A_aug[k][k] = sum w dep^2
+      // rows >= k of a column (the augmented rows) and whole columns >= k play no part in the eigenproblem
+#pragma unroll
+      for (int r = 0; r < KR; ++r)
+        if (r >= k || lane >= k) g[r] = 0.0;
       // diagonal: trace for the adaptive inflation, then the shift (common_letkf.f90:140-143)
       const double shift = km1 / infl_old;
       double diag = 0.0;
@@ -429,13 +559,13 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
       }
       double parm1 = 0.0, parm2 = 0.0, parm3 = 0.0;
       if (A.infl_adaptive) {
-        parm1 = wave_sum(p1);
+        parm1 = p1;
         parm3 = wave_sum(p3);
         parm2 = wave_sum(lane < k ? diag : 0.0) / km1;
       }
 
       // ------------------------------------------------------------ eigen-decomposition in registers
-      sweeps = jacobi_regs<KR>(g, k, A.max_sweep);
+      sweeps = jacobi_regs<KR>(g, k, A.max_sweep, slice, A.jmix);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
 
       double ss = 0.0;
 #pragma unroll
@@ -648,7 +778,7 @@ static hipError_t launch_wave(const PointArgs& a, int grid, hipStream_t st) {
 }
 
 bool wave_kernel_supports(int k, int nv, int mode) {
-  if (k > 64) return false;
+  if (k > 62) return false;   // k + 2 augmented Gram columns must fit the 64 lanes
   if (mode == 0) return nv == 11;
   return nv == 0;
 }
