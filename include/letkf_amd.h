@@ -56,7 +56,8 @@ const char *letkf_amd_last_error(void);
 /* Context = device + stream + reusable device workspace.  device_id < 0: current device. */
 int letkf_ctx_create(int device_id, letkf_ctx **ctx);
 int letkf_ctx_destroy(letkf_ctx *ctx);
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the context's own. */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream).  The handle is used as is: NULL selects HIP's
+ * default (null) stream.  A fresh context runs on its own non-blocking stream until this is called. */
 int letkf_ctx_set_stream(letkf_ctx *ctx, void *hip_stream);
 int letkf_ctx_synchronize(letkf_ctx *ctx);
 
@@ -173,6 +174,58 @@ int letkf_ens_to_perturbations_dev(letkf_ctx *ctx, int32_t k, int32_t nv, int64_
                                    int64_t sp, int64_t sm, int64_t sv);
 int letkf_ens_mean_dev(letkf_ctx *ctx, int32_t k, int32_t nv, int64_t npts, double *x, int64_t sp,
                        int64_t sm, int64_t sv);
+
+
+/*---------------------------------------------------------------------------
+ * (3) Local-observation search on the device: obs_local
+ *     scale/letkf/letkf_tools.f90:1325-1759 with obs_local_range (:1765), obs_local_cal (:1793-1906),
+ *     ij_obsgrd_ext / obs_choose_ext (scale/letkf/letkf_obs.f90:1209-1285) and the top-N selection that the
+ *     reference does with QUICKSELECT_arg (common/common_sort.f90:341).  Produces, for a batch of grid points, the
+ *     CSR lists that letkf_das_points_dev consumes, so the lists never exist on the host.
+ *
+ *     Tables = what set_letkf_obs leaves behind (letkf_obs.f90:35-72): the combined obs types ("ctype"), their
+ *     localisation scales, the per-ctype sorting mesh with prefix sums ac_ext, and the obs metadata in
+ *     obsda_sort order.  All three selection modes: no limit (:1438-1476; list order = the reference's: ctype,
+ *     mesh row j, candidate index), limit by distance (:1479-1660), limit by weight / error (:1663-1729).  With a
+ *     limit the selected SET equals the reference's (the N best inside the cut-off; the incremental search of
+ *     :1527-1602 is a pure speed heuristic) up to ties; the order inside the list is
+ *     implementation-defined in the reference too (unstable quick-select).
+ *     The cut-off constants are the reference's single-precision literals (letkf_obs.f90:27-28).
+ *-------------------------------------------------------------------------*/
+typedef struct {
+  int32_t nctype;
+  int32_t ngroup;             /* merged groups (letkf_tools.f90:167-192); a lone ctype is a group of one */
+  int32_t criterion;          /* MAX_NOBS_PER_GRID_CRITERION: 1 distance, 2 weight, 3 error */
+  int32_t nlon, nlat;         /* interior size of the (sub)domain the mesh was built on */
+  int32_t reserved0;
+  double dx, dy;              /* DX, DY */
+  double i_org, j_org;        /* ri - i_org is (ril - IHALO - 0.5) of ij_obsgrd_ext (letkf_obs.f90:1221) */
+  double rain_base;           /* VERT_LOCAL_RAIN_BASE */
+  /* per group [ngroup+1] / members (ctype ids, master first) */
+  const int32_t *group_start;
+  const int32_t *group_member;
+  /* per ctype [nctype] */
+  const int32_t *vmode;       /* vertical coordinate: 0 |dln p| (obs lev), 1 |dz| (type 22), 2 ps (obs dat), 3 rain base */
+  const double *hori_loc;
+  const double *vert_loc;     /* 0 = no vertical localisation */
+  const double *varloc;       /* var_local(nvar, uid_obs_varlocal(elm)) of the variable class; < tiny rejects */
+  const int32_t *max_nobs;    /* MAX_NOBS_PER_GRID of the report type; <= 0: no limit */
+  const int32_t *ngrd_i, *ngrd_j, *ngrdsch_i, *ngrdsch_j, *ngrdext_i, *ngrdext_j;
+  const int64_t *ac_off;      /* start of the ctype's table inside ac_ext */
+  const int32_t *ac_ext;      /* per ctype (ngrdext_i+1) x ngrdext_j: entry (i, j), i = 0..ngrdext_i, j = 1..ngrdext_j at
+                                 ac_off + i + (ngrdext_i+1)*(j-1) = number of table rows before the end of cell (i, j)
+                                 (obsgrd%ac_ext, letkf_obs.f90:60): cell (i,j) owns rows ac(i-1,j) .. ac(i,j)-1, 0-based */
+  /* obs metadata in obsda_sort order [nobstotal] (obs(set)%{ri,rj,lev,dat,err}(idx)) */
+  const double *ob_ri, *ob_rj, *ob_lev, *ob_dat, *ob_err;
+} letkf_search_tables;
+
+/* Points: fractional grid indices ri, rj (rig1, rjg1), pressure rlev (gues3d mean of iv3d_p), height rz (hgt1).
+ * Two-phase CSR build: call with fill = 0 to get counts[npts]; exclusive-scan them into obs_off[npts+1] (any
+ * scan; torch.cumsum in the harness); call again with fill = 1 to write obs_idx / rdiag_l / rloc_l.
+ * All pointers are device pointers (the tables struct itself is passed by value from the host). */
+int letkf_obs_search_dev(letkf_ctx *ctx, const letkf_search_tables *tables, int64_t npts, const double *ri,
+                         const double *rj, const double *rlev, const double *rz, int32_t fill, int32_t *counts,
+                         const int64_t *obs_off, int32_t *obs_idx, double *rdiag_l, double *rloc_l);
 
 /* Kernel timing helper for bench.py: average duration (ms) of the last
  * letkf_das_points_dev / letkf_core_batch_dev launches measured with HIP events on the

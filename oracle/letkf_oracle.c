@@ -650,3 +650,114 @@ int orc_das_letkf_points(const orc_das_params *p, int64_t npts, const int64_t *o
   }
   return worst;
 }
+
+/* common/common_sort.f90:341-369 / :404-432 -- selection semantics only: after the call the first K entries of x
+ * index the K smallest (largest) keys.  The reference's pivot rules (sample_second_min_arg :224, median_of_three_arg
+ * :168) only decide the ORDER inside the two halves, which its callers never rely on
+ * (scale/letkf/letkf_tools.f90:1615-1628 copies the first K in whatever order they come). */
+typedef struct { double key; int32_t id; } orc_kv;
+static int orc_kv_cmp(const void *pa, const void *pb) {
+  const orc_kv *a = (const orc_kv *)pa, *b = (const orc_kv *)pb;
+  if (a->key < b->key) return -1;
+  if (a->key > b->key) return 1;
+  return (a->id > b->id) - (a->id < b->id);
+}
+void orc_select_arg(const double *a, int32_t *x, int n, int K, int desc) {
+  (void)K;
+  orc_kv *kv = (orc_kv *)malloc(sizeof(orc_kv) * (size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; ++i) {
+    kv[i].key = desc ? -a[x[i]] : a[x[i]];
+    kv[i].id = x[i];
+  }
+  qsort(kv, (size_t)n, sizeof(orc_kv), orc_kv_cmp);
+  for (int i = 0; i < n; ++i) x[i] = kv[i].id;
+  free(kv);
+}
+
+/* scale/letkf/letkf_obs.f90:1209-1227 */
+static void orc_ij_obsgrd_ext(const orc_search_tables *t, int ic, double ri, double rj, int *ogi, int *ogj) {
+  *ogi = (int)ceil((ri - t->i_org) * (double)t->ngrd_i[ic] / (double)t->nlon) + t->ngrdsch_i[ic];
+  *ogj = (int)ceil((rj - t->j_org) * (double)t->ngrd_j[ic] / (double)t->nlat) + t->ngrdsch_j[ic];
+}
+
+/* scale/letkf/letkf_tools.f90:1765-1788 */
+static void orc_obs_local_range(const orc_search_tables *t, int ic, double ri, double rj, int *imin, int *imax,
+                                int *jmin, int *jmax) {
+  const double dzi = t->hori_loc[ic] * ORC_DIST_ZERO_FAC / t->dx;
+  const double dzj = t->hori_loc[ic] * ORC_DIST_ZERO_FAC / t->dy;
+  orc_ij_obsgrd_ext(t, ic, ri - dzi, rj - dzj, imin, jmin);
+  orc_ij_obsgrd_ext(t, ic, ri + dzi, rj + dzj, imax, jmax);
+}
+
+static inline int32_t orc_ac(const orc_search_tables *t, int ic, int i, int j) {   /* obsgrd(ic)%ac_ext(i, j) */
+  return t->ac_ext[t->ac_off[ic] + i + (int64_t)(t->ngrdext_i[ic] + 1) * (j - 1)];
+}
+
+int orc_obs_local(const orc_search_tables *t, double ri, double rj, double rlev, double rz, int cap,
+                  int32_t *idx_out, double *rdiag_out, double *rloc_out, double *dist_out) {
+  int nobsl = 0;
+  for (int ig = 0; ig < t->ngroup; ++ig) {                       /* do ic = 1, nctype (masters only) :1426-1432 */
+    const int gs = t->group_start[ig], ge = t->group_start[ig + 1];
+    const int icm = t->group_member[gs];                         /* master ctype :1434-1436 */
+    const int nmax = t->max_nobs[icm];
+    /* candidates of the whole group inside the cut-off rectangles, in the reference's order:
+     * member ctype, mesh row j, table row (obs_choose_ext, letkf_obs.f90:1262-1285) */
+    int ncand = 0, ccap = 256;
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)ccap);
+    double *cr = (double *)malloc(sizeof(double) * (size_t)ccap * 3);   /* rloc, rdiag, dist */
+    for (int m = gs; m < ge; ++m) {
+      const int ic = t->group_member[m];
+      int imin, imax, jmin, jmax;
+      orc_obs_local_range(t, ic, ri, rj, &imin, &imax, &jmin, &jmax);
+      if (imin > imax || jmin > jmax) continue;
+      for (int j = jmin; j <= jmax; ++j)
+        for (int32_t row = orc_ac(t, ic, imin - 1, j); row < orc_ac(t, ic, imax, j); ++row) {
+          double nd, nr;
+          const double rl = orc_obs_local_cal(ri, rj, rlev, rz, t->varloc[ic], t->vmode[ic], t->hori_loc[ic],
+                                              t->vert_loc[ic], t->rain_base, t->ob_ri[row], t->ob_rj[row],
+                                              t->ob_lev[row], t->ob_dat[row], t->ob_err[row], t->dx, t->dy, &nd, &nr);
+          if (rl == 0.0) continue;                               /* :1460 / :1584 / :1684 */
+          if (ncand == ccap) {
+            ccap *= 2;
+            cand = (int32_t *)realloc(cand, sizeof(int32_t) * (size_t)ccap);
+            cr = (double *)realloc(cr, sizeof(double) * (size_t)ccap * 3);
+          }
+          cand[ncand] = row;
+          cr[3 * ncand] = rl;
+          cr[3 * ncand + 1] = nr;
+          cr[3 * ncand + 2] = nd;
+          ++ncand;
+        }
+    }
+    int nsel = ncand;
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ncand > 0 ? ncand : 1));
+    for (int i = 0; i < ncand; ++i) order[i] = i;
+    if (nmax > 0 && ncand > nmax) {
+      /* :1614-1617 (criterion 1: the N nearest inside the cut-off -- the incremental rectangle search of
+       * :1527-1602 only bounds the work, any obs within normalised distance q*search_incr/hori_loc lies inside the
+       * q-th rectangle, so the selected set is the same), :1694-1704 (criterion 2: largest rloc, 3: smallest rdiag) */
+      double *key = (double *)malloc(sizeof(double) * (size_t)ncand);
+      for (int i = 0; i < ncand; ++i)
+        key[i] = (t->criterion == 1) ? cr[3 * i + 2] : (t->criterion == 2) ? cr[3 * i] : cr[3 * i + 1];
+      orc_select_arg(key, order, ncand, nmax, t->criterion == 2);
+      free(key);
+      nsel = nmax;
+    }
+    for (int s = 0; s < nsel; ++s) {
+      const int i = order[s];
+      if (nobsl >= cap) {
+        free(cand); free(cr); free(order);
+        return -1;
+      }
+      idx_out[nobsl] = cand[i];
+      rloc_out[nobsl] = cr[3 * i];
+      rdiag_out[nobsl] = cr[3 * i + 1];
+      if (dist_out) dist_out[nobsl] = cr[3 * i + 2];
+      ++nobsl;
+    }
+    free(cand);
+    free(cr);
+    free(order);
+  }
+  return nobsl;
+}

@@ -55,9 +55,22 @@ class DasArgs(C.Structure):
                 ("status", C.c_void_p), ("nsweep", C.c_void_p)]
 
 
+class SearchTables(C.Structure):
+    """letkf_search_tables (include/letkf_amd.h section 3)"""
+    _fields_ = [("nctype", C.c_int32), ("ngroup", C.c_int32), ("criterion", C.c_int32), ("nlon", C.c_int32),
+                ("nlat", C.c_int32), ("reserved0", C.c_int32), ("dx", C.c_double), ("dy", C.c_double),
+                ("i_org", C.c_double), ("j_org", C.c_double), ("rain_base", C.c_double),
+                ("group_start", C.c_void_p), ("group_member", C.c_void_p), ("vmode", C.c_void_p),
+                ("hori_loc", C.c_void_p), ("vert_loc", C.c_void_p), ("varloc", C.c_void_p), ("max_nobs", C.c_void_p),
+                ("ngrd_i", C.c_void_p), ("ngrd_j", C.c_void_p), ("ngrdsch_i", C.c_void_p), ("ngrdsch_j", C.c_void_p),
+                ("ngrdext_i", C.c_void_p), ("ngrdext_j", C.c_void_p), ("ac_off", C.c_void_p), ("ac_ext", C.c_void_p),
+                ("ob_ri", C.c_void_p), ("ob_rj", C.c_void_p), ("ob_lev", C.c_void_p), ("ob_dat", C.c_void_p),
+                ("ob_err", C.c_void_p)]
+
+
 EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", "letkf_ctx_destroy",
            "letkf_ctx_set_stream", "letkf_ctx_synchronize", "letkf_core_c", "letkf_core_batch_dev",
-           "letkf_das_points_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
+           "letkf_das_points_dev", "letkf_obs_search_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
            "letkf_ctx_timing_enable", "letkf_ctx_timing_read"]
 
 _lib = None
@@ -154,6 +167,26 @@ class Context:
         a.trans_out, a.transm_out, a.pa_out = _ptr(trans_out), _ptr(transm_out), _ptr(pa_out)
         a.status, a.nsweep = _ptr(status), _ptr(nsweep)
         self._check(self._l.letkf_das_points_dev(self._c, C.byref(a)))
+
+    # ---- (3) obs_local on the device: two-phase CSR build (count, scan, fill)
+    def obs_search(self, tables, ri, rj, rlev, rz):
+        """Returns (obs_off, obs_idx, rdiag_l, rloc_l) device tensors for the points (ri, rj, rlev, rz)."""
+        import torch
+        npts = ri.numel()
+        counts = torch.zeros(npts, dtype=torch.int32, device=ri.device)
+        self._check(self._l.letkf_obs_search_dev(self._c, C.byref(tables), C.c_int64(npts), _ptr(ri), _ptr(rj),
+                                                 _ptr(rlev), _ptr(rz), C.c_int32(0), _ptr(counts), None, None, None,
+                                                 None))
+        obs_off = torch.zeros(npts + 1, dtype=torch.int64, device=ri.device)
+        obs_off[1:] = torch.cumsum(counts.to(torch.int64), 0)
+        nnz = int(obs_off[-1].item())
+        obs_idx = torch.empty(max(nnz, 1), dtype=torch.int32, device=ri.device)
+        rdiag = torch.empty(max(nnz, 1), dtype=torch.float64, device=ri.device)
+        rloc = torch.empty(max(nnz, 1), dtype=torch.float64, device=ri.device)
+        self._check(self._l.letkf_obs_search_dev(self._c, C.byref(tables), C.c_int64(npts), _ptr(ri), _ptr(rj),
+                                                 _ptr(rlev), _ptr(rz), C.c_int32(1), None, _ptr(obs_off),
+                                                 _ptr(obs_idx), _ptr(rdiag), _ptr(rloc)))
+        return obs_off, obs_idx[:nnz], rdiag[:nnz], rloc[:nnz]
 
     def to_perturbations(self, k, nv, npts, x, sp, sm, sv):
         self._check(self._l.letkf_ens_to_perturbations_dev(self._c, C.c_int32(k), C.c_int32(nv), C.c_int64(npts),

@@ -237,7 +237,9 @@ int letkf_ctx_destroy(letkf_ctx* c) {
 
 int letkf_ctx_set_stream(letkf_ctx* c, void* hip_stream) {
   if (int rc = check_ctx(c)) return rc;
-  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  // the handle is used as is: NULL is HIP's default (null) stream, which is also what torch.cuda.current_stream()
+  // hands out unless the caller switched streams -- work then orders with the caller's other work on that stream
+  c->stream = static_cast<hipStream_t>(hip_stream);
   return LETKF_OK;
 }
 
@@ -377,6 +379,34 @@ int letkf_ens_mean_dev(letkf_ctx* c, int32_t k, int32_t nv, int64_t npts, double
   if (!x || k < 1 || nv < 1 || npts < 0) return fail(LETKF_E_INVALID, "bad argument");
   if (npts == 0) return LETKF_OK;
   HIP_TRY(letkf::launch_ens_mean(k, nv, npts, x, sp, sm, sv, c->stream));
+  return LETKF_OK;
+}
+
+int letkf_obs_search_dev(letkf_ctx* c, const letkf_search_tables* t, int64_t npts, const double* ri, const double* rj,
+                         const double* rlev, const double* rz, int32_t fill, int32_t* counts, const int64_t* obs_off,
+                         int32_t* obs_idx, double* rdiag_l, double* rloc_l) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!t || npts < 0) return fail(LETKF_E_INVALID, "tables is NULL or npts < 0");
+  if (npts == 0) return LETKF_OK;
+  if (!ri || !rj || !rlev || !rz) return fail(LETKF_E_INVALID, "a point coordinate array is NULL");
+  if (t->nctype < 1 || t->ngroup < 1 || t->criterion < 1 || t->criterion > 3)
+    return fail(LETKF_E_INVALID, "bad nctype / ngroup / criterion");
+  if (fill ? (!obs_off || !obs_idx || !rdiag_l || !rloc_l) : !counts)
+    return fail(LETKF_E_INVALID, "missing output array for this phase");
+  letkf::SearchArgs a;
+  a.t = *t;
+  a.npts = npts;
+  a.ri = ri;
+  a.rj = rj;
+  a.rlev = rlev;
+  a.rz = rz;
+  a.fill = fill;
+  a.counts = counts;
+  a.obs_off = reinterpret_cast<const long*>(obs_off);
+  a.obs_idx = obs_idx;
+  a.rdiag_l = rdiag_l;
+  a.rloc_l = rloc_l;
+  HIP_TRY(letkf::launch_search(a, c->num_cu, c->stream));
   return LETKF_OK;
 }
 

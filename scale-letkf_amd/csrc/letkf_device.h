@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/letkf_amd.h"
+
 namespace letkf {
 
 struct PointArgs {
@@ -59,6 +61,22 @@ struct LaunchPlan {
   int grid, block;
   size_t lds_bytes;
 };
+
+struct SearchArgs {
+  letkf_search_tables t;
+  long npts;
+  const double* ri;
+  const double* rj;
+  const double* rlev;
+  const double* rz;
+  int fill;
+  int* counts;
+  const long* obs_off;
+  int* obs_idx;
+  double* rdiag_l;
+  double* rloc_l;
+};
+hipError_t launch_search(const SearchArgs& a, int num_cu, hipStream_t st);
 
 hipError_t launch_point_kernel(const PointArgs& a, const LaunchPlan& p, hipStream_t st);
 bool wave_kernel_supports(int k, int nv, int mode);
