@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--relax", default="rtps", choices=["rtps", "rtpp", "none"])
+    ap.add_argument("--lists", default="torch", choices=["torch", "search"],
+                    help="where the local-obs lists come from: the torch workload builder, or letkf_obs_search_dev "
+                         "(on-device obs_local; its time is reported separately as search_ms)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(affinity, cgroup quota, 16 = the box's CPU share)")
     args = ap.parse_args()
 
@@ -61,6 +64,21 @@ def main():
     # the streaming passes either side of the loop: mean into slot k, members -> perturbations
     ctx.ens_mean(k, nv, npts, w["gues"], w["sp"], w["sm"], w["sv"])
     ctx.to_perturbations(k, nv, npts, w["gues"], w["sp"], w["sm"], w["sv"])
+    search_ms = None
+    if args.lists == "search":
+        # obs_local on the device: rebuild the lists with the search kernel on the mesh-sorted table
+        t_s, keep_s, order_s, pts_s = bw.search_tables(w, pkg, dev)
+        n_torch = int(w["obs_off"][-1].item())
+        w["ensval"] = w["ensval"][order_s].contiguous()
+        w["dep"] = w["dep"][order_s].contiguous()
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0s = time.perf_counter()
+            off_s, idx_s, rd_s, rl_s = ctx.obs_search(t_s, *pts_s)
+            torch.cuda.synchronize()
+            search_ms = (time.perf_counter() - t0s) * 1e3
+        assert int(off_s[-1].item()) == n_torch, "device search and torch builder disagree on the list sizes"
+        w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"] = off_s, idx_s, rd_s, rl_s
     anal = torch.empty_like(w["gues"])
     infl = torch.ones(npts * nv, dtype=torch.float64, device=dev)
     status = torch.zeros(npts, dtype=torch.int32, device=dev)
@@ -145,7 +163,8 @@ def main():
                                       f"relax={args.relax}", "points_per_gpu": npts, "obs_table_rows": w["nobs"],
                           "parallelism": f"grid-point shard x{n_gpus}" + (" + RCCL obs all-gather" if world > 1 else "")},
                "analysis_wall_s": elapsed / args.steps, "nonzero_status_points": bad,
-               "jacobi_sweeps_mean": sweeps_mean, "roofline": roofline, "cpu_baseline": cpu}
+               "jacobi_sweeps_mean": sweeps_mean, "lists": args.lists, "search_ms": search_ms,
+               "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

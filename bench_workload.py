@@ -121,3 +121,57 @@ def alg_flops_per_solve(n, k, nv, rtps=True):
     if rtps:
         f += 2.0 * k ** 3 + 2.0 * nv * k * k
     return f
+
+
+def search_tables(w, pkg, device):
+    """The same C2-style lattice as build(), described the way set_letkf_obs leaves it behind (one radar ctype, mesh of
+    letkf_obs.f90:655-695, rows sorted (j, i)), so that the lists can come from letkf_obs_search_dev instead of
+    torch.  Returns (tables struct, keepalive, row order, point coordinate tensors)."""
+    cfg = w["cfg"]
+    nx, ny, nz = cfg["nx"], cfg["ny"], cfg["nz"]
+    dx, hloc, vloc, sp_o = cfg["dx"], cfg["hloc"], cfg["vloc"], cfg["spacing"]
+    f64 = torch.float64
+    ox = torch.arange(0.5 * sp_o, nx * dx, sp_o, device=device, dtype=f64)
+    oy = torch.arange(0.5 * sp_o, ny * dx, sp_o, device=device, dtype=f64)
+    oz = torch.arange(0.5 * sp_o, cfg["ztop"], sp_o, device=device, dtype=f64)
+    nox, noy, noz = len(ox), len(oy), len(oz)
+    # lattice row index = (iz*noy + iy)*nox + ix  (as in build())
+    ri = (ox / dx).repeat(noy * noz)
+    rj = (oy / dx).repeat_interleave(nox).repeat(noz)
+    lev = oz.repeat_interleave(nox * noy)
+    spc = hloc * DIST_ZERO_FAC / 6.0
+    ngrd_i = min(math.ceil(dx * nx / spc), nx)
+    ngrd_j = min(math.ceil(dx * ny / spc), ny)
+    nsch_i = math.ceil(hloc * DIST_ZERO_FAC / (dx * nx / ngrd_i))
+    nsch_j = math.ceil(hloc * DIST_ZERO_FAC / (dx * ny / ngrd_j))
+    next_i, next_j = ngrd_i + 2 * nsch_i, ngrd_j + 2 * nsch_j
+    ogi = torch.ceil(ri * ngrd_i / nx).long() + nsch_i
+    ogj = torch.ceil(rj * ngrd_j / ny).long() + nsch_j
+    cell = (ogj - 1) * next_i + (ogi - 1)
+    order = torch.argsort(cell, stable=True)
+    counts = torch.bincount(cell, minlength=next_i * next_j).view(next_j, next_i)
+    ends = torch.cumsum(counts.reshape(-1), 0).view(next_j, next_i)
+    ac = torch.zeros(next_j, next_i + 1, dtype=torch.int64, device=device)
+    ac[:, 1:] = ends
+    ac[1:, 0] = ends[:-1, -1]
+    t = pkg.SearchTables()
+    t.nctype, t.ngroup, t.criterion, t.nlon, t.nlat = 1, 1, 1, nx, ny
+    t.dx, t.dy, t.i_org, t.j_org, t.rain_base = dx, dx, 0.0, 0.0, 8.5e4
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
+    d64 = lambda v: torch.tensor(v, dtype=f64, device=device)
+    keep = dict(group_start=i32([0, 1]), group_member=i32([0]), vmode=i32([1]), hori_loc=d64([hloc]),
+                vert_loc=d64([vloc]), varloc=d64([1.0]), max_nobs=i32([0]), ngrd_i=i32([ngrd_i]), ngrd_j=i32([ngrd_j]),
+                ngrdsch_i=i32([nsch_i]), ngrdsch_j=i32([nsch_j]), ngrdext_i=i32([next_i]), ngrdext_j=i32([next_j]),
+                ac_off=torch.zeros(1, dtype=torch.int64, device=device), ac_ext=ac.reshape(-1).to(torch.int32),
+                ob_ri=ri[order].contiguous(), ob_rj=rj[order].contiguous(), ob_lev=lev[order].contiguous(),
+                ob_dat=torch.full_like(ri, 1.0e5), ob_err=torch.full_like(ri, cfg["err"]))
+    for k, v in keep.items():
+        setattr(t, k, v.data_ptr())
+    zlev = torch.from_numpy(level_heights(nz, cfg["ztop"])).to(device)
+    gx = (torch.arange(nx, device=device, dtype=f64) + 0.5)
+    gy = (torch.arange(ny, device=device, dtype=f64) + 0.5)
+    pri = gx.repeat(ny).repeat(nz)
+    prj = gy.repeat_interleave(nx).repeat(nz)
+    prz = zlev.repeat_interleave(nx * ny)
+    prl = torch.full_like(pri, 1.0e5)
+    return t, keep, order, (pri, prj, prl, prz)
