@@ -20,6 +20,11 @@ CONFIGS = {
     # small stand-ins for tests / smoke-sized benches
     "C2-mini": dict(nx=48, ny=48, nz=12, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
                     ztop=18000.0, seed=20240610),
+    # production ensemble size (MEMBER=100 in 20 of the reference's 38 configs), small grid
+    "C2-mini-k100": dict(nx=48, ny=48, nz=12, k=100, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
+                         ztop=18000.0, seed=20240611),
+    "C2-mini-k20": dict(nx=48, ny=48, nz=12, k=20, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
+                        ztop=18000.0, seed=20240612),
     # profiling stand-in: same grid, no observation in range (isolates state I/O + transform)
     "C2-mini-noobs": dict(nx=48, ny=48, nz=12, k=50, dx=1000.0, hloc=40.0, vloc=20.0, spacing=3200.0, err=3.0,
                           ztop=18000.0, seed=20240610),

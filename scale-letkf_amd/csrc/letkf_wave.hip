@@ -39,8 +39,15 @@ __device__ __forceinline__ double wshfl(double v, int src) { return __shfl(v, sr
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  // quad_perm / mirror patterns have a valid source in every lane: no `old` value is needed, and asking for one
+  // costs an extra v_mov_b32 per dword (seen in the ISA: 106 of the 264 instructions of an even Jacobi step)
+  if constexpr (CTRL < 0x130) {
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  } else {
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  }
   return __hiloint2double(hi, lo);
 }
 
@@ -102,6 +109,9 @@ __device__ __forceinline__ long xcd_remap_w(long orig, long n) {
 constexpr double kRotTol2W = 1e-30;   // rotate when cos^2 > 1e-30
 constexpr double kStopTol2W = 1e-20;  // sweep counts as converged when every visited pair had |cos| <= 1e-10 (all of them were
                                       // still rotated away in that sweep, so what is left is second order)
+#ifndef LETKF_KS_NUM
+#define LETKF_KS_NUM 10   // tenths of the rows that take the LDS path in odd Jacobi steps
+#endif
 constexpr int kTnW = 8;               // obs rows per LDS tile (per wave)
 constexpr int kChunk = 8;             // columns per LDS transposition chunk
 constexpr int kVld = kChunk + 2;      // row stride of the transposition buffer (doubles, even)
@@ -150,12 +160,128 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // into the column but accumulated in a per-column inverse scale `is`, and the squared norms alpha follow the
 // rotation identities alpha' = alpha -/+ t*gamma.  Both are refreshed once per sweep.
 // ---------------------------------------------------------------------------------------------
-template <int KR>
-__device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const int max_sweep, double* xbuf, const int jmix) {
+// One Jacobi step.  `own` holds this lane's column, the partner's column is fetched into `oth`, and the lane's NEW
+// column (the partner's rotated one: rotate-and-swap) is left in `oth` -- the caller ping-pongs the two arrays, so
+// the update is a single v_fmac per element with no register copy (the first version updated in place and paid
+// 50 v_mov_b64 per step for it).  Lanes without a partner in this step (the two ends of the line in odd steps, and
+// every lane beyond the last column) are made their own partner: they fetch their own column and all formulas
+// degenerate to the identity (gamma-driven t = 0), so no branch on `has` is needed.
+template <int KR, bool ODD>
+__device__ __forceinline__ bool jacobi_step(double (&own)[KR], double (&oth)[KR], double& al, double& is, double& sc,
+                                            const int ncol, double* xbuf) {
   const int lane = threadIdx.x & 63;
   const bool oddlane = (lane & 1) != 0;
+  double be, isq, scq;
+  double ga0 = 0.0, ga1 = 0.0;
+  int pl;
+  if (!ODD) {
+    pl = lane ^ 1;                                       // ncol is even: every lane < ncol has its partner
+#pragma unroll
+    for (int r = 0; r < KR; r += 2) {
+      oth[r] = dpp_mov<0xB1>(own[r]);
+      oth[r + 1] = dpp_mov<0xB1>(own[r + 1]);
+      ga0 = fma(own[r], oth[r], ga0);
+      ga1 = fma(own[r + 1], oth[r + 1], ga1);
+    }
+    be = dpp_mov<0xB1>(al);
+    isq = dpp_mov<0xB1>(is);
+    scq = dpp_mov<0xB1>(sc);
+  } else {
+    // partner is lane+1 (odd lanes) / lane-1 (even lanes): through LDS in row chunks with b128 accesses (conflict-free
+    // at a lane stride of 10 doubles) -- the VALU alternative is 2 DPP moves + a select per dword (measured slower)
+    pl = oddlane ? lane + 1 : lane - 1;
+    if (lane >= ncol || pl < 0 || pl >= ncol) pl = lane;
+    constexpr int CR = (KR % 10 == 0) ? 10 : 8;          // rows per chunk
+    constexpr int LS = 10;                                // lane stride in doubles
+    constexpr int NCH = (KR + CR - 1) / CR;
+    // two chunk slots, software pipelined.  DS instructions of one wave execute in order, so a later ds_read sees
+    // every earlier ds_write of the wave; only the compiler must keep program order (it has to: the two pointers may
+    // alias as far as it can tell).
+    double* smine = xbuf + 2 * 64 * LS + lane * 4;
+    const double* stheirs = xbuf + 2 * 64 * LS + pl * 4;
+    smine[0] = al;
+    smine[1] = is;
+    smine[2] = sc;
+    auto put = [&](int c) {
+      double* mine = xbuf + (c & 1) * 64 * LS + lane * LS;
+#pragma unroll
+      for (int e = 0; e < CR; e += 2)
+        if (c * CR + e < KR) *reinterpret_cast<double2*>(&mine[e]) = double2{own[c * CR + e], own[c * CR + e + 1]};
+    };
+    put(0);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c + 1 < NCH) put(c + 1);
+      __builtin_amdgcn_wave_barrier();
+      const double* theirs = xbuf + (c & 1) * 64 * LS + pl * LS;
+#pragma unroll
+      for (int e = 0; e < CR; e += 2) {
+        if (c * CR + e < KR) {
+          const double2 t2 = *reinterpret_cast<const double2*>(&theirs[e]);
+          oth[c * CR + e] = t2.x;
+          oth[c * CR + e + 1] = t2.y;
+          ga0 = fma(own[c * CR + e], t2.x, ga0);
+          ga1 = fma(own[c * CR + e + 1], t2.y, ga1);
+        }
+      }
+    }
+    be = stheirs[0];
+    isq = stheirs[1];
+    scq = stheirs[2];
+    __builtin_amdgcn_wave_barrier();
+  }
+  const double ga = (ga0 + ga1) * (is * isq);            // true inner product
+  const bool lo = lane <= pl;
+  const double a = lo ? al : be, b = lo ? be : al;       // both lanes of a pair see the same (a, b, ga)
+  const double g2 = ga * ga, ab = a * b;
+  const bool real_pair = pl != lane;
+  const bool notconv = real_pair && g2 > kStopTol2W * ab;
+  const bool rot = real_pair && g2 > kRotTol2W * ab;
+  // tan(2 theta) = 2 ga / (b - a);  t = 2 ga sgn(d) / (|d| + sqrt(d^2 + 4 ga^2))
+  const double d = b - a;
+  const double x = fma(d, d, 4.0 * g2);
+  const double hh = x * fast_rsqrt1(x);
+  double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
+  tt = rot ? tt : 0.0;
+  const double w = fma(tt, tt, 1.0);
+  const double c = fast_rsqrt(w);                        // cos (exactly 1 when tt == 0)
+  // rotate and swap: this lane takes over the PARTNER's new column.  True columns g_p' = c (g_p - t g_q),
+  // g_q' = c (g_q + t g_p); in the partner's scaled storage that is  G' = H +/- t (is_own / is_partner) G.
+  const double tg = tt * ga;
+  al = lo ? b + tg : a - tg;
+  const double coef = (lo ? tt : -tt) * (is * scq);
+  is = isq * c;
+  sc = scq * (w * c);                                    // 1/cos = sqrt(1 + t^2)
+  if (__any(rot)) {
+#pragma unroll
+    for (int r = 0; r < KR; ++r) oth[r] = fma(coef, own[r], oth[r]);
+  }
+  return notconv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One-sided (Hestenes) Jacobi on register-resident columns.  Returns sweeps used.
+//
+// Pair ordering = odd-even transposition on the lane line: even steps pair lanes (0,1)(2,3)..., odd steps
+// (1,2)(3,4)...; after its rotation a pair SWAPS places (each lane simply computes the partner's new column
+// instead of its own).  After ncol steps every one of the column pairs has met exactly once, for any ncol,
+// and the only partners a lane ever has are its two neighbours -- so the column fetch is a DPP move on the VALU
+// (quad_perm[1,0,3,2], even steps) or a b128 round trip through LDS (odd steps) instead of ds_bpermute through
+// the LDS crossbar, which at 4 LDS cycles per dword-move and 4 SIMDs per CU was what bounded the XOR-tournament
+// version (measured 1.6 ms -> 0.84 ms per sweep on the C2-mini workload).
+//
+// The rotation itself is a "fast" scaled rotation G' = H + coef * G (KR FMAs): the cosine is not multiplied
+// into the column but accumulated in a per-column inverse scale `is`, and the squared norms alpha follow the
+// rotation identities alpha' = alpha -/+ t*gamma.  Both are refreshed once per sweep.
+// ---------------------------------------------------------------------------------------------
+template <int KR>
+__device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const int max_sweep, double* xbuf,
+                                           const int jmix) {
+  (void)jmix;
+  const int ncol = (k + 1) & ~1;   // an odd k gets one zero column as an extra (inert) participant
+  double h[KR];
   int sweep = 0;
-  double is = 1.0, sc = 1.0;     // true column = is * g ; sc = 1/is
+  double is = 1.0, sc = 1.0;       // true column = is * g ; sc = 1/is
   for (; sweep < max_sweep; ++sweep) {
     // refresh: fold the scale back, recompute the squared norm
     double a0 = 0.0, a1 = 0.0;
@@ -170,106 +296,9 @@ __device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const i
     is = 1.0;
     sc = 1.0;
     bool notconv = false;
-    for (int t = 0; t < k; ++t) {
-      const bool oddstep = (t & 1) != 0;
-      const int pl = oddstep ? (oddlane ? lane + 1 : lane - 1) : (lane ^ 1);
-      const bool has = (lane < k) && (pl >= 0) && (pl < k);
-      double h[KR];
-      double be, isq, scq;
-      double ga0 = 0.0, ga1 = 0.0;
-      const bool use_lds = oddstep ? (jmix & 1) != 0 : ((jmix & 4) != 0 || ((jmix & 2) != 0 && (t & 2) != 0));
-      if (!oddstep && !use_lds) {
-#pragma unroll
-        for (int r = 0; r < KR; r += 2) {
-          h[r] = dpp_mov<0xB1>(g[r]);
-          h[r + 1] = dpp_mov<0xB1>(g[r + 1]);
-          ga0 = fma(g[r], h[r], ga0);
-          ga1 = fma(g[r + 1], h[r + 1], ga1);
-        }
-        be = dpp_mov<0xB1>(al);
-        isq = dpp_mov<0xB1>(is);
-        scq = dpp_mov<0xB1>(sc);
-      } else if (!use_lds) {
-        // odd step on the VALU: wave_shl:1 / wave_shr:1 + select
-#pragma unroll
-        for (int r = 0; r < KR; r += 2) {
-          const double u0 = dpp_mov<0x130>(g[r]), d0 = dpp_mov<0x138>(g[r]);          // lane+1 / lane-1
-          const double u1 = dpp_mov<0x130>(g[r + 1]), d1 = dpp_mov<0x138>(g[r + 1]);
-          h[r] = oddlane ? u0 : d0;
-          h[r + 1] = oddlane ? u1 : d1;
-          ga0 = fma(g[r], h[r], ga0);
-          ga1 = fma(g[r + 1], h[r + 1], ga1);
-        }
-        const double bu = dpp_mov<0x130>(al), bd = dpp_mov<0x138>(al);
-        const double iu = dpp_mov<0x130>(is), id = dpp_mov<0x138>(is);
-        const double su = dpp_mov<0x130>(sc), sd = dpp_mov<0x138>(sc);
-        be = oddlane ? bu : bd;
-        isq = oddlane ? iu : id;
-        scq = oddlane ? su : sd;
-      } else {
-        // odd steps: partner is lane+1 (odd lanes) / lane-1 (even lanes).  On the VALU that costs two DPP moves and
-        // a select per dword (300 ops); instead the columns go through a small LDS buffer in row chunks with
-        // b128 accesses (2*KR/ (2) LDS instructions, conflict-free at a lane stride of 10 doubles), which moves this
-        // half of the exchange from the saturated VALU to the otherwise idle LDS pipe.
-        constexpr int CR = (KR % 10 == 0) ? 10 : 8;          // rows per chunk
-        constexpr int LS = 10;                                // lane stride in doubles
-        const int plc = pl < 0 ? 0 : (pl > 63 ? 63 : pl);
-        double* mine = xbuf + lane * LS;
-        const double* theirs = xbuf + plc * LS;
-        double* smine = xbuf + 64 * LS + lane * 4;
-        const double* stheirs = xbuf + 64 * LS + plc * 4;
-        smine[0] = al;
-        smine[1] = is;
-        smine[2] = sc;
-#pragma unroll
-        for (int c0 = 0; c0 < KR; c0 += CR) {
-          wave_lds_sync();
-#pragma unroll
-          for (int e = 0; e < CR; e += 2) {
-            if (c0 + e < KR) *reinterpret_cast<double2*>(&mine[e]) = double2{g[c0 + e], g[c0 + e + 1]};
-          }
-          wave_lds_sync();
-#pragma unroll
-          for (int e = 0; e < CR; e += 2) {
-            if (c0 + e < KR) {
-              const double2 t2 = *reinterpret_cast<const double2*>(&theirs[e]);
-              h[c0 + e] = t2.x;
-              h[c0 + e + 1] = t2.y;
-              ga0 = fma(g[c0 + e], t2.x, ga0);
-              ga1 = fma(g[c0 + e + 1], t2.y, ga1);
-            }
-          }
-        }
-        be = stheirs[0];
-        isq = stheirs[1];
-        scq = stheirs[2];
-        wave_lds_sync();
-      }
-      const double ga = (ga0 + ga1) * (is * isq);          // true inner product
-      const bool lo = lane < pl;
-      const double a = lo ? al : be, b = lo ? be : al;     // both lanes of a pair see the same (a, b, ga)
-      const double g2 = ga * ga, ab = a * b;
-      notconv = notconv || (has && g2 > kStopTol2W * ab);
-      const bool rot = has && g2 > kRotTol2W * ab;
-      // tan(2 theta) = 2 ga / (b - a);  t = 2 ga sgn(d) / (|d| + sqrt(d^2 + 4 ga^2))
-      const double d = b - a;
-      const double x = fma(d, d, 4.0 * g2);
-      const double hh = x * fast_rsqrt1(x);
-      double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
-      tt = rot ? tt : 0.0;
-      const double w = fma(tt, tt, 1.0);
-      const double c = fast_rsqrt(w);                      // cos
-      if (has) {
-        // rotate and swap: this lane takes over the PARTNER's new column.  True columns g_p' = c (g_p - t g_q),
-        // g_q' = c (g_q + t g_p); in the partner's scaled storage that is  G' = H +/- t (is_own / is_partner) G.
-        const double tg = tt * ga;
-        al = lo ? b + tg : a - tg;
-        const double coef = (lo ? tt : -tt) * (is * scq);
-        is = isq * c;
-        sc = scq * (w * c);                                // 1/cos = sqrt(1 + t^2)
-#pragma unroll
-        for (int r = 0; r < KR; ++r) g[r] = fma(coef, g[r], h[r]);
-      }
+    for (int t = 0; t < ncol; t += 2) {
+      notconv |= jacobi_step<KR, false>(g, h, al, is, sc, ncol, xbuf);
+      notconv |= jacobi_step<KR, true>(h, g, al, is, sc, ncol, xbuf);
     }
     if (!__any(notconv)) {
       ++sweep;
@@ -291,7 +320,8 @@ __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const dou
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int b = 0; b < NB; ++b) out[b] = 0.0;
-  for (int j0 = 0; j0 < k; j0 += kChunk) {
+  const int ncol = (k + 1) & ~1;                 // columns live in lanes [0, ncol) (see jacobi_regs)
+  for (int j0 = 0; j0 < ncol; j0 += kChunk) {
     wave_lds_sync();
     if (lane >= j0 && lane < j0 + kChunk) {
       const int jj = lane - j0;
@@ -310,7 +340,7 @@ __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const dou
       vv[jj] = t2.x;
       vv[jj + 1] = t2.y;
     }
-    const int nj = min(kChunk, k - j0);
+    const int nj = min(kChunk, ncol - j0);
 #pragma unroll
     for (int jj = 0; jj < kChunk; ++jj) {
       if (jj < nj) {
@@ -339,7 +369,8 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv) {
   if (kChunk * KR > bmat) bmat = kChunk * KR;
   const int cb = kChunk * ((nb + 1) & ~1);
   const int small = 3 * kTnW + 8 * nv + 16;
-  if (tile + bmat < 64 * 18) bmat = 64 * 18 - tile;   // the Gram transposition buffer abuf[64][18] spans tile + bmat
+  if (tile + bmat < 1536) bmat = 1536 - tile;   // Gram transposition buffer abuf[64][18] and the Jacobi exchange
+                                               // slots (2 * 64 * 10 + 64 * 4 doubles) span tile + bmat
   int tot = tile + bmat + cb + small;
   return (tot + 1) & ~1;
 }
@@ -362,7 +393,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
   if (KR * kVld > tile_sz) tile_sz = KR * kVld;
   int bmat_sz = NBP * KR;
   if (kChunk * KR > bmat_sz) bmat_sz = kChunk * KR;
-  if (tile_sz + bmat_sz < 64 * 18) bmat_sz = 64 * 18 - tile_sz;
+  if (tile_sz + bmat_sz < 1536) bmat_sz = 1536 - tile_sz;
   double* ytile = slice;                      // [kTnW][64]
   double* vbuf = slice;                       // [KR][kVld]          (after the Gram phase)
   double* bmat = slice + tile_sz;             // [KR][NBP]
@@ -425,6 +456,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
     double racc = 0.0, rdacc = 0.0, p1 = 0.0, p3 = 0.0;
     int sweeps = 0;
     double lam = km1 / infl_old;               // n == 0: T = sqrt(rho) I, Pa = rho/(k-1) I (common_letkf.f90:89-107)
+    bool colvalid = lane < k;                  // does this lane hold an eigen-column?
 
     if (n > 0) {
       constexpr int NBLK = (KR + 2 + 15) / 16;                 // member blocks incl. the 2 augmented columns
@@ -571,7 +603,9 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
 #pragma unroll
       for (int r = 0; r < KR; ++r) ss = fma(g[r], g[r], ss);
       lam = sqrt(ss);
-      const double il = (lane < k) ? 1.0 / lam : 0.0;
+      colvalid = ss > 0.0;     // after the rotate-and-swap sweeps the columns sit in permuted lanes; with an odd k the
+                               // inert zero column that pads the line to even length can be anywhere among them
+      const double il = colvalid ? 1.0 / lam : 0.0;
 #pragma unroll
       for (int r = 0; r < KR; ++r) g[r] *= il;
 
@@ -592,14 +626,14 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
     // ------------------------------------------------------------ status (common_mtx.f90:66-78)
     int st = 0;
     {
-      const double lmx = wave_max(lane < k ? lam : 0.0);
-      const double lmn = wave_min(lane < k ? lam : 1e300);
+      const double lmx = wave_max(colvalid ? lam : 0.0);
+      const double lmn = wave_min(colvalid ? lam : 1e300);
       if (sweeps >= A.max_sweep && A.max_sweep >= 60) st = 1;
       else if (!(lmx > 0.0)) st = 2;
       else if (lmn < lmx * 1.4901161193847656e-08) st = 3;
     }
-    const double sc1 = (lane < k) ? sqrt(km1 / lam) : 0.0;    // T spectrum
-    const double sc2 = (lane < k) ? 1.0 / lam : 0.0;          // Pa spectrum
+    const double sc1 = colvalid ? sqrt(km1 / lam) : 0.0;      // T spectrum
+    const double sc2 = colvalid ? 1.0 / lam : 0.0;            // Pa spectrum
 
     // ------------------------------------------------------------ B = [r, r_det, x'_v] as bmat[m][NBP]; U = V^T B
     wave_lds_sync();
@@ -723,7 +757,8 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
 #pragma unroll
         for (int r = 0; r < KR; ++r) kk[r] = 0.0;
         double* ckk = bmat;                       // [kChunk][KR], B vectors are dead by now
-        for (int j0 = 0; j0 < k; j0 += kChunk) {
+        const int ncol = (k + 1) & ~1;
+        for (int j0 = 0; j0 < ncol; j0 += kChunk) {
           wave_lds_sync();
           if (lane >= j0 && lane < j0 + kChunk) {
             const int jj = lane - j0;
@@ -735,7 +770,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
           }
           wave_lds_sync();
           const int mrow = lane < KR ? lane : KR - 1;
-          const int nj = min(kChunk, k - j0);
+          const int nj = min(kChunk, ncol - j0);
           for (int jj = 0; jj < nj; ++jj) {
             const double vv = vbuf[mrow * kVld + jj];
 #pragma unroll
