@@ -227,6 +227,45 @@ int letkf_obs_search_dev(letkf_ctx *ctx, const letkf_search_tables *tables, int6
                          const double *rj, const double *rlev, const double *rz, int32_t fill, int32_t *counts,
                          const int64_t *obs_off, int32_t *obs_idx, double *rdiag_l, double *rloc_l);
 
+
+/*---------------------------------------------------------------------------
+ * (4) The steps either side of the loop, all pure-bandwidth kernels:
+ *     state_trans / state_trans_inv   scale/common/common_scale.f90:1181-1224 / :1229-1280
+ *       pointwise (DENS,MOMX,MOMY,MOMZ,RHOT,Q*) <-> (U,V,W,T,P,Q*) on a member's subdomain field
+ *       v3dg(nlev,nlon,nlat,nv3d) (level-fastest).  The SCALE-RM constants are not in the reference tree
+ *       (scale_const / scale_tracer): the caller passes them.  Variable order as common_scale.f90:36-51:
+ *       0 rho/u, 1 rhou... : see letkf_state_consts.  state_trans_inv applies the positive-definite clamps of
+ *       :1243-1250 first when requested.
+ *     member field <-> point-major ensemble   grd_to_buf / buf_to_grd + the ALLTOALL of read_ens_mpi / write_ens_mpi
+ *       (scale/common/common_mpi_scale.f90:1099-1274, :1428-1480): the horizontal points of a subdomain are dealt
+ *       cyclically over np ranks (local point i of rank r is subdomain point r + np*i, ilon = mod(j,nlon)); this
+ *       entry moves ONE member's field into / out of slot m of gues3d(nij1,nlev,nens,nv3d) for one rank's share --
+ *       on one node the all-to-all is np of these per member (or device-to-device copies between the GPUs).
+ *     enssprd_grd                      scale/common/common_scale.f90:1570-1607
+ *-------------------------------------------------------------------------*/
+typedef struct {
+  double rdry, rvap, cvdry, pre00;   /* CONST_Rdry, CONST_Rvap, CONST_CVdry, CONST_PRE00 */
+  double tracer_cv[8];               /* TRACER_CV(1..nv3d-iv3d_q+1): specific heats of the moisture species */
+  int32_t iv_rho, iv_rhou, iv_rhov, iv_rhow, iv_rhot;   /* 0-based slots of the prognostic variables ...        */
+  int32_t iv_u, iv_v, iv_w, iv_t, iv_p;                 /* ... and of the analysis variables that replace them */
+  int32_t iv_q;                      /* first moisture variable; moisture = iv_q .. nv3d-1 */
+  int32_t positive_definite_q, positive_definite_qhyd;  /* POSITIVE_DEFINITE_Q / _QHYD (inverse only) */
+  int32_t reserved0;
+} letkf_state_consts;
+
+int letkf_state_trans_dev(letkf_ctx *ctx, const letkf_state_consts *c, int32_t nlev, int32_t nlon, int32_t nlat,
+                          int32_t nv3d, double *v3dg, int32_t inverse);
+
+/* dir = 0: v3dg (member field, level-fastest) -> x slot m;  dir = 1: x slot m -> v3dg.
+ * x element (point i, level k, member m, variable n) at (i + nij1*k)*sp + m*sm + n*sv (the strides of section 2). */
+int letkf_member_points_dev(letkf_ctx *ctx, int32_t dir, int32_t nlev, int32_t nlon, int32_t nlat, int32_t nv3d,
+                            int32_t np, int32_t rank, int32_t m, double *v3dg, double *x, int64_t nij1, int64_t sp,
+                            int64_t sm, int64_t sv);
+
+/* sprd[p + npts*v] = sqrt( sum_m (x_m - mean)^2 / (k-1) ), mean taken from slot k. */
+int letkf_ens_spread_dev(letkf_ctx *ctx, int32_t k, int32_t nv, int64_t npts, const double *x, int64_t sp,
+                         int64_t sm, int64_t sv, double *sprd);
+
 /* Kernel timing helper for bench.py: average duration (ms) of the last
  * letkf_das_points_dev / letkf_core_batch_dev launches measured with HIP events on the
  * context's stream since the previous reset; *nlaunch receives the count. */

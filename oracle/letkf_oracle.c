@@ -761,3 +761,78 @@ int orc_obs_local(const orc_search_tables *t, double ri, double rj, double rlev,
   }
   return nobsl;
 }
+
+/* scale/common/common_scale.f90:1181-1224 and :1229-1280 */
+void orc_state_trans(const orc_state_consts *c, int nlev, int nlon, int nlat, int nv3d, double *v, int inverse) {
+  const int64_t nxy = (int64_t)nlon * nlat, st = (int64_t)nlev * nxy;
+  if (inverse) {                                             /* :1243-1250 */
+    for (int n = c->iv_q; n < nv3d; ++n) {
+      const int clamp = (n == c->iv_q) ? c->positive_definite_q : c->positive_definite_qhyd;
+      if (clamp)
+        for (int64_t e = 0; e < st; ++e) v[n * st + e] = fmax(v[n * st + e], 0.0);
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t e = 0; e < st; ++e) {
+    double *p = v + e;
+    double qdry = 1.0, cvtot = 0.0;
+    for (int n = c->iv_q; n < nv3d; ++n) {
+      qdry = qdry - p[n * st];
+      cvtot = cvtot + p[n * st] * c->tracer_cv[n - c->iv_q];
+    }
+    cvtot = c->cvdry * qdry + cvtot;
+    const double rtot = c->rdry * qdry + c->rvap * p[c->iv_q * st];
+    if (!inverse) {
+      const double cpovcv = (cvtot + rtot) / cvtot;
+      const double rho = p[c->iv_rho * st];
+      const double pres = c->pre00 * pow(p[c->iv_rhot * st] * rtot / c->pre00, cpovcv);
+      const double temp = pres / (rho * rtot);
+      const double u = p[c->iv_rhou * st] / rho, vv = p[c->iv_rhov * st] / rho, w = p[c->iv_rhow * st] / rho;
+      p[c->iv_u * st] = u;
+      p[c->iv_v * st] = vv;
+      p[c->iv_w * st] = w;
+      p[c->iv_t * st] = temp;
+      p[c->iv_p * st] = pres;
+    } else {
+      const double cvovcp = cvtot / (cvtot + rtot);
+      const double pr = p[c->iv_p * st];
+      const double rho = pr / (rtot * p[c->iv_t * st]);
+      const double rhot = c->pre00 / rtot * pow(pr / c->pre00, cvovcp);
+      const double ru = p[c->iv_u * st] * rho, rv = p[c->iv_v * st] * rho, rw = p[c->iv_w * st] * rho;
+      p[c->iv_rhot * st] = rhot;
+      p[c->iv_rhow * st] = rw;
+      p[c->iv_rhov * st] = rv;
+      p[c->iv_rhou * st] = ru;
+      p[c->iv_rho * st] = rho;
+    }
+  }
+}
+
+/* scale/common/common_mpi_scale.f90:1428-1455 (grd_to_buf), :1460-1480 (buf_to_grd) */
+void orc_member_points(int dir, int nlev, int nlon, int nlat, int nv3d, int np, int rank, int m, double *v3dg,
+                       double *x, int64_t nij1, int64_t sp, int64_t sm, int64_t sv) {
+  const int64_t nxy = (int64_t)nlon * nlat;
+  for (int n = 0; n < nv3d; ++n)
+    for (int k = 0; k < nlev; ++k)
+      for (int64_t i = 0; i < nij1; ++i) {
+        const int64_t j = rank + (int64_t)np * i;            /* j = m-1 + np*(i-1) */
+        const int ilon = (int)(j % nlon);
+        const int ilat = (int)((j - ilon) / nlon);
+        double *f = &v3dg[k + (int64_t)nlev * (ilon + (int64_t)nlon * ilat) + (int64_t)n * nlev * nxy];
+        double *b = &x[(i + nij1 * k) * sp + (int64_t)m * sm + (int64_t)n * sv];
+        if (dir == 0) *b = *f;
+        else *f = *b;
+      }
+}
+
+/* scale/common/common_scale.f90:1570-1607 */
+void orc_ens_spread(int k, int nv, int64_t npts, const double *x, int64_t sp, int64_t sm, int64_t sv, double *sprd) {
+  for (int v = 0; v < nv; ++v)
+    for (int64_t pt = 0; pt < npts; ++pt) {
+      const double *b = x + pt * sp + v * sv;
+      const double mean = b[k * sm];
+      double s = (b[0] - mean) * (b[0] - mean);
+      for (int m = 1; m < k; ++m) s = s + (b[m * sm] - mean) * (b[m * sm] - mean);
+      sprd[pt + npts * v] = sqrt(s / (double)(k - 1));
+    }
+}

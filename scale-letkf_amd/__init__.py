@@ -68,9 +68,36 @@ class SearchTables(C.Structure):
                 ("ob_err", C.c_void_p)]
 
 
+class StateConsts(C.Structure):
+    """letkf_state_consts (include/letkf_amd.h section 4)"""
+    _fields_ = [("rdry", C.c_double), ("rvap", C.c_double), ("cvdry", C.c_double), ("pre00", C.c_double),
+                ("tracer_cv", C.c_double * 8), ("iv_rho", C.c_int32), ("iv_rhou", C.c_int32), ("iv_rhov", C.c_int32),
+                ("iv_rhow", C.c_int32), ("iv_rhot", C.c_int32), ("iv_u", C.c_int32), ("iv_v", C.c_int32),
+                ("iv_w", C.c_int32), ("iv_t", C.c_int32), ("iv_p", C.c_int32), ("iv_q", C.c_int32),
+                ("positive_definite_q", C.c_int32), ("positive_definite_qhyd", C.c_int32), ("reserved0", C.c_int32)]
+
+
+def scale_rm_consts(clamp=True):
+    """SCALE-RM's constants (scale_const / scale_tracer; NOT in the reference tree, values of SCALE-RM 5.x) with the
+    variable slots of scale/common/common_scale.f90:36-51 (rho/u, rhou/v? no: u=1 v=2 w=3 t=4 p=5 q=6..11, 0-based
+    0..10; prognostic twins share the slots: rho<->... see below)."""
+    c = StateConsts()
+    c.rdry, c.rvap, c.pre00 = 287.04, 461.46, 1.0e5
+    c.cvdry = 1004.64 - 287.04
+    for i, v in enumerate([1407.0, 4218.0, 4218.0, 2006.0, 2006.0, 2006.0]):   # QV, QC, QR, QI, QS, QG
+        c.tracer_cv[i] = v
+    # common_scale.f90:36-51: iv3d_rho=1 iv3d_rhou=2 iv3d_rhov=3 iv3d_rhow=4 iv3d_rhot=5 share the slots of
+    # iv3d_u=1 iv3d_v=2 iv3d_w=3 iv3d_t=4 iv3d_p=5 (the transform overwrites in place)
+    c.iv_rho, c.iv_rhou, c.iv_rhov, c.iv_rhow, c.iv_rhot = 0, 1, 2, 3, 4
+    c.iv_u, c.iv_v, c.iv_w, c.iv_t, c.iv_p, c.iv_q = 0, 1, 2, 3, 4, 5
+    c.positive_definite_q = c.positive_definite_qhyd = int(clamp)
+    return c
+
+
 EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", "letkf_ctx_destroy",
            "letkf_ctx_set_stream", "letkf_ctx_synchronize", "letkf_core_c", "letkf_core_batch_dev",
            "letkf_das_points_dev", "letkf_obs_search_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
+           "letkf_state_trans_dev", "letkf_member_points_dev", "letkf_ens_spread_dev",
            "letkf_ctx_timing_enable", "letkf_ctx_timing_read"]
 
 _lib = None
@@ -187,6 +214,22 @@ class Context:
                                                  _ptr(rlev), _ptr(rz), C.c_int32(1), None, _ptr(obs_off),
                                                  _ptr(obs_idx), _ptr(rdiag), _ptr(rloc)))
         return obs_off, obs_idx[:nnz], rdiag[:nnz], rloc[:nnz]
+
+    # ---- (4) the steps either side of the loop
+    def state_trans(self, consts, nlev, nlon, nlat, nv3d, v3dg, inverse=False):
+        self._check(self._l.letkf_state_trans_dev(self._c, C.byref(consts), C.c_int32(nlev), C.c_int32(nlon),
+                                                  C.c_int32(nlat), C.c_int32(nv3d), _ptr(v3dg),
+                                                  C.c_int32(1 if inverse else 0)))
+
+    def member_points(self, direction, nlev, nlon, nlat, nv3d, np_, rank, m, v3dg, x, nij1, sp, sm, sv):
+        self._check(self._l.letkf_member_points_dev(self._c, C.c_int32(direction), C.c_int32(nlev), C.c_int32(nlon),
+                                                    C.c_int32(nlat), C.c_int32(nv3d), C.c_int32(np_), C.c_int32(rank),
+                                                    C.c_int32(m), _ptr(v3dg), _ptr(x), C.c_int64(nij1), C.c_int64(sp),
+                                                    C.c_int64(sm), C.c_int64(sv)))
+
+    def ens_spread(self, k, nv, npts, x, sp, sm, sv, sprd):
+        self._check(self._l.letkf_ens_spread_dev(self._c, C.c_int32(k), C.c_int32(nv), C.c_int64(npts), _ptr(x),
+                                                 C.c_int64(sp), C.c_int64(sm), C.c_int64(sv), _ptr(sprd)))
 
     def to_perturbations(self, k, nv, npts, x, sp, sm, sv):
         self._check(self._l.letkf_ens_to_perturbations_dev(self._c, C.c_int32(k), C.c_int32(nv), C.c_int64(npts),

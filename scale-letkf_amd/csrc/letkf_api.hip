@@ -410,6 +410,37 @@ int letkf_obs_search_dev(letkf_ctx* c, const letkf_search_tables* t, int64_t npt
   return LETKF_OK;
 }
 
+int letkf_state_trans_dev(letkf_ctx* c, const letkf_state_consts* k, int32_t nlev, int32_t nlon, int32_t nlat,
+                          int32_t nv3d, double* v3dg, int32_t inverse) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!k || !v3dg || nlev < 1 || nlon < 1 || nlat < 1) return fail(LETKF_E_INVALID, "bad argument");
+  if (k->iv_q < 0 || k->iv_q >= nv3d || nv3d - k->iv_q > 8) return fail(LETKF_E_INVALID, "moisture range must be 1..8 variables");
+  HIP_TRY(letkf::launch_state_trans(*k, nlev, (long)nlon * nlat, nv3d, v3dg, inverse, c->stream));
+  return LETKF_OK;
+}
+
+int letkf_member_points_dev(letkf_ctx* c, int32_t dir, int32_t nlev, int32_t nlon, int32_t nlat, int32_t nv3d,
+                            int32_t np, int32_t rank, int32_t m, double* v3dg, double* x, int64_t nij1, int64_t sp,
+                            int64_t sm, int64_t sv) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!v3dg || !x || np < 1 || rank < 0 || rank >= np || m < 0 || nij1 < 0) return fail(LETKF_E_INVALID, "bad argument");
+  const long nxy = (long)nlon * nlat;
+  const long expect = (nxy - rank + np - 1) / np;               // points r, r+np, ... below nlon*nlat
+  if (nij1 != expect) return fail(LETKF_E_INVALID, "nij1 does not match the cyclic share of this rank");
+  if (nij1 == 0) return LETKF_OK;
+  HIP_TRY(letkf::launch_member_points(dir, nlev, nlon, nxy, nv3d, np, rank, nij1, v3dg, x, sp, (long)m * sm, sv, c->stream));
+  return LETKF_OK;
+}
+
+int letkf_ens_spread_dev(letkf_ctx* c, int32_t k, int32_t nv, int64_t npts, const double* x, int64_t sp, int64_t sm,
+                         int64_t sv, double* sprd) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!x || !sprd || k < 2 || nv < 1 || npts < 0) return fail(LETKF_E_INVALID, "bad argument");
+  if (npts == 0) return LETKF_OK;
+  HIP_TRY(letkf::launch_ens_spread(k, nv, npts, x, sp, sm, sv, sprd, c->stream));
+  return LETKF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fine boundary on host pointers: the drop-in for common/common_letkf.f90:52 used by the Fortran shim.
 // One context per calling thread (the reference calls letkf_core from inside !$OMP PARALLEL).

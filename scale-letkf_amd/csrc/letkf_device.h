@@ -82,6 +82,12 @@ hipError_t launch_point_kernel(const PointArgs& a, const LaunchPlan& p, hipStrea
 bool wave_kernel_supports(int k, int nv, int mode);
 hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st);
 hipError_t launch_ens_to_pert(int k, int nv, long npts, double* x, long sp, long sm, long sv, hipStream_t st);
+hipError_t launch_state_trans(const letkf_state_consts& c, int nlev, long nxy, int nv3d, double* v, int inverse,
+                              hipStream_t st);
+hipError_t launch_member_points(int dir, int nlev, int nlon, long nxy, int nv3d, int np, int rank, long nij1,
+                                double* v3dg, double* x, long sp, long sm_m, long sv, hipStream_t st);
+hipError_t launch_ens_spread(int k, int nv, long npts, const double* x, long sp, long sm, long sv, double* sprd,
+                             hipStream_t st);
 hipError_t launch_ens_mean(int k, int nv, long npts, double* x, long sp, long sm, long sv, hipStream_t st);
 
 }  // namespace letkf

@@ -659,6 +659,112 @@ __global__ void ens_mean_kernel(int k, int nv, long npts, double* x, long sp, lo
   }
 }
 
+
+// ------------------------------------------------------------------ row f3: state_trans, member<->points, spread
+// scale/common/common_scale.f90:1181-1224 (inverse = false) and :1229-1280 (inverse = true); one thread per (k,i,j),
+// level-fastest layout => fully coalesced, 11 reads + 5 writes per point.
+__global__ void state_trans_kernel(const letkf_state_consts C, int nlev, long nxy, int nv3d, double* v, int inverse) {
+  const long total = (long)nlev * nxy;
+  const long stride = total;                       // distance between variables
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    double* p = v + e;
+    if (inverse) {                                 // :1243-1250 positive-definite clamps
+      for (int n = C.iv_q; n < nv3d; ++n) {
+        const bool clamp = (n == C.iv_q) ? C.positive_definite_q != 0 : C.positive_definite_qhyd != 0;
+        if (clamp) p[n * stride] = fmax(p[n * stride], 0.0);
+      }
+    }
+    double qdry = 1.0, cvtot = 0.0;
+    for (int n = C.iv_q; n < nv3d; ++n) {          // :1199-1202
+      const double q = p[n * stride];
+      qdry = qdry - q;
+      cvtot = cvtot + q * C.tracer_cv[n - C.iv_q];
+    }
+    cvtot = C.cvdry * qdry + cvtot;
+    const double rtot = C.rdry * qdry + C.rvap * p[C.iv_q * stride];
+    if (!inverse) {
+      const double cpovcv = (cvtot + rtot) / cvtot;
+      const double rho = p[C.iv_rho * stride];
+      const double pres = C.pre00 * pow(p[C.iv_rhot * stride] * rtot / C.pre00, cpovcv);
+      const double temp = pres / (rho * rtot);
+      const double u = p[C.iv_rhou * stride] / rho, vv = p[C.iv_rhov * stride] / rho, w = p[C.iv_rhow * stride] / rho;
+      p[C.iv_u * stride] = u;
+      p[C.iv_v * stride] = vv;
+      p[C.iv_w * stride] = w;
+      p[C.iv_t * stride] = temp;
+      p[C.iv_p * stride] = pres;
+    } else {
+      const double cvovcp = cvtot / (cvtot + rtot);
+      const double pr = p[C.iv_p * stride];
+      const double rho = pr / (rtot * p[C.iv_t * stride]);
+      const double rhot = C.pre00 / rtot * pow(pr / C.pre00, cvovcp);
+      const double ru = p[C.iv_u * stride] * rho, rv = p[C.iv_v * stride] * rho, rw = p[C.iv_w * stride] * rho;
+      p[C.iv_rhot * stride] = rhot;
+      p[C.iv_rhow * stride] = rw;
+      p[C.iv_rhov * stride] = rv;
+      p[C.iv_rhou * stride] = ru;
+      p[C.iv_rho * stride] = rho;
+    }
+  }
+}
+
+// grd_to_buf / buf_to_grd (common_mpi_scale.f90:1428-1480) fused with the level/member re-ordering of
+// read_ens_mpi / write_ens_mpi: a 32 x 32 (level x point) tile is transposed through LDS so that both the
+// level-fastest field and the point-fastest ensemble array are touched with unit stride.
+__global__ void member_points_kernel(int dir, int nlev, int nlon, long nxy, int np, int rank, long nij1, double* v3dg,
+                                     double* x, long sp, long sm_m, long sv) {
+  __shared__ double tile[32][33];
+  const int n = blockIdx.z;                         // variable
+  const long i0 = (long)blockIdx.x * 32;            // local point tile
+  const int k0 = blockIdx.y * 32;                   // level tile
+  const int tx = threadIdx.x, ty = threadIdx.y;     // 32 x 8
+  double* fld = v3dg + (long)n * nlev * nxy;        // v3dg(k, ilon, ilat, n): level-fastest, then j = ilon-1 + nlon*(ilat-1)
+  double* xs = x + sm_m + (long)n * sv;             // slot m, variable n
+  if (dir == 0) {
+    for (int r = ty; r < 32; r += 8) {              // read: threads along k
+      const long i = i0 + r;
+      const int k = k0 + tx;
+      if (i < nij1 && k < nlev) tile[r][tx] = fld[k + (long)nlev * (rank + (long)np * i)];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {              // write: threads along the point index
+      const long i = i0 + tx;
+      const int k = k0 + r;
+      if (i < nij1 && k < nlev) xs[(i + nij1 * k) * sp] = tile[tx][r];
+    }
+  } else {
+    for (int r = ty; r < 32; r += 8) {
+      const long i = i0 + tx;
+      const int k = k0 + r;
+      if (i < nij1 && k < nlev) tile[tx][r] = xs[(i + nij1 * k) * sp];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const long i = i0 + r;
+      const int k = k0 + tx;
+      if (i < nij1 && k < nlev) fld[k + (long)nlev * (rank + (long)np * i)] = tile[r][tx];
+    }
+  }
+  (void)nlon;
+}
+
+// scale/common/common_scale.f90:1570-1607, member-order summation
+__global__ void ens_spread_kernel(int k, int nv, long npts, const double* x, long sp, long sm, long sv, double* sprd) {
+  const long total = npts * nv;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long v = e / npts, pt = e - v * npts;
+    const double* b = x + pt * sp + v * sv;
+    const double mean = b[k * sm];
+    double d = b[0] - mean;
+    double s = d * d;
+    for (int m = 1; m < k; ++m) {
+      d = b[m * sm] - mean;
+      s = s + d * d;
+    }
+    sprd[e] = sqrt(s / (double)(k - 1));
+  }
+}
+
 // ------------------------------------------------------------------ host-callable launchers
 template <bool BIG, int RMAX, int MAXT>
 static hipError_t launch_one(const PointArgs& a, int grid, int block, size_t lds, hipStream_t st) {
@@ -695,6 +801,34 @@ hipError_t launch_ens_mean(int k, int nv, long npts, double* x, long sp, long sm
   const int block = 256;
   const int grid = (int)((total + block - 1) / block < 65535L * 16 ? (total + block - 1) / block : 65535L * 16);
   hipLaunchKernelGGL(ens_mean_kernel, dim3(grid > 0 ? grid : 1), dim3(block), 0, st, k, nv, npts, x, sp, sm, sv);
+  return hipGetLastError();
+}
+
+hipError_t launch_state_trans(const letkf_state_consts& c, int nlev, long nxy, int nv3d, double* v, int inverse,
+                              hipStream_t st) {
+  const long total = (long)nlev * nxy;
+  const int block = 256;
+  long g = (total + block - 1) / block;
+  if (g > 65535L * 8) g = 65535L * 8;
+  hipLaunchKernelGGL(state_trans_kernel, dim3((unsigned)(g > 0 ? g : 1)), dim3(block), 0, st, c, nlev, nxy, nv3d, v, inverse);
+  return hipGetLastError();
+}
+
+hipError_t launch_member_points(int dir, int nlev, int nlon, long nxy, int nv3d, int np, int rank, long nij1,
+                                double* v3dg, double* x, long sp, long sm_m, long sv, hipStream_t st) {
+  dim3 grid((unsigned)((nij1 + 31) / 32), (unsigned)((nlev + 31) / 32), (unsigned)nv3d);
+  hipLaunchKernelGGL(member_points_kernel, grid, dim3(32, 8), 0, st, dir, nlev, nlon, nxy, np, rank, nij1, v3dg, x, sp,
+                     sm_m, sv);
+  return hipGetLastError();
+}
+
+hipError_t launch_ens_spread(int k, int nv, long npts, const double* x, long sp, long sm, long sv, double* sprd,
+                             hipStream_t st) {
+  const long total = npts * nv;
+  const int block = 256;
+  long g = (total + block - 1) / block;
+  if (g > 65535L * 16) g = 65535L * 16;
+  hipLaunchKernelGGL(ens_spread_kernel, dim3((unsigned)(g > 0 ? g : 1)), dim3(block), 0, st, k, nv, npts, x, sp, sm, sv, sprd);
   return hipGetLastError();
 }
 

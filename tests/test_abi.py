@@ -26,7 +26,7 @@ def declared_functions():
 def test_header_symbols_exported(pkg):
     lib = C.CDLL(pkg.LIB_PATH)
     names = declared_functions()
-    assert "letkf_core_c" in names and "letkf_das_points_dev" in names and len(names) >= 13
+    assert "letkf_core_c" in names and "letkf_das_points_dev" in names and len(names) >= 16
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/letkf_amd.h but not exported"
     assert set(names) == set(pkg.EXPORTS), "python binding list out of sync with the header"
@@ -48,13 +48,14 @@ def test_fails_loudly_without_device(pkg):
 def test_struct_layout_matches_header(pkg):
     # sizes of the argument blocks as the C compiler lays them out (guards the ctypes mirror)
     import subprocess, tempfile
-    code = '#include <stdio.h>\n#include "letkf_amd.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(letkf_core_batch_args), sizeof(letkf_das_args), sizeof(letkf_search_tables));return 0;}\n'
+    code = '#include <stdio.h>\n#include "letkf_amd.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(letkf_core_batch_args), sizeof(letkf_das_args), sizeof(letkf_search_tables), sizeof(letkf_state_consts));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "s.c")
         open(src, "w").write(code)
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
-        a, b, c = map(int, subprocess.check_output([exe]).split())
+        a, b, c, d4 = map(int, subprocess.check_output([exe]).split())
+        assert d4 == C.sizeof(pkg.StateConsts)
     assert a == C.sizeof(pkg.CoreBatchArgs)
     assert b == C.sizeof(pkg.DasArgs)
     assert c == C.sizeof(pkg.SearchTables)
