@@ -149,7 +149,7 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p) {
   if (const char* e = std::getenv("LETKF_AMD_JMIX")) a.jmix = std::atoi(e);
   if (const char* e = std::getenv("LETKF_AMD_MAX_SWEEP")) {   // profiling knob: time the non-eigensolve phases
     int v = std::atoi(e);
-    if (v > 0 && v < 60) a.max_sweep = v;
+    if (v >= 0 && v < 60) a.max_sweep = v;   // 0: skip the eigensolve entirely (timing only, results invalid)
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing) {

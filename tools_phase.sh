@@ -1,7 +1,7 @@
 #!/bin/bash
 # profiling helper: time the das kernel with the Jacobi sweep cap lowered (LETKF_AMD_MAX_SWEEP knob)
 mkdir -p gpurun_out
-for ms in 60 1 2 5; do
+for ms in 60 0 1 2; do
   LETKF_AMD_MAX_SWEEP=$ms timeout -k 10 200 python bench.py --workload ${1:-C2-mini} --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null > gpurun_out/phase_$ms.json
   python - "$ms" <<'PY'
 import sys, json
