@@ -42,6 +42,37 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
+// DPP move of a double (VALU, no LDS crossbar): 0xB1 quad_perm[1,0,3,2], 0x4E quad_perm[2,3,0,1], 0x141 row_half_mirror
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over aligned groups of 8 lanes: lane^1, lane^2, then the mirror image inside the 8 (after the first two
+// steps every lane of a quad holds the quad sum, so "7 - lane" is as good as lane^4)
+__device__ __forceinline__ double group8_sum(double v) {
+  v += dpp_mov_d<0xB1>(v);
+  v += dpp_mov_d<0x4E>(v);
+  v += dpp_mov_d<0x141>(v);
+  return v;
+}
+__device__ __forceinline__ double frsqrt2(double x) {   // v_rsq_f64 seed + 2 Newton steps
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * y, y, 1.0);
+  y = fma(y * 0.5, e, y);
+  e = fma(-x * y, y, 1.0);
+  return fma(y * 0.5, e, y);
+}
+__device__ __forceinline__ double frcp2(double x) {     // v_rcp_f64 seed + 2 Newton steps
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+
 // Bijective XCD-aware remap (blocks b and b+8 share an XCD and its L2): consecutive logical
 // work items go to the same XCD so neighbouring grid points, which read almost the same obs
 // rows, hit the same L2.  Speed only, never correctness.
@@ -67,15 +98,19 @@ __device__ __forceinline__ void rr_pair(int m, int s, int pi, int& p, int& q) {
 }
 
 // Hestenes rotation that orthogonalises two columns with squared norms a, b and inner product g.
+// tan(2 theta) = 2 g / (b - a);  t = 2 g sgn(d) / (|d| + sqrt(d^2 + 4 g^2)); hardware rsq/rcp seeds + Newton instead
+// of the IEEE division / sqrt expansions (3 + 2 of them were most of the step's FP64 issue slots)
 __device__ __forceinline__ void hestenes_cs(double a, double b, double g, double& c, double& s) {
-  const double zeta = (b - a) / (2.0 * g);
-  const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-  c = 1.0 / sqrt(1.0 + t * t);
+  const double d = b - a;
+  const double x = fma(d, d, 4.0 * g * g);
+  const double hh = x * frsqrt2(x);
+  const double t = (2.0 * g) * copysign(1.0, d) * frcp2(fabs(d) + hh);
+  c = frsqrt2(fma(t, t, 1.0));
   s = c * t;
 }
 
 constexpr double kRotTol2 = 1e-30;   // rotate when gamma^2 > kRotTol2 * alpha * beta  (|cos| > 1e-15)
-constexpr double kStopTol2 = 1e-22;  // converged when a whole sweep saw only |cos| <= 1e-11 (measured: 1e-9 leaves 5e-12 in T when n < k)
+constexpr double kStopTol2 = 1e-20;  // converged when a whole sweep saw only |cos| <= 1e-10 (all still rotated away in it)
 constexpr int kMaxSweep = 60;
 
 // ------------------------------------------------------------------ Jacobi, 8 lanes per pair, rows in registers
@@ -109,9 +144,9 @@ __device__ __forceinline__ int jacobi_cached(double* __restrict__ G, const int l
             be = fma(b[r], b[r], be);
             ga = fma(a[r], b[r], ga);
           }
-          al = group_sum<8>(al);
-          be = group_sum<8>(be);
-          ga = group_sum<8>(ga);
+          al = group8_sum(al);
+          be = group8_sum(be);
+          ga = group8_sum(ga);
           const double g2 = ga * ga, ab = al * be;
           if (g2 > kStopTol2 * ab) notconv = 1;
           if (g2 > kRotTol2 * ab) {
