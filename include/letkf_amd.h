@@ -160,6 +160,9 @@ typedef struct {
   double *pa_out;            /* dev [npts][k*k] or NULL */
   int32_t *status;           /* dev [npts] or NULL */
   int32_t *nsweep;           /* dev [npts] or NULL */
+  double *rtps_infl_out;     /* dev [npts*nv] or NULL: the RTPS factor applied to T per variable, work3da of
+                                RELAX_SPREAD_OUT (scale/letkf/letkf_tools.f90:271-276, 460-462, 735-759); 1 where
+                                no RTPS factor applies (RTPP / none / beta = 0 / Q_UPDATE_TOP skip) */
 } letkf_das_args;
 int letkf_das_points_dev(letkf_ctx *ctx, const letkf_das_args *args);
 

@@ -515,7 +515,7 @@ static int das_point(const orc_das_params *p, int64_t pt, int nobsl, const int32
                      const double *gues, double *anal, int64_t sp, int64_t sm, int64_t sv,
                      double *trans_o, double *transm_o, double *pa_o,
                      double *hdxf, double *rd, double *rl, double *dp, double *dpd,
-                     double *trans, double *transm, double *transmd, double *pa, double *wrlx) {
+                     double *trans, double *transm, double *transmd, double *pa, double *wrlx, double *rtps_o) {
   const int k = p->k, nv = p->nv;
   const double *g0 = gues + pt * sp;
   double *a0 = anal + pt * sp;
@@ -565,6 +565,7 @@ static int das_point(const orc_das_params *p, int64_t pt, int nobsl, const int32
       double xb[k], tmpinfl;
       for (int m = 0; m < k; ++m) xb[m] = g0[m * sm + v * sv];
       orc_weight_rtps(k, p->relax_alpha_spread, trans, pa, xb, parm, wrlx, &tmpinfl);
+      if (rtps_o) rtps_o[pt + npts * (size_t)v] = tmpinfl;               /* work3da(ij,ilev,n) :461-462 */
     } else {
       memcpy(wrlx, trans, sizeof(double) * (size_t)k * (size_t)k);
     }
@@ -604,6 +605,18 @@ int orc_das_letkf_points(const orc_das_params *p, int64_t npts, const int64_t *o
                          double *infl, const double *gues, double *anal, int64_t sp, int64_t sm,
                          int64_t sv, double *trans_out, double *transm_out, double *pa_out,
                          int32_t *status) {
+  return orc_das_letkf_points_diag(p, npts, obs_off, obs_idx, rdiag_l, rloc_l, ensval, kld, dep, beta, infl, gues,
+                                   anal, sp, sm, sv, trans_out, transm_out, pa_out, status, NULL);
+}
+
+int orc_das_letkf_points_diag(const orc_das_params *p, int64_t npts, const int64_t *obs_off,
+                              const int32_t *obs_idx, const double *rdiag_l, const double *rloc_l,
+                              const double *ensval, int64_t kld, const double *dep, const double *beta,
+                              double *infl, const double *gues, double *anal, int64_t sp, int64_t sm,
+                              int64_t sv, double *trans_out, double *transm_out, double *pa_out,
+                              int32_t *status, double *rtps_out) {
+  if (rtps_out)
+    for (int64_t e = 0; e < npts * p->nv; ++e) rtps_out[e] = 1.0;       /* work3da = 1.0d0 :274 */
   const int k = p->k;
   int64_t nmax = 1;
   for (int64_t pt = 0; pt < npts; ++pt) {
@@ -637,7 +650,7 @@ int orc_das_letkf_points(const orc_das_params *p, int64_t npts, const int64_t *o
                          trans_out ? trans_out + (size_t)pt * kk : NULL,
                          transm_out ? transm_out + (size_t)pt * (size_t)k : NULL,
                          pa_out ? pa_out + (size_t)pt * kk : NULL, hdxf, rd, rl, dp, dpd, trans,
-                         transm, transmd, pa, wrlx);
+                         transm, transmd, pa, wrlx, rtps_out);
       if (status) status[pt] = rc;
       if (rc != 0) {
 #pragma omp critical

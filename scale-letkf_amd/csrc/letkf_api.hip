@@ -361,6 +361,7 @@ int letkf_das_points_dev(letkf_ctx* c, const letkf_das_args* g) {
   a.pa_out = g->pa_out;
   a.status = g->status;
   a.nsweep = g->nsweep;
+  a.rtps_out = g->rtps_infl_out;
   return launch(c, a, p);
 }
 

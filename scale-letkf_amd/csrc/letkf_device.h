@@ -50,6 +50,7 @@ struct PointArgs {
   double* pa_out;
   int* status;
   int* nsweep;
+  double* rtps_out;    // [npts*nv] RTPS factor diagnostic (work3da), or null
   // large-k workspace
   double* ws;
   long ws_per_block;   // doubles

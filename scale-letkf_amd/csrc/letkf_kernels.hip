@@ -306,6 +306,8 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) letkf_point_kernel(const Poi
       }
       if (A.det_run)
         for (int v = tid; v < nv; v += nthr) a0[(k + 1) * A.sm + v * A.sv] = g0[(k + 1) * A.sm + v * A.sv];
+      if (A.rtps_out)
+        for (int v = tid; v < nv; v += nthr) A.rtps_out[pt + A.npts * (long)v] = 1.0;
       if (tid == 0) {
         if (A.status) A.status[pt] = 0;
         if (A.nsweep) A.nsweep[pt] = 0;
@@ -563,6 +565,10 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) letkf_point_kernel(const Poi
         }
         cfac[v] = cf;
         cdiag[v] = cd;
+        if (A.rtps_out) {                            // work3da (letkf_tools.f90:460-462)
+          const bool skipv = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
+          A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cf : 1.0;
+        }
       }
     }
     __syncthreads();

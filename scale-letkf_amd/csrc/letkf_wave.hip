@@ -430,6 +430,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
         if (lane < k) a0[moff + v * A.sv] = g0[k * A.sm + v * A.sv] + g0[moff + v * A.sv];
       }
       if (A.det_run && lane < nv) a0[(k + 1) * A.sm + lane * A.sv] = g0[(k + 1) * A.sm + lane * A.sv];
+      if (A.rtps_out && lane < nv) A.rtps_out[pt + A.npts * (long)lane] = 1.0;
       if (lane == 0) {
         if (A.status) A.status[pt] = 0;
         if (A.nsweep) A.nsweep[pt] = 0;
@@ -735,6 +736,10 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
             cfv = A.relax_alpha_spread * sqrt(var_g * parm / (var_a * km1)) - A.relax_alpha_spread + 1.0;
         }
         cf[v] = uniform(cfv);
+        if (A.rtps_out && lane == 0) {                     // work3da (letkf_tools.f90:460-462); skipped variables keep 1
+          const bool skipv = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
+          A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cfv : 1.0;
+        }
       }
     }
     // C = D U : w-bar spectrum 1/lam, T spectrum sqrt((k-1)/lam)

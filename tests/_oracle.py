@@ -121,7 +121,7 @@ class DasParams(C.Structure):
 
 
 def das_points(params, obs_off, obs_idx, rdiag_l, rloc_l, ensval, dep, beta, infl, gues, sp, sm, sv,
-               want_trans=False, want_pa=False):
+               want_trans=False, want_pa=False, want_rtps=False):
     """orc_das_letkf_points on flat numpy buffers.  gues: 1-D float64 buffer holding perturbations+mean(+det).
     Returns dict(anal, infl, trans, transm, pa, status, rc)."""
     k = params.k
@@ -135,9 +135,11 @@ def das_points(params, obs_off, obs_idx, rdiag_l, rloc_l, ensval, dep, beta, inf
     obs_off = np.ascontiguousarray(obs_off, dtype=np.int64)
     obs_idx = np.ascontiguousarray(obs_idx, dtype=np.int32)
     kld = ensval.shape[1]
-    rc = oracle().orc_das_letkf_points(
+    rtps = np.zeros(npts * params.nv) if want_rtps else None
+    oracle().orc_das_letkf_points_diag.restype = C.c_int
+    rc = oracle().orc_das_letkf_points_diag(
         C.byref(params), C.c_int64(npts), obs_off.ctypes.data_as(C.POINTER(C.c_int64)),
         obs_idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(rdiag_l), _dp(rloc_l), _dp(ensval), C.c_int64(kld),
         _dp(dep), _dp(beta), _dp(infl), _dp(gues), _dp(anal), C.c_int64(sp), C.c_int64(sm), C.c_int64(sv),
-        _dp(trans), _dp(transm), _dp(pa), status.ctypes.data_as(C.POINTER(C.c_int32)))
-    return dict(anal=anal, infl=infl, trans=trans, transm=transm, pa=pa, status=status, rc=rc)
+        _dp(trans), _dp(transm), _dp(pa), status.ctypes.data_as(C.POINTER(C.c_int32)), _dp(rtps))
+    return dict(anal=anal, infl=infl, trans=trans, transm=transm, pa=pa, status=status, rc=rc, rtps=rtps)

@@ -92,6 +92,29 @@ def test_das_points_weights_match():
         assert np.abs(W[p] - ref["transm"][p]).max() <= 1e-11 * max(1.0, np.abs(ref["transm"][p]).max())
 
 
+@pytest.mark.parametrize("k", [50, 100])
+def test_rtps_factor_diagnostic(k):
+    """work3da of RELAX_SPREAD_OUT (scale/letkf/letkf_tools.f90:271-276, 460-462): the RTPS factor per variable"""
+    from _gpu import ctx, dev
+    cfg = dict(relax_alpha_spread=0.9, q_update_top=49.0, det_run=1)
+    c = das_case(k=k, nv=11, npts=24, nobs_tot=500, n_mean=120, seed=77, det_run=True, infl0=1.02)
+    prm = _oracle.DasParams(k=k, nv=11, det_run=1, infl_adaptive=0, relax_to_inflated_prior=1, relax_alpha=0.0,
+                            relax_alpha_spread=0.9, q_update_top=49.0, q_sprd_max=0.0, iv_p=4, iv_q_first=5,
+                            iv_q_last=10, nthreads=2)
+    ref = _oracle.das_points(prm, c["obs_off"], c["obs_idx"], c["rdiag"], c["rloc"], c["ensval"], c["dep"],
+                             c["beta"], c["infl"], c["gues"], c["sp"], c["sm"], c["sv"], want_rtps=True)
+    anal = torch.zeros(c["gues"].size, dtype=torch.float64, device="cuda")
+    rt = torch.full((24 * 11,), -7.0, dtype=torch.float64, device="cuda")
+    ctx().das_points(k, 11, dev(c["obs_off"]), dev(c["obs_idx"]), dev(c["rdiag"]), dev(c["rloc"]), dev(c["ensval"]),
+                     c["kld"], dev(c["dep"]), dev(c["infl"]), dev(c["gues"]), anal, c["sp"], c["sm"], c["sv"],
+                     beta=dev(c["beta"]), det_run=True, relax_to_inflated_prior=1, relax_alpha_spread=0.9,
+                     q_update_top=49.0, rtps_infl_out=rt)
+    torch.cuda.synchronize()
+    got = rt.cpu().numpy()
+    assert np.abs(got - ref["rtps"]).max() <= 1e-11 * np.abs(ref["rtps"]).max()
+    assert (ref["rtps"] != 1.0).sum() > 50
+
+
 def test_das_points_odd_k_and_other_nv():
     c, ref, got, infl, status, _, _ = run_both(33, 5, 20, 300, 50, seed=9, cfg=dict(relax_alpha_spread=0.9))
     assert (status == 0).all()
