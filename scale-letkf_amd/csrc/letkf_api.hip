@@ -145,8 +145,6 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p) {
   a.ws = c->ws;
   a.ws_per_block = p.ws_per_block;
   a.max_sweep = 60;
-  a.jmix = 1;
-  if (const char* e = std::getenv("LETKF_AMD_JMIX")) a.jmix = std::atoi(e);
   if (const char* e = std::getenv("LETKF_AMD_MAX_SWEEP")) {   // profiling knob: time the non-eigensolve phases
     int v = std::atoi(e);
     if (v >= 0 && v < 60) a.max_sweep = v;   // 0: skip the eigensolve entirely (timing only, results invalid)

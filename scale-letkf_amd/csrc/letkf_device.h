@@ -34,7 +34,6 @@ struct PointArgs {
   int det_run, infl_adaptive, relax_to_inflated_prior;
   int iv_p, iv_q_first, iv_q_last;
   int add_wbar_to_trans;
-  int jmix;            // odd-step exchange of the wave kernel: 0 DPP, 1 LDS, 2 alternate (tuning knob)
   int max_sweep;       // Jacobi sweep cap (60); lowered only by the LETKF_AMD_MAX_SWEEP profiling knob
   double relax_alpha, relax_alpha_spread, q_update_top, q_sprd_max;
   // state

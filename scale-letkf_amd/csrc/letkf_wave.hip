@@ -109,9 +109,6 @@ __device__ __forceinline__ long xcd_remap_w(long orig, long n) {
 constexpr double kRotTol2W = 1e-30;   // rotate when cos^2 > 1e-30
 constexpr double kStopTol2W = 1e-20;  // sweep counts as converged when every visited pair had |cos| <= 1e-10 (all of them were
                                       // still rotated away in that sweep, so what is left is second order)
-#ifndef LETKF_KS_NUM
-#define LETKF_KS_NUM 10   // tenths of the rows that take the LDS path in odd Jacobi steps
-#endif
 constexpr int kTnW = 8;               // obs rows per LDS tile (per wave)
 constexpr int kChunk = 8;             // columns per LDS transposition chunk
 constexpr int kVld = kChunk + 2;      // row stride of the transposition buffer (doubles, even)
@@ -275,9 +272,7 @@ __device__ __forceinline__ bool jacobi_step(double (&own)[KR], double (&oth)[KR]
 // rotation identities alpha' = alpha -/+ t*gamma.  Both are refreshed once per sweep.
 // ---------------------------------------------------------------------------------------------
 template <int KR>
-__device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const int max_sweep, double* xbuf,
-                                           const int jmix) {
-  (void)jmix;
+__device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const int max_sweep, double* xbuf) {
   const int ncol = (k + 1) & ~1;   // an odd k gets one zero column as an extra (inert) participant
   double h[KR];
   int sweep = 0;
@@ -646,7 +641,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
       }
 
       // ------------------------------------------------------------ eigen-decomposition in registers
-      sweeps = jacobi_regs<KR>(g, k, A.max_sweep, slice, A.jmix);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
+      sweeps = jacobi_regs<KR>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
 
       double ss = 0.0;
 #pragma unroll
