@@ -99,6 +99,34 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A grid point is solved by NW wavefronts (NW = 1: k <= 62, 4 independent points per 256-thread workgroup;
+// NW = 2: 62 < k <= 100, one point per 128-thread workgroup).  Hand-offs through LDS between lanes of the point:
+template <int NW>
+__device__ __forceinline__ void psync() {
+  if constexpr (NW == 1) wave_lds_sync();
+  else __syncthreads();
+}
+template <int NW>
+__device__ __forceinline__ bool pany(bool v) {
+  if constexpr (NW == 1) return __any(v) != 0;
+  else return __syncthreads_or(v) != 0;
+}
+// sum / max / min over all lanes of the point.  With two waves the partials meet in a 4-double LDS scratch; `slot`
+// alternates between consecutive calls (each call has its own barrier, so slot s is free again two calls later).
+template <int NW, int OP>
+__device__ __forceinline__ double preduce(double v, double* red, int& slot) {
+  v = (OP == 0) ? wave_sum(v) : (OP == 1) ? wave_max(v) : wave_min(v);
+  if constexpr (NW == 1) {
+    return v;
+  } else {
+    if ((threadIdx.x & 63) == 0) red[2 * slot + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    const double a = red[2 * slot], b = red[2 * slot + 1];
+    slot ^= 1;
+    return (OP == 0) ? a + b : (OP == 1) ? fmax(a, b) : fmin(a, b);
+  }
+}
+
 __device__ __forceinline__ long xcd_remap_w(long orig, long n) {
   const long q = n >> 3, r = n & 7;
   const long xcd = orig & 7, j = orig >> 3;
@@ -163,10 +191,11 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // 50 v_mov_b64 per step for it).  Lanes without a partner in this step (the two ends of the line in odd steps, and
 // every lane beyond the last column) are made their own partner: they fetch their own column and all formulas
 // degenerate to the identity (gamma-driven t = 0), so no branch on `has` is needed.
-template <int KR, bool ODD>
+template <int KR, bool ODD, int NW>
 __device__ __forceinline__ bool jacobi_step(double (&own)[KR], double (&oth)[KR], double& al, double& is, double& sc,
                                             const int ncol, double* xbuf) {
-  const int lane = threadIdx.x & 63;
+  constexpr int NL = 64 * NW;                            // lanes of the point
+  const int lane = threadIdx.x & (NL - 1);
   const bool oddlane = (lane & 1) != 0;
   double be, isq, scq;
   double ga0 = 0.0, ga1 = 0.0;
@@ -193,24 +222,21 @@ __device__ __forceinline__ bool jacobi_step(double (&own)[KR], double (&oth)[KR]
     constexpr int NCH = (KR + CR - 1) / CR;
     // two chunk slots, software pipelined.  DS instructions of one wave execute in order, so a later ds_read sees
     // every earlier ds_write of the wave; only the compiler must keep program order (it has to: the two pointers may
-    // alias as far as it can tell).
-    double* smine = xbuf + 2 * 64 * LS + lane * 4;
-    const double* stheirs = xbuf + 2 * 64 * LS + pl * 4;
+    // alias as far as it can tell).  With two waves per point the pair (63, 64) straddles the waves: then every
+    // chunk hand-off is a workgroup barrier (read c, barrier, write c+2 into the slot just read).
+    double* smine = xbuf + 2 * NL * LS + lane * 4;
+    const double* stheirs = xbuf + 2 * NL * LS + pl * 4;
     smine[0] = al;
     smine[1] = is;
     smine[2] = sc;
     auto put = [&](int c) {
-      double* mine = xbuf + (c & 1) * 64 * LS + lane * LS;
+      double* mine = xbuf + (c & 1) * NL * LS + lane * LS;
 #pragma unroll
       for (int e = 0; e < CR; e += 2)
         if (c * CR + e < KR) *reinterpret_cast<double2*>(&mine[e]) = double2{own[c * CR + e], own[c * CR + e + 1]};
     };
-    put(0);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      if (c + 1 < NCH) put(c + 1);
-      __builtin_amdgcn_wave_barrier();
-      const double* theirs = xbuf + (c & 1) * 64 * LS + pl * LS;
+    auto get = [&](int c) {
+      const double* theirs = xbuf + (c & 1) * NL * LS + pl * LS;
 #pragma unroll
       for (int e = 0; e < CR; e += 2) {
         if (c * CR + e < KR) {
@@ -221,11 +247,33 @@ __device__ __forceinline__ bool jacobi_step(double (&own)[KR], double (&oth)[KR]
           ga1 = fma(own[c * CR + e + 1], t2.y, ga1);
         }
       }
+    };
+    if constexpr (NW == 1) {
+      put(0);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) put(c + 1);
+        __builtin_amdgcn_wave_barrier();
+        get(c);
+      }
+      be = stheirs[0];
+      isq = stheirs[1];
+      scq = stheirs[2];
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      put(0);
+      if (NCH > 1) put(1);
+      __syncthreads();
+      be = stheirs[0];
+      isq = stheirs[1];
+      scq = stheirs[2];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        get(c);
+        __syncthreads();
+        if (c + 2 < NCH) put(c + 2);
+      }
     }
-    be = stheirs[0];
-    isq = stheirs[1];
-    scq = stheirs[2];
-    __builtin_amdgcn_wave_barrier();
   }
   const double ga = (ga0 + ga1) * (is * isq);            // true inner product
   const bool lo = lane <= pl;
@@ -271,7 +319,7 @@ __device__ __forceinline__ bool jacobi_step(double (&own)[KR], double (&oth)[KR]
 // into the column but accumulated in a per-column inverse scale `is`, and the squared norms alpha follow the
 // rotation identities alpha' = alpha -/+ t*gamma.  Both are refreshed once per sweep.
 // ---------------------------------------------------------------------------------------------
-template <int KR>
+template <int KR, int NW>
 __device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const int max_sweep, double* xbuf) {
   const int ncol = (k + 1) & ~1;   // an odd k gets one zero column as an extra (inert) participant
   double h[KR];
@@ -292,10 +340,10 @@ __device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const i
     sc = 1.0;
     bool notconv = false;
     for (int t = 0; t < ncol; t += 2) {
-      notconv |= jacobi_step<KR, false>(g, h, al, is, sc, ncol, xbuf);
-      notconv |= jacobi_step<KR, true>(h, g, al, is, sc, ncol, xbuf);
+      notconv |= jacobi_step<KR, false, NW>(g, h, al, is, sc, ncol, xbuf);
+      notconv |= jacobi_step<KR, true, NW>(h, g, al, is, sc, ncol, xbuf);
     }
-    if (!__any(notconv)) {
+    if (!pany<NW>(notconv)) {
       ++sweep;
       break;
     }
@@ -308,16 +356,16 @@ __device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const i
 // Out[b] (lane m: row m of V C) += sum over the wave's columns j of V[m][j] * C[j][b], b < NB.
 // V[:, j] is lane j's register column vcol[], C[j][:] is lane j's crow[].  Done in chunks of
 // kChunk columns through LDS:  vbuf[KR][kVld], cbuf[kChunk][NBP].
-template <int KR, int NB>
+template <int KR, int NB, int NW>
 __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const double (&crow)[NB], double (&out)[NB],
                                              const int k, double* vbuf, double* cbuf) {
   constexpr int NBP = (NB + 1) & ~1;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & (64 * NW - 1);
 #pragma unroll
   for (int b = 0; b < NB; ++b) out[b] = 0.0;
   const int ncol = (k + 1) & ~1;                 // columns live in lanes [0, ncol) (see jacobi_regs)
   for (int j0 = 0; j0 < ncol; j0 += kChunk) {
-    wave_lds_sync();
+    psync<NW>();
     if (lane >= j0 && lane < j0 + kChunk) {
       const int jj = lane - j0;
 #pragma unroll
@@ -326,7 +374,7 @@ __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const dou
       for (int b = 0; b < NB; ++b) cbuf[jj * NBP + b] = crow[b];
       if (NBP > NB) cbuf[jj * NBP + NB] = 0.0;
     }
-    wave_lds_sync();
+    psync<NW>();
     const int mrow = lane < KR ? lane : KR - 1;
     double vv[kChunk];
 #pragma unroll
@@ -349,13 +397,13 @@ __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const dou
       pin_acc<NB>(out);
     }
   }
-  wave_lds_sync();
+  psync<NW>();
 }
 
 }  // namespace
 
 // per-wave LDS slice (doubles); mirrored by wave_lds_doubles() in letkf_api.hip
-__host__ __device__ inline int wave_slice_doubles(int KR, int nv) {
+__host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
   const int nb = nv + 2;
   int tile = kTnW * 64;                       // obs tile, also reused as vbuf (KR * kVld) and kk-output C chunk
   const int vb = KR * kVld;
@@ -364,31 +412,34 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv) {
   if (kChunk * KR > bmat) bmat = kChunk * KR;
   const int cb = kChunk * ((nb + 1) & ~1);
   const int small = 3 * kTnW + 8 * nv + 16;
-  if (tile + bmat < 1536) bmat = 1536 - tile;   // Gram transposition buffer abuf[64][18] and the Jacobi exchange
-                                               // slots (2 * 64 * 10 + 64 * 4 doubles) span tile + bmat
-  int tot = tile + bmat + cb + small;
+  if (tile + bmat < 1536 * NW) bmat = 1536 * NW - tile;   // Gram transposition buffer abuf[64 NW][18] and the Jacobi
+                                                         // exchange slots (64 NW * 24 doubles) span tile + bmat
+  int tot = tile + bmat + cb + small + 8;                // + 4 doubles of reduction scratch (two-wave points)
   return (tot + 1) & ~1;
 }
 
 // KKOUT: also materialise T / Pa (fine boundary, parity, diagnostics) -- a separate instantiation so that the
 // production kernel carries neither the code nor the registers for it.
-template <int KR, int NV, bool KKOUT>
-__global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
+template <int KR, int NV, bool KKOUT, int NW>
+__global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wave_kernel(const PointArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NB = NV + 2;
   constexpr int NBP = (NB + 1) & ~1;
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  constexpr int NL = 64 * NW;                 // lanes per point
+  const int lane = threadIdx.x & (NL - 1);    // lane of the point: column index in the eigen phase, member index after
+  const int wlane = threadIdx.x & 63;         // lane inside the wavefront (MFMA operand layout)
+  const int wvp = (NW == 1) ? 0 : (threadIdx.x >> 6);   // wave inside the point
+  const int wv = (NW == 1) ? (threadIdx.x >> 6) : 0;    // point slot inside the workgroup
   const int k = A.k;
   const int nv = A.nv;                        // == NV on the das path, 0 on the letkf_core batch path
   const double km1 = (double)(k - 1);
 
-  double* slice = smem + (size_t)wv * wave_slice_doubles(KR, NV);
+  double* slice = smem + (size_t)wv * wave_slice_doubles(KR, NV, NW);
   int tile_sz = kTnW * 64;
   if (KR * kVld > tile_sz) tile_sz = KR * kVld;
   int bmat_sz = NBP * KR;
   if (kChunk * KR > bmat_sz) bmat_sz = kChunk * KR;
-  if (tile_sz + bmat_sz < 1536) bmat_sz = 1536 - tile_sz;
+  if (tile_sz + bmat_sz < 1536 * NW) bmat_sz = 1536 * NW - tile_sz;
   double* ytile = slice;                      // [kTnW][64]
   double* vbuf = slice;                       // [KR][kVld]          (after the Gram phase)
   double* bmat = slice + tile_sz;             // [KR][NBP]
@@ -397,12 +448,14 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
   double* xsm = wrow + 3 * kTnW;              // 8 * NV + 16
   double* xmean = xsm;
   double* xdet = xsm + NV;
+  double* red = xsm + 8 * NV + 16;            // 4 doubles (+ pad): partials of two-wave reductions
+  int rslot = 0;
 
   // 4 consecutive points share a workgroup; workgroups are dealt over the XCDs so that neighbouring
   // points (which gather almost the same obs rows) hit the same L2
-  const long nB = (A.npts + 3) >> 2;
+  const long nB = (NW == 1) ? ((A.npts + 3) >> 2) : A.npts;
   for (long B = blockIdx.x; B < nB; B += gridDim.x) {
-    const long pt = xcd_remap_w(B, nB) * 4 + wv;
+    const long pt = (NW == 1) ? xcd_remap_w(B, nB) * 4 + wv : xcd_remap_w(B, nB);
     if (pt >= A.npts) continue;
     long o0 = 0;
     int n = 0;
@@ -460,7 +513,8 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
       v4d acc[NTILE];
 #pragma unroll
       for (int t = 0; t < NTILE; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
-      const int q = lane >> 4, c16 = lane & 15;
+      const int q = wlane >> 4, c16 = wlane & 15;
+      const int ioff = 4 * wvp;                               // with two waves each takes every other 4-obs chunk
 
       // Software pipeline, three loads deep, so that no load is consumed in the iteration that issued it (the first
       // version waited a full memory latency per 4-obs chunk on the obs_idx -> dep dependent pair):
@@ -531,20 +585,20 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
       // 10 MFMAs of a 4-obs chunk already cover the row-load latency; 16-obs stages only added padding work
       // (C2-mini: 2.9 ms vs 1.9 ms for the non-eigensolve part).
       constexpr int kGS = 1;
-      constexpr int kStage = 4 * kGS;
+      constexpr int kStage = 4 * kGS * NW;
       StA a2[kGS];
       StB b0[kGS], b1[kGS];
       double f0[kGS][NBLK], f1[kGS][NBLK];
 #pragma unroll
-      for (int u = 0; u < kGS; ++u) a2[u] = stage_a(4 * u);
+      for (int u = 0; u < kGS; ++u) a2[u] = stage_a(4 * u + ioff);
 #pragma unroll
       for (int u = 0; u < kGS; ++u) b0[u] = stage_b(a2[u]);
 #pragma unroll
-      for (int u = 0; u < kGS; ++u) a2[u] = stage_a(kStage + 4 * u);
+      for (int u = 0; u < kGS; ++u) a2[u] = stage_a(kStage + 4 * u + ioff);
 #pragma unroll
       for (int u = 0; u < kGS; ++u) b1[u] = stage_b(a2[u]);
 #pragma unroll
-      for (int u = 0; u < kGS; ++u) a2[u] = stage_a(2 * kStage + 4 * u);
+      for (int u = 0; u < kGS; ++u) a2[u] = stage_a(2 * kStage + 4 * u + ioff);
 #pragma unroll
       for (int u = 0; u < kGS; ++u) load_rows(b0[u], f0[u]);
       for (int i0 = 0; i0 < n; i0 += kStage) {
@@ -554,7 +608,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
 #pragma unroll
         for (int u = 0; u < kGS; ++u) b2[u] = stage_b(a2[u]);
 #pragma unroll
-        for (int u = 0; u < kGS; ++u) a2[u] = stage_a(i0 + 3 * kStage + 4 * u);
+        for (int u = 0; u < kGS; ++u) a2[u] = stage_a(i0 + 3 * kStage + 4 * u + ioff);
 #pragma unroll
         for (int u = 0; u < kGS; ++u) {
           // augmented columns and scaling of the current sub-chunk
@@ -589,40 +643,50 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
       // accumulator tiles -> "lane j owns column j": 16 rows at a time through LDS.  C/D layout of the f64 MFMA:
       // lane l holds rows (l>>4) + 4*reg, column l&15 of its 16x16 tile.
       constexpr int LDA = 18;
-      double* abuf = slice;                                    // [64][LDA], spans the tile + bmat regions
+      double* abuf = slice;                                    // [64 NW][LDA], spans the tile + bmat regions
 #pragma unroll
       for (int I = 0; I < NBLK; ++I) {
-        wave_lds_sync();
+        psync<NW>();
+        // wave 0 stores its partial tiles, wave 1 (two-wave points) adds its own on top
 #pragma unroll
-        for (int J = 0; J < NBLK; ++J) {
-          const int ti = I <= J ? I : J, tj = I <= J ? J : I;
-          const int t = ti * NBLK - ti * (ti - 1) / 2 + (tj - ti);
+        for (int pass = 0; pass < NW; ++pass) {
+          if (pass == 1) __syncthreads();
+          if (wvp == pass) {
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int a = q + 4 * reg, b = c16;                // tile-local (row, col) of this element
-            // rows of block I, columns of block J: element (I:a, J:b) directly, or the mirror of tile (J, I)
-            if (I <= J) abuf[(16 * J + b) * LDA + a] = acc[t][reg];
-            else abuf[(16 * J + a) * LDA + b] = acc[t][reg];
+            for (int J = 0; J < NBLK; ++J) {
+              const int ti = I <= J ? I : J, tj = I <= J ? J : I;
+              const int t = ti * NBLK - ti * (ti - 1) / 2 + (tj - ti);
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) {
+                const int a = q + 4 * reg, b = c16;            // tile-local (row, col) of this element
+                // rows of block I, columns of block J: element (I:a, J:b) directly, or the mirror of tile (J, I)
+                double* dst = (I <= J) ? &abuf[(16 * J + b) * LDA + a] : &abuf[(16 * J + a) * LDA + b];
+                if (pass == 0) *dst = acc[t][reg];
+                else *dst += acc[t][reg];
+              }
+            }
           }
         }
-        wave_lds_sync();
+        psync<NW>();
+        if (lane < 16 * NBLK) {
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          if (16 * I + e < KR) {
-            const double2 v2 = *reinterpret_cast<const double2*>(&abuf[lane * LDA + e]);
-            g[16 * I + e] = v2.x;
-            g[16 * I + e + 1] = v2.y;
+          for (int e = 0; e < 16; e += 2) {
+            if (16 * I + e < KR) {
+              const double2 v2 = *reinterpret_cast<const double2*>(&abuf[lane * LDA + e]);
+              g[16 * I + e] = v2.x;
+              g[16 * I + e + 1] = v2.y;
+            }
           }
+          if ((k >> 4) == I) racc = abuf[lane * LDA + (k & 15)];
+          if (((k + 1) >> 4) == I) rdacc = abuf[lane * LDA + ((k + 1) & 15)];
         }
-        if ((k >> 4) == I) racc = abuf[lane * LDA + (k & 15)];
-        if (((k + 1) >> 4) == I) rdacc = abuf[lane * LDA + ((k + 1) & 15)];
+        if ((k >> 4) == I) p1 = abuf[k * LDA + (k & 15)];      // A_aug[k][k] = sum w dep^2
       }
-      wave_lds_sync();
-      p1 = wshfl(racc, k);                                     // A_aug[k][k] = sum w dep^2
+      psync<NW>();
       // rows >= k of a column (the augmented rows) and whole columns >= k play no part in the eigenproblem
 #pragma unroll
       for (int r = 0; r < KR; ++r)
-        if (r >= k || lane >= k) g[r] = 0.0;
+        if (r >= k || lane >= k || lane >= 16 * NBLK) g[r] = 0.0;
       // diagonal: trace for the adaptive inflation, then the shift (common_letkf.f90:140-143)
       const double shift = km1 / infl_old;
       double diag = 0.0;
@@ -636,12 +700,12 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
       double parm1 = 0.0, parm2 = 0.0, parm3 = 0.0;
       if (A.infl_adaptive) {
         parm1 = p1;
-        parm3 = wave_sum(p3);
-        parm2 = wave_sum(lane < k ? diag : 0.0) / km1;
+        parm3 = preduce<NW, 0>(p3, red, rslot);
+        parm2 = preduce<NW, 0>(lane < k ? diag : 0.0, red, rslot) / km1;
       }
 
       // ------------------------------------------------------------ eigen-decomposition in registers
-      sweeps = jacobi_regs<KR>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
+      sweeps = jacobi_regs<KR, NW>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
 
       double ss = 0.0;
 #pragma unroll
@@ -670,8 +734,8 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
     // ------------------------------------------------------------ status (common_mtx.f90:66-78)
     int st = 0;
     {
-      const double lmx = wave_max(colvalid ? lam : 0.0);
-      const double lmn = wave_min(colvalid ? lam : 1e300);
+      const double lmx = preduce<NW, 1>(colvalid ? lam : 0.0, red, rslot);
+      const double lmn = preduce<NW, 2>(colvalid ? lam : 1e300, red, rslot);
       if (sweeps >= A.max_sweep && A.max_sweep >= 60) st = 1;
       else if (!(lmx > 0.0)) st = 2;
       else if (lmn < lmx * 1.4901161193847656e-08) st = 3;
@@ -680,7 +744,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
     const double sc2 = colvalid ? 1.0 / lam : 0.0;            // Pa spectrum
 
     // ------------------------------------------------------------ B = [r, r_det, x'_v] as bmat[m][NBP]; U = V^T B
-    wave_lds_sync();
+    psync<NW>();
     if (lane < KR) {
       bmat[lane * NBP + 0] = (lane < k) ? racc : 0.0;
       bmat[lane * NBP + 1] = (lane < k) ? rdacc : 0.0;
@@ -699,7 +763,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
         xdet[lane] = A.det_run ? g0[(k + 1) * A.sm + lane * A.sv] : 0.0;
       }
     }
-    wave_lds_sync();
+    psync<NW>();
     double crow[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) crow[b] = 0.0;
@@ -725,8 +789,8 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
         } else if (A.relax_alpha_spread != 0.0) {
           const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391
           const double x = (lane < k) ? bmat[mrow_l * NBP + 2 + v] : 0.0;
-          const double var_g = wave_sum(x * x);
-          const double var_a = wave_sum(crow[2 + v] * crow[2 + v] * sc2);
+          const double var_g = preduce<NW, 0>(x * x, red, rslot);
+          const double var_a = preduce<NW, 0>(crow[2 + v] * crow[2 + v] * sc2, red, rslot);
           if (var_g > 0.0 && var_a > 0.0)
             cfv = A.relax_alpha_spread * sqrt(var_g * parm / (var_a * km1)) - A.relax_alpha_spread + 1.0;
         }
@@ -744,7 +808,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
     for (int v = 0; v < NV; ++v) crow[2 + v] *= sc1;
 
     double out[NB];
-    rows_times_c<KR, NB>(g, crow, out, k, vbuf, cbuf);   // lane m: out[0] = w-bar_m, out[1] = w-bar_det_m, out[2+v] = (T x'_v)_m
+    rows_times_c<KR, NB, NW>(g, crow, out, k, vbuf, cbuf);   // lane m: out[0] = w-bar_m, out[1] = w-bar_det_m, out[2+v] = (T x'_v)_m
 
     // ------------------------------------------------------------ analysis members (letkf_tools.f90:472-513)
     if (NV > 0 && A.mode == 0) {
@@ -753,8 +817,8 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
       for (int v = 0; v < NV; ++v) {
         const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
         const double x = (lane < k) ? bmat[mrow_l * NBP + 2 + v] : 0.0;
-        const double sdot = wave_sum(x * out[0]);
-        const double sdotd = A.det_run ? wave_sum(x * out[1]) : 0.0;
+        const double sdot = preduce<NW, 0>(x * out[0], red, rslot);
+        const double sdotd = A.det_run ? preduce<NW, 0>(x * out[1], red, rslot) : 0.0;
         const double xm = xmean[v];
         double val;
         if (skip) {
@@ -768,9 +832,9 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
           const double pert = cf[v] * out[2 + v] + cdv * x;
           val = xm + beta * (pert + sdot) + (1.0 - beta) * x;
           if (A.q_sprd_max > 0.0 && v == A.iv_q_first) {      // :500-513
-            const double q_mean = wave_sum(lane < k ? val : 0.0) / (double)k;
+            const double q_mean = preduce<NW, 0>(lane < k ? val : 0.0, red, rslot) / (double)k;
             const double dq = (lane < k) ? val - q_mean : 0.0;
-            const double q_sprd = sqrt(wave_sum(dq * dq) / km1) / q_mean;
+            const double q_sprd = sqrt(preduce<NW, 0>(dq * dq, red, rslot) / km1) / q_mean;
             if (q_sprd > A.q_sprd_max) val = q_mean + dq * A.q_sprd_max / q_sprd;
           }
         }
@@ -807,7 +871,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
         double* ckk = bmat;                       // [kChunk][KR], B vectors are dead by now
         const int ncol = (k + 1) & ~1;
         for (int j0 = 0; j0 < ncol; j0 += kChunk) {
-          wave_lds_sync();
+          psync<NW>();
           if (lane >= j0 && lane < j0 + kChunk) {
             const int jj = lane - j0;
 #pragma unroll
@@ -816,7 +880,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
               ckk[jj * KR + r] = sc * g[r];
             }
           }
-          wave_lds_sync();
+          psync<NW>();
           const int mrow = lane < KR ? lane : KR - 1;
           const int nj = min(kChunk, ncol - j0);
           for (int jj = 0; jj < nj; ++jj) {
@@ -829,7 +893,7 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
             }
           }
         }
-        wave_lds_sync();
+        psync<NW>();
         // lane m holds row m; the matrices are symmetric, so write it as column m (coalescing is irrelevant here)
         if (lane < k) {
           const double add = (which == 0 && A.add_wbar_to_trans) ? 1.0 : 0.0;
@@ -848,41 +912,46 @@ __global__ void __launch_bounds__(256, 2) letkf_wave_kernel(const PointArgs A) {
 }
 
 // ------------------------------------------------------------------ host launcher
-template <int KR, int NV, bool KKOUT>
-static hipError_t launch_wave(const PointArgs& a, int grid, hipStream_t st) {
-  const size_t lds = (size_t)4 * wave_slice_doubles(KR, NV) * sizeof(double);
+template <int KR, int NV, bool KKOUT, int NW>
+static hipError_t launch_wave(const PointArgs& a, int num_cu, hipStream_t st) {
+  const size_t lds = (size_t)(NW == 1 ? 4 : 1) * wave_slice_doubles(KR, NV, NW) * sizeof(double);
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_wave_kernel<KR, NV, KKOUT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_wave_kernel<KR, NV, KKOUT, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((letkf_wave_kernel<KR, NV, KKOUT>), dim3(grid), dim3(256), lds, st, a);
+  const long nwg = (NW == 1) ? (a.npts + 3) / 4 : a.npts;
+  const long g = (long)num_cu * 16;
+  const int grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
+  hipLaunchKernelGGL((letkf_wave_kernel<KR, NV, KKOUT, NW>), dim3(grid), dim3(NW == 1 ? 256 : 128), lds, st, a);
   return hipGetLastError();
 }
 
 bool wave_kernel_supports(int k, int nv, int mode) {
-  if (k > 62) return false;   // k + 2 augmented Gram columns must fit the 64 lanes
+  // one wave per point up to k = 62 (k + 2 augmented Gram columns in 64 lanes); two waves for 65..100, where the
+  // columns no longer fit the 256 VALU-addressable VGPRs twice and part of them lives in AGPRs (measured: 170 k
+  // solves/s at k = 100 against 79 k for the workgroup kernel; at k = 63, 64 the workgroup kernel is still ahead)
+  if (k > 100 || k == 63 || k == 64) return false;
   if (mode == 0) return nv == 11;
   return nv == 0;
 }
 
 hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st) {
-  const long nwg = (a.npts + 3) / 4;
-  long g = (long)num_cu * 16;
-  const int grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
   const int k = a.k;
   const bool kkout = a.trans_out || a.pa_out;
-#define LETKF_WAVE_CASE(KR)                                                            \
-  if (k <= KR) {                                                                       \
-    if (a.mode == 0)                                                                   \
-      return kkout ? launch_wave<KR, 11, true>(a, grid, st) : launch_wave<KR, 11, false>(a, grid, st); \
-    return launch_wave<KR, 0, true>(a, grid, st);                                      \
+#define LETKF_WAVE_CASE(KR, NW)                                                                                 \
+  if (k <= (NW == 1 ? (KR < 62 ? KR : 62) : KR)) {                                                              \
+    if (a.mode == 0)                                                                                            \
+      return kkout ? launch_wave<KR, 11, true, NW>(a, num_cu, st) : launch_wave<KR, 11, false, NW>(a, num_cu, st); \
+    return launch_wave<KR, 0, true, NW>(a, num_cu, st);                                                         \
   }
-  LETKF_WAVE_CASE(16)
-  LETKF_WAVE_CASE(32)
-  LETKF_WAVE_CASE(48)
-  LETKF_WAVE_CASE(50)
-  LETKF_WAVE_CASE(64)
+  LETKF_WAVE_CASE(16, 1)
+  LETKF_WAVE_CASE(32, 1)
+  LETKF_WAVE_CASE(48, 1)
+  LETKF_WAVE_CASE(50, 1)
+  LETKF_WAVE_CASE(64, 1)
+  LETKF_WAVE_CASE(80, 2)
+  LETKF_WAVE_CASE(100, 2)
 #undef LETKF_WAVE_CASE
   return hipErrorInvalidValue;
 }
