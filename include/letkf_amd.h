@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LETKF_AMD_ABI_VERSION 1
+#define LETKF_AMD_ABI_VERSION 2
 
 /* host-side errors (function return values) */
 #define LETKF_OK 0
@@ -163,6 +163,10 @@ typedef struct {
   double *rtps_infl_out;     /* dev [npts*nv] or NULL: the RTPS factor applied to T per variable, work3da of
                                 RELAX_SPREAD_OUT (scale/letkf/letkf_tools.f90:271-276, 460-462, 735-759); 1 where
                                 no RTPS factor applies (RTPP / none / beta = 0 / Q_UPDATE_TOP skip) */
+  int32_t warm_run;          /* eigensolver warm start: consecutive points are solved in runs, each solve started
+                                from the eigenvectors of the point before it (same results to rounding; fewer sweeps
+                                when consecutive points are spatial neighbours, as in gues3d's ij-fastest order).
+                                0 = library default (runs of up to 16), 1 = off, n > 1 = runs of n points */
 } letkf_das_args;
 int letkf_das_points_dev(letkf_ctx *ctx, const letkf_das_args *args);
 

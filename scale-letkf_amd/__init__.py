@@ -52,7 +52,8 @@ class DasArgs(C.Structure):
                 ("dep", C.c_void_p), ("beta", C.c_void_p), ("infl", C.c_void_p), ("gues", C.c_void_p),
                 ("anal", C.c_void_p), ("sp", C.c_int64), ("sm", C.c_int64), ("sv", C.c_int64),
                 ("trans_out", C.c_void_p), ("transm_out", C.c_void_p), ("pa_out", C.c_void_p),
-                ("status", C.c_void_p), ("nsweep", C.c_void_p), ("rtps_infl_out", C.c_void_p)]
+                ("status", C.c_void_p), ("nsweep", C.c_void_p), ("rtps_infl_out", C.c_void_p),
+                ("warm_run", C.c_int32)]
 
 
 class SearchTables(C.Structure):
@@ -180,7 +181,8 @@ class Context:
     def das_points(self, k, nv, obs_off, obs_idx, rdiag_l, rloc_l, ensval, kld, dep, infl, gues, anal, sp, sm, sv,
                    beta=None, det_run=False, infl_adaptive=False, relax_to_inflated_prior=False, relax_alpha=0.0,
                    relax_alpha_spread=0.0, q_update_top=0.0, q_sprd_max=0.0, iv_p=4, iv_q_first=5, iv_q_last=10,
-                   trans_out=None, transm_out=None, pa_out=None, status=None, nsweep=None, rtps_infl_out=None):
+                   trans_out=None, transm_out=None, pa_out=None, status=None, nsweep=None, rtps_infl_out=None,
+                   warm_run=0):
         a = DasArgs()
         a.k, a.nv, a.det_run, a.infl_adaptive = k, nv, int(bool(det_run)), int(bool(infl_adaptive))
         a.relax_to_inflated_prior = int(bool(relax_to_inflated_prior))
@@ -194,6 +196,7 @@ class Context:
         a.trans_out, a.transm_out, a.pa_out = _ptr(trans_out), _ptr(transm_out), _ptr(pa_out)
         a.status, a.nsweep = _ptr(status), _ptr(nsweep)
         a.rtps_infl_out = _ptr(rtps_infl_out)
+        a.warm_run = int(warm_run)
         self._check(self._l.letkf_das_points_dev(self._c, C.byref(a)))
 
     # ---- (3) obs_local on the device: two-phase CSR build (count, scan, fill)

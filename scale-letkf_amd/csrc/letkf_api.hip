@@ -44,6 +44,8 @@ struct letkf_ctx {
   hipStream_t stream = nullptr;
   double* ws = nullptr;       // large-k workspace
   size_t ws_bytes = 0;
+  char* warm_ws = nullptr;    // wave kernel: eigenvectors handed from point to point inside a run
+  size_t warm_ws_bytes = 0;
   char* scratch = nullptr;    // staging for the host-pointer entry
   size_t scratch_bytes = 0;
   bool timing = false;
@@ -138,7 +140,7 @@ int ensure_ws(letkf_ctx* c, const Plan& p) {
   return LETKF_OK;
 }
 
-int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p) {
+int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
   a.ldg = p.ldg;
   a.ldy = p.ldy;
   a.tn = p.tn;
@@ -158,9 +160,18 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p) {
   // k <= 64: one wavefront per grid point, matrix in registers (letkf_wave.hip); otherwise one workgroup per
   // point with the matrix in LDS, or in the HBM workspace for large k (letkf_kernels.hip)
   static const bool force_block = std::getenv("LETKF_AMD_FORCE_BLOCK") != nullptr;
-  if (!force_block && letkf::wave_kernel_supports(a.k, a.nv, a.mode))
+  if (!force_block && letkf::wave_kernel_supports(a.k, a.nv, a.mode)) {
+    int run_req = warm_run;
+    if (const char* e = std::getenv("LETKF_AMD_RUN_LEN")) run_req = std::atoi(e);   // experiments: 1 = all cold
+    size_t wbytes = 0;
+    letkf::wave_launch_shape(a.k, a.mode, a.npts, c->num_cu, run_req, &a.run_len, &a.wave_grid, &wbytes);
+    if (wbytes > c->warm_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));   // old buffer may still be in use
+    if (int rc = ensure_bytes(c, &c->warm_ws, &c->warm_ws_bytes, wbytes)) return rc;
+    a.warm_ws = reinterpret_cast<double*>(c->warm_ws);
+    a.warm_dbg = 0;
+    if (const char* e = std::getenv("LETKF_AMD_WARM_DBG")) a.warm_dbg = std::atoi(e);
     HIP_TRY(letkf::launch_wave_kernel(a, c->num_cu, c->stream));
-  else
+  } else
     HIP_TRY(letkf::launch_point_kernel(a, p.lp, c->stream));
   if (c->timing) {
     HIP_TRY(hipEventRecord(e1, c->stream));
@@ -226,6 +237,7 @@ int letkf_ctx_destroy(letkf_ctx* c) {
       (void)hipEventDestroy(ev.second);
     }
     if (c->ws) (void)hipFree(c->ws);
+    if (c->warm_ws) (void)hipFree(c->warm_ws);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   }
@@ -360,7 +372,7 @@ int letkf_das_points_dev(letkf_ctx* c, const letkf_das_args* g) {
   a.status = g->status;
   a.nsweep = g->nsweep;
   a.rtps_out = g->rtps_infl_out;
-  return launch(c, a, p);
+  return launch(c, a, p, g->warm_run < 0 ? 0 : g->warm_run);
 }
 
 int letkf_ens_to_perturbations_dev(letkf_ctx* c, int32_t k, int32_t nv, int64_t npts, double* x, int64_t sp,

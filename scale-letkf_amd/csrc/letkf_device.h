@@ -53,6 +53,9 @@ struct PointArgs {
   // large-k workspace
   double* ws;
   long ws_per_block;   // doubles
+  // wave kernel: launch shape and warm-start workspace (wave_launch_shape)
+  double* warm_ws;
+  int run_len, wave_grid, warm_dbg;
 };
 
 struct LaunchPlan {
@@ -80,6 +83,7 @@ hipError_t launch_search(const SearchArgs& a, int num_cu, hipStream_t st);
 
 hipError_t launch_point_kernel(const PointArgs& a, const LaunchPlan& p, hipStream_t st);
 bool wave_kernel_supports(int k, int nv, int mode);
+void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, int* run_len, int* grid, size_t* ws_bytes);
 hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st);
 hipError_t launch_ens_to_pert(int k, int nv, long npts, double* x, long sp, long sm, long sv, hipStream_t st);
 hipError_t launch_state_trans(const letkf_state_consts& c, int nlev, long nxy, int nv3d, double* v, int inverse,

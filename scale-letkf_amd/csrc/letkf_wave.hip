@@ -400,6 +400,57 @@ __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const dou
   psync<NW>();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Warm start of the eigensolve: G0 = A Q with Q the eigenvector matrix of the PREVIOUS point of this wave's run.
+// One-sided Jacobi on A Q (any orthogonal Q) still ends with columns lambda_j v_j of A -- the accumulated rotation
+// is simply Q^T V -- but neighbouring grid points see almost the same observations, so Q nearly diagonalises A and
+// the slow linear phase of the iteration (6 of the 9 sweeps at k = 50) is skipped: 9.1 -> 6.0 sweeps on the C2
+// workload for x- or y-neighbours, no worse than the cold start for an unrelated Q.  Q's departure from
+// orthogonality is the previous point's final residual (< 1e-10 measured BEFORE its last sweep rotated it away),
+// so errors do not accumulate along a run.
+//
+// Lane j needs (A Q)[:, j] = sum_i A[:, i] Q[i][j]: its own Q column comes back from the wave's global workspace
+// slot a chunk at a time (it cannot stay in registers: 256 VGPRs hold g, h and nothing else); A[r][i] is register
+// g[r] of lane i, broadcast through v_readlane_b32 x2 into an SGPR pair that the FMA takes as its scalar operand.
+// Measured (tools/ubench_readlane.hip): 5.6 ns per readlane-pair + FMA against 2.35 ns for a bare v_fma_f64, i.e.
+// the whole product costs half a sweep; the first version broadcast A from LDS (ds_read_b128) and ran into the
+// LDS return bandwidth that the odd Jacobi steps of the other waves already load to ~70 % (1.6 sweeps' worth).
+// ---------------------------------------------------------------------------------------------
+constexpr int kWC = 8;   // Q rows per chunk
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+template <int KR, int NW>
+__device__ __forceinline__ void warm_start_product(double (&g)[KR], const double* __restrict__ uws, const int k) {
+  static_assert(NW == 1, "readlane broadcast stays inside one wavefront");
+  constexpr int NL = 64 * NW;
+  const int ncol = (k + 1) & ~1;
+  double out[KR];
+#pragma unroll
+  for (int r = 0; r < KR; ++r) out[r] = 0.0;
+  double un[kWC];
+#pragma unroll
+  for (int q = 0; q < kWC; ++q) un[q] = (q < ncol) ? uws[(size_t)q * NL] : 0.0;
+#pragma unroll 1
+  for (int i0 = 0; i0 < ncol; i0 += kWC) {
+    double u[kWC];
+#pragma unroll
+    for (int q = 0; q < kWC; ++q) u[q] = un[q];
+#pragma unroll
+    for (int q = 0; q < kWC; ++q) un[q] = (i0 + kWC + q < ncol) ? uws[(size_t)(i0 + kWC + q) * NL] : 0.0;
+#pragma unroll
+    for (int q = 0; q < kWC; ++q) {
+      const int i = i0 + q;            // < 64: lanes >= ncol hold zero columns and meet u = 0
+#pragma unroll
+      for (int r = 0; r < KR; ++r) out[r] = fma(lane_bcast(g[r], i), u[q], out[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < KR; ++r) g[r] = out[r];
+}
+
 }  // namespace
 
 // per-wave LDS slice (doubles); mirrored by wave_lds_doubles() in letkf_api.hip
@@ -451,12 +502,22 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
   double* red = xsm + 8 * NV + 16;            // 4 doubles (+ pad): partials of two-wave reductions
   int rslot = 0;
 
-  // 4 consecutive points share a workgroup; workgroups are dealt over the XCDs so that neighbouring
-  // points (which gather almost the same obs rows) hit the same L2
-  const long nB = (NW == 1) ? ((A.npts + 3) >> 2) : A.npts;
+  // Each wave walks a RUN of run_len consecutive points (warm-started eigensolves, see warm_start_product); the 4
+  // runs of a workgroup are consecutive too, and workgroups are dealt over the XCDs so that neighbouring points
+  // (which gather almost the same obs rows) hit the same L2
+  constexpr bool WARM = (NW == 1);
+  constexpr int PPW = (NW == 1) ? 4 : 1;      // points in flight per workgroup
+  const int run_len = WARM ? A.run_len : 1;
+  const long per_wg = (long)PPW * run_len;
+  const long nB = (A.npts + per_wg - 1) / per_wg;
+  // this wave's slot of the warm-start workspace: [KR][NL] doubles, lane-fastest
+  double* uws = (WARM && run_len > 1) ? A.warm_ws + ((size_t)blockIdx.x * PPW + wv) * ((size_t)KR * NL) + lane : nullptr;
   for (long B = blockIdx.x; B < nB; B += gridDim.x) {
-    const long pt = (NW == 1) ? xcd_remap_w(B, nB) * 4 + wv : xcd_remap_w(B, nB);
-    if (pt >= A.npts) continue;
+   const long run0 = xcd_remap_w(B, nB) * per_wg + (long)wv * run_len;
+   bool have_u = false;
+   for (int ir = 0; ir < run_len; ++ir) {
+    const long pt = run0 + ir;
+    if (pt >= A.npts) break;
     long o0 = 0;
     int n = 0;
     double beta = 1.0;
@@ -705,6 +766,9 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       }
 
       // ------------------------------------------------------------ eigen-decomposition in registers
+      if constexpr (WARM) {
+        if (have_u && !(A.warm_dbg & 1)) warm_start_product<KR, NW>(g, uws, k);
+      }
       sweeps = jacobi_regs<KR, NW>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
 
       double ss = 0.0;
@@ -730,6 +794,22 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       for (int r = 0; r < KR; ++r) g[r] = (r == lane && lane < k) ? 1.0 : 0.0;
     }
     const double infl_new = (A.infl_adaptive && n > 0) ? p1 : infl_old;
+    if constexpr (WARM) {
+      // leave the eigenvectors behind for the next point of the run.  Here, while g is still entirely in registers:
+      // further down part of it is spilled, and a store loop that alternates scratch reloads with global stores
+      // pays one store-acknowledge latency per element (s_waitcnt vmcnt counts both) -- measured 41 us per point.
+      if (uws && !(A.warm_dbg & 2)) {
+        // (the pointer is laundered every 8 rows: otherwise all KR row addresses are hoisted out of the point loop
+        // as 64-bit values, spilled, and reloaded one by one in front of each store -- same serialisation)
+        double* p = uws;
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+          if ((r & 7) == 0) asm volatile("" : "+v"(p));
+          p[(size_t)(r & 7) * NL] = g[r];
+          if ((r & 7) == 7) p += 8 * NL;
+        }
+      }
+    }
 
     // ------------------------------------------------------------ status (common_mtx.f90:66-78)
     int st = 0;
@@ -740,6 +820,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       else if (!(lmx > 0.0)) st = 2;
       else if (lmn < lmx * 1.4901161193847656e-08) st = 3;
     }
+    if constexpr (WARM) have_u = uws != nullptr && st == 0;
     const double sc1 = colvalid ? sqrt(km1 / lam) : 0.0;      // T spectrum
     const double sc2 = colvalid ? 1.0 / lam : 0.0;            // Pa spectrum
 
@@ -908,6 +989,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       if (A.status) A.status[pt] = st;
       if (A.nsweep) A.nsweep[pt] = sweeps;
     }
+   }
   }
 }
 
@@ -920,10 +1002,8 @@ static hipError_t launch_wave(const PointArgs& a, int num_cu, hipStream_t st) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  const long nwg = (NW == 1) ? (a.npts + 3) / 4 : a.npts;
-  const long g = (long)num_cu * 16;
-  const int grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
-  hipLaunchKernelGGL((letkf_wave_kernel<KR, NV, KKOUT, NW>), dim3(grid), dim3(NW == 1 ? 256 : 128), lds, st, a);
+  hipLaunchKernelGGL((letkf_wave_kernel<KR, NV, KKOUT, NW>), dim3(a.wave_grid), dim3(NW == 1 ? 256 : 128), lds, st, a);
+  (void)num_cu;
   return hipGetLastError();
 }
 
@@ -934,6 +1014,33 @@ bool wave_kernel_supports(int k, int nv, int mode) {
   if (k > 100 || k == 63 || k == 64) return false;
   if (mode == 0) return nv == 11;
   return nv == 0;
+}
+
+static int wave_kr(int k) {
+  return k <= 16 ? 16 : k <= 32 ? 32 : k <= 48 ? 48 : k <= 50 ? 50 : k <= 62 ? 64 : k <= 80 ? 80 : 100;
+}
+
+// Launch shape of the wave kernel: run length of the warm-started runs, grid, and the bytes of warm-start workspace
+// (one [KR][64] slot per resident-or-not wave of the grid).  run_req: 0 = library default, 1 = every point cold,
+// n > 1 = runs of n points.
+void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, int* run_len, int* grid, size_t* ws_bytes) {
+  const bool one_wave = k <= 62;
+  int R = 1;
+  if (one_wave && mode == 0) {
+    if (run_req > 0) R = run_req;
+    else {
+      // runs of 16 (first point of a run is a cold start), shortened until there are >= 4 workgroups per CU
+      long r = npts / (4L * num_cu * 4);
+      R = (int)(r < 1 ? 1 : r > 16 ? 16 : r);
+    }
+    if (R > 4096) R = 4096;
+  }
+  const long per_wg = (one_wave ? 4L : 1L) * R;
+  const long nwg = (npts + per_wg - 1) / per_wg;
+  const long g = (long)num_cu * 8;
+  *grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
+  *run_len = R;
+  *ws_bytes = (R > 1) ? (size_t)*grid * 4 * (size_t)wave_kr(k) * 64 * sizeof(double) : 0;
 }
 
 hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st) {
