@@ -575,129 +575,142 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
 #pragma unroll
       for (int t = 0; t < NTILE; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
       const int q = wlane >> 4, c16 = wlane & 15;
-      const int ioff = 4 * wvp;                               // with two waves each takes every other 4-obs chunk
 
-      // Software pipeline, three loads deep, so that no load is consumed in the iteration that issued it (the first
-      // version waited a full memory latency per 4-obs chunk on the obs_idx -> dep dependent pair):
-      //   stage A (chunk c+3): obs_idx, rdiag, rloc            stage B (chunk c+2): dep[iob], det departure
-      //   rows    (chunk c+1): the 4 x NBLK member segments    MFMA    (chunk c)
-      struct StA {
-        int iob;
-        double rdv, rl, d, dd;
-        bool ok;
-      };
-      struct StB {
-        long rb;
-        double sw, d, dd, rl;
-        bool ok;
-      };
-      auto stage_a = [&](int i0) -> StA {
-        StA a{0, 1.0, 0.0, 0.0, 0.0, false};
-        const int i = i0 + q;
-        a.ok = i < n;
-        if (a.ok) {
-          if (A.mode == 0) {
-            const long e = o0 + i;
-            a.iob = A.obs_idx[e];
-            a.rl = A.rloc_l[e];
-            a.rdv = A.rdiag_l[e];
-          } else {
-            const long e = pt * (long)A.nobs + i;
-            a.iob = i;
-            a.rl = A.rloc[e];
-            a.rdv = A.rdiag[e];
-            a.d = A.depv[e];
-            if (A.depd) a.dd = A.depd[e];
-          }
-        }
-        return a;
-      };
-      auto stage_b = [&](const StA& a) -> StB {
-        StB b{0, 0.0, 0.0, 0.0, 0.0, a.ok};
-        if (a.ok) {
-          // sqrt(w) with w = 1/rdiag (or rloc/rdiag): one rsqrt + Newton instead of an IEEE division and sqrt
-          b.sw = fast_rsqrt(a.rdv);
-          b.rl = a.rl;
-          if (A.mode == 0) {
-            b.rb = (long)a.iob * A.kld;
-            b.d = A.dep[a.iob];
-            if (A.det_run) b.dd = A.ensval[b.rb + k];
-          } else {
-            if (!A.rdiag_wloc) b.sw *= sqrt(a.rl);
-            b.rb = pt * (long)A.nobs * (long)k + a.iob;
-            b.d = a.d;
-            b.dd = a.dd;
-          }
-        }
-        return b;
-      };
-      auto load_rows = [&](const StB& b, double (&f)[NBLK]) {
+      // Two phases per batch of kSC observations, so that the per-observation scalars are computed ONCE (lane = obs,
+      // coalesced reads of the CSR slice, all gathers of a batch in flight together) instead of 16 times over in
+      // every 4-obs MFMA step -- the first version spent ~250 VALU instructions and a dozen s_waitcnt per 4 obs in
+      // its load pipeline, as much SIMD time as a Jacobi sweep per point:
+      //   stage: lane i -> obs i: row base, sqrt(w), sqrt(w) dep, sqrt(w) dep_det into LDS (4 doubles per obs)
+      //   MFMA : per 4-obs step 2 ds_read_b128 + NBLK row loads (three steps in flight) + NBLK multiplies
+      constexpr int kSC = 256;                                 // obs per batch (4 kSC doubles <= 1536 NW of the slice)
+      double* stg = slice;
+      const bool mode0 = A.mode == 0;
+      const double* ybase = mode0 ? A.ensval : A.hdxb;
+      bool rowok[NBLK];
+      long mo[NBLK];
 #pragma unroll
-        for (int I = 0; I < NBLK; ++I) {
-          const int m = 16 * I + c16;
-          double y = 0.0;
-          if (b.ok && m < k) y = (A.mode == 0) ? A.ensval[b.rb + m] : A.hdxb[b.rb + (long)m * A.nobs];
-          f[I] = y;
-        }
+      for (int I = 0; I < NBLK; ++I) {
+        const int m = 16 * I + c16;
+        rowok[I] = m < k;
+        const long mm = rowok[I] ? m : 0;
+        mo[I] = mode0 ? mm : mm * (long)A.nobs;
+      }
+      const bool is_d = c16 == (k & 15), is_dd = c16 == ((k + 1) & 15);   // lanes of the two augmented columns
+      const int blk_d = k >> 4, blk_dd = (k + 1) >> 4;
+      struct Step {
+        double f[NBLK];
+        double sw, dsw, ddsw;
       };
 
-      // one pipeline stage = kGS sub-chunks of 4 obs.  Measured on MI355X: v_mfma_f64_16x16x4 takes ~45 ns per
-      // instruction at 2 waves/SIMD (46.6 TFLOP/s chip-wide, no faster per flop than v_fma_f64 at 56.7), so the
-      // 10 MFMAs of a 4-obs chunk already cover the row-load latency; 16-obs stages only added padding work
-      // (C2-mini: 2.9 ms vs 1.9 ms for the non-eigensolve part).
-      constexpr int kGS = 1;
-      constexpr int kStage = 4 * kGS * NW;
-      StA a2[kGS];
-      StB b0[kGS], b1[kGS];
-      double f0[kGS][NBLK], f1[kGS][NBLK];
+      for (int s0 = 0; s0 < n; s0 += kSC) {
+        const int ns = min(kSC, n - s0);
+        const int nsp = (ns + 3) & ~3;
+        psync<NW>();                                           // the previous batch has been consumed
+        // ---- stage
+        constexpr int NPASS = kSC / NL;
+        int iob[NPASS];
+        double rdv[NPASS], rlv[NPASS], dv[NPASS], ddv[NPASS];
 #pragma unroll
-      for (int u = 0; u < kGS; ++u) a2[u] = stage_a(4 * u + ioff);
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int i = ps * NL + lane;
+          iob[ps] = 0;
+          rdv[ps] = 1.0;
+          rlv[ps] = 0.0;
+          dv[ps] = 0.0;
+          ddv[ps] = 0.0;
+          if (i < ns) {
+            if (mode0) {
+              const long e = o0 + s0 + i;
+              iob[ps] = A.obs_idx[e];
+              rlv[ps] = A.rloc_l[e];
+              rdv[ps] = A.rdiag_l[e];
+            } else {
+              const long e = pt * (long)A.nobs + s0 + i;
+              rlv[ps] = A.rloc[e];
+              rdv[ps] = A.rdiag[e];
+              dv[ps] = A.depv[e];
+              if (A.depd) ddv[ps] = A.depd[e];
+            }
+          }
+        }
+        if (mode0) {
 #pragma unroll
-      for (int u = 0; u < kGS; ++u) b0[u] = stage_b(a2[u]);
+          for (int ps = 0; ps < NPASS; ++ps) {
+            const int i = ps * NL + lane;
+            if (i < ns) {
+              dv[ps] = A.dep[iob[ps]];
+              if (A.det_run) ddv[ps] = A.ensval[(long)iob[ps] * A.kld + k];
+            }
+          }
+        }
 #pragma unroll
-      for (int u = 0; u < kGS; ++u) a2[u] = stage_a(kStage + 4 * u + ioff);
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int i = ps * NL + lane;
+          if (i < nsp) {
+            // sqrt(w) with w = 1/rdiag (or rloc/rdiag): one rsqrt + Newton instead of an IEEE division and sqrt
+            double sw = 0.0;
+            long rb = 0;
+            if (i < ns) {
+              sw = fast_rsqrt(rdv[ps]);
+              if (!mode0 && !A.rdiag_wloc) sw *= sqrt(rlv[ps]);
+              rb = mode0 ? (long)iob[ps] * A.kld : pt * (long)A.nobs * (long)k + (s0 + i);
+              p3 += rlv[ps];
+            }
+            *reinterpret_cast<double2*>(&stg[4 * i]) = double2{__longlong_as_double(rb), sw};
+            *reinterpret_cast<double2*>(&stg[4 * i + 2]) = double2{dv[ps] * sw, ddv[ps] * sw};
+          }
+        }
+        psync<NW>();
+        // ---- MFMA steps of 4 obs; with two waves each takes every other step
+        const int nch = nsp >> 2;
+        auto fetch = [&](const int c, Step& t) {
+          const bool ok = c < nch;
+          const int i = 4 * (ok ? c : 0) + q;
+          const double2 a2 = *reinterpret_cast<const double2*>(&stg[4 * i]);
+          const double2 b2 = *reinterpret_cast<const double2*>(&stg[4 * i + 2]);
+          const long rb = __double_as_longlong(a2.x);
+          t.sw = ok ? a2.y : 0.0;
+          t.dsw = ok ? b2.x : 0.0;
+          t.ddsw = ok ? b2.y : 0.0;
 #pragma unroll
-      for (int u = 0; u < kGS; ++u) b1[u] = stage_b(a2[u]);
-#pragma unroll
-      for (int u = 0; u < kGS; ++u) a2[u] = stage_a(2 * kStage + 4 * u + ioff);
-#pragma unroll
-      for (int u = 0; u < kGS; ++u) load_rows(b0[u], f0[u]);
-      for (int i0 = 0; i0 < n; i0 += kStage) {
-#pragma unroll
-        for (int u = 0; u < kGS; ++u) load_rows(b1[u], f1[u]);
-        StB b2[kGS];
-#pragma unroll
-        for (int u = 0; u < kGS; ++u) b2[u] = stage_b(a2[u]);
-#pragma unroll
-        for (int u = 0; u < kGS; ++u) a2[u] = stage_a(i0 + 3 * kStage + 4 * u + ioff);
-#pragma unroll
-        for (int u = 0; u < kGS; ++u) {
-          // augmented columns and scaling of the current sub-chunk
+          for (int I = 0; I < NBLK; ++I) t.f[I] = ybase[rb + mo[I]];
+        };
+        auto mma = [&](const Step& t) {
+          double y[NBLK];
 #pragma unroll
           for (int I = 0; I < NBLK; ++I) {
-            const int m = 16 * I + c16;
-            double y = f0[u][I];
-            if (m == k) y = b0[u].d;
-            if (m == k + 1) y = b0[u].dd;
-            f0[u][I] = y * b0[u].sw;
+            double v = t.f[I] * t.sw;
+            if (16 * (I + 1) > k) {                            // wave-uniform: block reaches past the members
+              v = rowok[I] ? v : 0.0;
+              if (I == blk_d && is_d) v = t.dsw;
+              if (I == blk_dd && is_dd) v = t.ddsw;
+            }
+            y[I] = v;
           }
-          if (c16 == 0) p3 += b0[u].rl;
-          int t = 0;
+          int tt = 0;
 #pragma unroll
           for (int I = 0; I < NBLK; ++I)
 #pragma unroll
             for (int J = I; J < NBLK; ++J) {
-              acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[u][I], f0[u][J], acc[t], 0, 0, 0);
-              ++t;
+              acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[I], y[J], acc[tt], 0, 0, 0);
+              ++tt;
             }
-        }
-        // rotate the pipeline
-#pragma unroll
-        for (int u = 0; u < kGS; ++u) {
-#pragma unroll
-          for (int I = 0; I < NBLK; ++I) f0[u][I] = f1[u][I];
-          b0[u] = b1[u];
-          b1[u] = b2[u];
+        };
+        Step t0, t1, t2;
+        fetch(wvp, t0);
+        fetch(wvp + NW, t1);
+        fetch(wvp + 2 * NW, t2);
+        for (int c = wvp; c < nch; c += 3 * NW) {
+          mma(t0);
+          fetch(c + 3 * NW, t0);
+          if (c + NW < nch) {
+            mma(t1);
+            fetch(c + 4 * NW, t1);
+          }
+          if (c + 2 * NW < nch) {
+            mma(t2);
+            fetch(c + 5 * NW, t2);
+          }
         }
       }
 
