@@ -353,6 +353,196 @@ __device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const i
   return sweep;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-split variant of the same iteration for one wave (k <= 62).  Same pair ordering, same fast scaled rotations,
+// same cached norms -- but a SLOT of two lanes (m, m + 32) owns the two columns at line positions (2m, 2m + 1),
+// lane m their even rows, lane m + 32 their odd rows:
+//   even steps pair the two columns of a slot: no column moves at all, KR/2 FMAs for the inner product (the two
+//     halves meet through v_permlane32_swap) and KR FMAs for the two half-columns;
+//   odd steps pair column 2m+1 with 2m+2 of the next slot: each lane fetches one half-column from either
+//     neighbour slot (wave_shr:1 / wave_shl:1 DPP moves, KR dword moves each way as before), but computes only ONE
+//     inner product half (the left slot of a pair passes its rotation on through four more DPP moves).
+// Per two steps: 3/2 KR FMAs + 2 KR moves less than the column-per-lane version (~390 instead of ~500
+// instructions at k = 50).  The lanes of unused slots are switched off for the whole iteration: DPP reads from a
+// disabled lane return 0 (bound_ctrl), which is exactly the "no partner" case at both ends of the line.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift0(double v) {     // wave_shl:1 (0x130) / wave_shr:1 (0x138), 0 if no source
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// v[l & 31] + v[32 + (l & 31)] in every lane (both lanes of a slot must be active)
+__device__ __forceinline__ double slot_sum(double v) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+template <int KR>
+__device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const int max_sweep, double* lds) {
+  static_assert(KR % 2 == 0, "row halves");
+  constexpr int H = KR / 2;
+  constexpr int RC = 24;                       // rows per conversion chunk: 24 * 64 doubles of LDS
+  const int lane = threadIdx.x & 63;
+  const int slot = lane & 31, par = lane >> 5;
+  const int ncol = (k + 1) & ~1;               // an odd k gets one zero column as an extra (inert) participant
+  const int S = ncol >> 1;                     // slots in use
+  double xa[H], xb[H];
+  // ---- column-per-lane -> row-split: lds[r][col], r in chunks
+#pragma unroll
+  for (int r0 = 0; r0 < KR; r0 += RC) {
+    wave_lds_sync();
+#pragma unroll
+    for (int r = r0; r < r0 + RC && r < KR; ++r) lds[(r - r0) * 64 + lane] = g[r];
+    wave_lds_sync();
+#pragma unroll
+    for (int rr = r0 / 2; rr < (r0 + RC) / 2 && rr < H; ++rr) {
+      const double2 v2 = *reinterpret_cast<const double2*>(&lds[(2 * rr + par - r0) * 64 + 2 * slot]);
+      xa[rr] = v2.x;
+      xb[rr] = v2.y;
+    }
+  }
+  int sweep = 0;
+  if (slot < S) {
+    const bool hasL = slot > 0, hasR = slot + 1 < S;
+    double alA = 0.0, alB = 0.0, isA = 1.0, isB = 1.0, scA = 1.0, scB = 1.0;
+    for (; sweep < max_sweep; ++sweep) {
+      // refresh: fold the scales back, recompute the squared norms
+      double a0 = 0.0, b0 = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < H; ++rr) {
+        xa[rr] *= isA;
+        xb[rr] *= isB;
+        a0 = fma(xa[rr], xa[rr], a0);
+        b0 = fma(xb[rr], xb[rr], b0);
+      }
+      alA = slot_sum(a0);
+      alB = slot_sum(b0);
+      isA = isB = scA = scB = 1.0;
+      bool notconv = false;
+      for (int t = 0; t < ncol; t += 2) {
+        // ---------------- even step: the slot's own two columns (A at the lower position)
+        {
+          double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+          for (int rr = 0; rr < H; ++rr) {
+            if (rr & 1) p1 = fma(xa[rr], xb[rr], p1);
+            else p0 = fma(xa[rr], xb[rr], p0);
+          }
+          const double ga = slot_sum(p0 + p1) * (isA * isB);
+          const double a = alA, b = alB;
+          const double g2 = ga * ga, ab = a * b;
+          notconv |= g2 > kStopTol2W * ab;
+          const bool rot = g2 > kRotTol2W * ab;
+          const double d = b - a;
+          const double x = fma(d, d, 4.0 * g2);
+          const double hh = x * fast_rsqrt1(x);
+          double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
+          tt = rot ? tt : 0.0;
+          const double w = fma(tt, tt, 1.0);
+          const double c = fast_rsqrt(w);
+          const double tg = tt * ga, wc = w * c;
+          // rotate and swap: position 2m takes c (g_B + t g_A), position 2m+1 takes c (g_A - t g_B)
+          const double cA = tt * (isA * scB), cB = -tt * (isB * scA);
+          const double nisA = isB * c, nscA = scB * wc, nisB = isA * c, nscB = scA * wc;
+          alA = b + tg;
+          alB = a - tg;
+          isA = nisA;
+          scA = nscA;
+          isB = nisB;
+          scB = nscB;
+          if (__any(rot)) {
+#pragma unroll
+            for (int rr = 0; rr < H; ++rr) {
+              const double na = fma(cA, xa[rr], xb[rr]);
+              xb[rr] = fma(cB, xb[rr], xa[rr]);
+              xa[rr] = na;
+            }
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < H; ++rr) {
+              const double na = xb[rr];
+              xb[rr] = xa[rr];
+              xa[rr] = na;
+            }
+          }
+        }
+        // ---------------- odd step: own B (lower position) with the right slot's A; own A with the left slot's B
+        {
+          double ar[H], bl[H];
+          double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+          for (int rr = 0; rr < H; ++rr) {
+            ar[rr] = dpp_shift0<0x130>(xa[rr]);
+            bl[rr] = dpp_shift0<0x138>(xb[rr]);
+            if (rr & 1) p1 = fma(xb[rr], ar[rr], p1);
+            else p0 = fma(xb[rr], ar[rr], p0);
+          }
+          const double alAr = dpp_shift0<0x130>(alA), isAr = dpp_shift0<0x130>(isA), scAr = dpp_shift0<0x130>(scA);
+          const double ga = slot_sum(p0 + p1) * (isB * isAr);
+          const double a = alB, b = alAr;
+          const double g2 = ga * ga, ab = a * b;
+          notconv |= hasR && g2 > kStopTol2W * ab;
+          const bool rot = hasR && g2 > kRotTol2W * ab;
+          const double d = b - a;
+          const double x = fma(d, d, 4.0 * g2);
+          const double hh = x * fast_rsqrt1(x);
+          double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
+          tt = rot ? tt : 0.0;
+          const double w = fma(tt, tt, 1.0);
+          const double c = fast_rsqrt(w);
+          const double tg = tt * ga, wc = w * c;
+          // what the right slot needs to rotate its A against this slot's (old) B
+          const double q1 = dpp_shift0<0x138>(-tt * scB), q2 = dpp_shift0<0x138>(isB * c),
+                       q3 = dpp_shift0<0x138>(scB * wc), q4 = dpp_shift0<0x138>(a - tg);
+          const double coefR = hasR ? tt * (isB * scAr) : 1.0;   // position 2m+1 takes c (g_Ar + t g_B)
+          const double coefL = hasL ? q1 * isA : 1.0;            // position 2m takes c (g_Bl - t g_A)
+          if (hasR) {
+            alB = b + tg;
+            isB = isAr * c;
+            scB = scAr * wc;
+          }
+          if (hasL) {
+            alA = q4;
+            isA = q2;
+            scA = q3;
+          }
+#pragma unroll
+          for (int rr = 0; rr < H; ++rr) {
+            xb[rr] = fma(coefR, xb[rr], ar[rr]);
+            xa[rr] = fma(coefL, xa[rr], bl[rr]);
+          }
+        }
+      }
+      if (!__any(notconv)) {
+        ++sweep;
+        break;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < H; ++rr) {
+      xa[rr] *= isA;
+      xb[rr] *= isB;
+    }
+  }
+  sweep = __builtin_amdgcn_readfirstlane(sweep);
+  // ---- row-split -> column-per-lane
+#pragma unroll
+  for (int r0 = 0; r0 < KR; r0 += RC) {
+    wave_lds_sync();
+#pragma unroll
+    for (int rr = r0 / 2; rr < (r0 + RC) / 2 && rr < H; ++rr)
+      *reinterpret_cast<double2*>(&lds[(2 * rr + par - r0) * 64 + 2 * slot]) = double2{xa[rr], xb[rr]};
+    wave_lds_sync();
+#pragma unroll
+    for (int r = r0; r < r0 + RC && r < KR; ++r) g[r] = lds[(r - r0) * 64 + lane];
+  }
+  wave_lds_sync();
+  return sweep;
+}
+
 // Out[b] (lane m: row m of V C) += sum over the wave's columns j of V[m][j] * C[j][b], b < NB.
 // V[:, j] is lane j's register column vcol[], C[j][:] is lane j's crow[].  Done in chunks of
 // kChunk columns through LDS:  vbuf[KR][kVld], cbuf[kChunk][NBP].
@@ -782,7 +972,8 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       if constexpr (WARM) {
         if (have_u && !(A.warm_dbg & 1)) warm_start_product<KR, NW>(g, uws, k);
       }
-      sweeps = jacobi_regs<KR, NW>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
+      if constexpr (NW == 1) sweeps = jacobi_split<KR>(g, k, A.max_sweep, slice);
+      else sweeps = jacobi_regs<KR, NW>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
 
       double ss = 0.0;
 #pragma unroll

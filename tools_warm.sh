@@ -1,8 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-for MS in 0 60; do
 for R in 1 16; do
-  echo "== C2 MAX_SWEEP=$MS RUN_LEN=$R"
-  LETKF_AMD_MAX_SWEEP=$MS LETKF_AMD_RUN_LEN=$R timeout -k 10 400 python bench.py --workload C2 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['jacobi_sweeps_mean'])"
-done
+  echo "== C2 RUN_LEN=$R"
+  LETKF_AMD_RUN_LEN=$R timeout -k 10 400 python bench.py --workload C2 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['jacobi_sweeps_mean'])"
 done
