@@ -408,7 +408,12 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
   if (slot < S) {
     const bool hasL = slot > 0, hasR = slot + 1 < S;
     double alA = 0.0, alB = 0.0, isA = 1.0, isB = 1.0, scA = 1.0, scB = 1.0;
-    for (; sweep < max_sweep; ++sweep) {
+    // `quiet` counts consecutive step pairs in which no visited column pair exceeded the tolerance; S of them in a
+    // row are one full cycle of the ordering (every column pair seen once) whatever step it started at, so the
+    // iteration stops S step pairs after the last significant rotation, not at the next sweep boundary.
+    int quiet = 0, pairs = 0;
+    bool done = false;
+    for (; sweep < max_sweep && !done; ++sweep) {
       // refresh: fold the scales back, recompute the squared norms
       double a0 = 0.0, b0 = 0.0;
 #pragma unroll
@@ -421,8 +426,8 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
       alA = slot_sum(a0);
       alB = slot_sum(b0);
       isA = isB = scA = scB = 1.0;
-      bool notconv = false;
-      for (int t = 0; t < ncol; t += 2) {
+      for (int t = 0; t < ncol && !done; t += 2) {
+        bool notconv = false;
         // ---------------- even step: the slot's own two columns (A at the lower position)
         {
           double p0 = 0.0, p1 = 0.0;
@@ -515,12 +520,12 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
             xa[rr] = fma(coefL, xa[rr], bl[rr]);
           }
         }
-      }
-      if (!__any(notconv)) {
-        ++sweep;
-        break;
+        ++pairs;
+        quiet = __any(notconv) ? 0 : quiet + 1;
+        done = quiet >= S;
       }
     }
+    sweep = (pairs + S - 1) / S;
 #pragma unroll
     for (int rr = 0; rr < H; ++rr) {
       xa[rr] *= isA;
@@ -600,22 +605,34 @@ __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const dou
 // so errors do not accumulate along a run.
 //
 // Lane j needs (A Q)[:, j] = sum_i A[:, i] Q[i][j]: its own Q column comes back from the wave's global workspace
-// slot a chunk at a time (it cannot stay in registers: 256 VGPRs hold g, h and nothing else); A[r][i] is register
-// g[r] of lane i, broadcast through v_readlane_b32 x2 into an SGPR pair that the FMA takes as its scalar operand.
-// Measured (tools/ubench_readlane.hip): 5.6 ns per readlane-pair + FMA against 2.35 ns for a bare v_fma_f64, i.e.
-// the whole product costs half a sweep; the first version broadcast A from LDS (ds_read_b128) and ran into the
-// LDS return bandwidth that the odd Jacobi steps of the other waves already load to ~70 % (1.6 sweeps' worth).
+// slot a chunk at a time (it cannot stay in registers: 256 VGPRs hold g, h and nothing else); the columns of A are
+// written to LDS kWC at a time and read back as wave-uniform (broadcast) ds_read_b128.  2 k^2 FMAs + k^2/2 LDS reads
+// per lane.  History: this LDS version was first measured at 1.6 sweeps' worth of time because the column-per-lane
+// Jacobi's odd steps kept the LDS return path ~70 % busy; a v_readlane_b32 x2 + SGPR-operand FMA version
+// (tools/ubench_readlane.hip: 5.6 ns per triple against 2.35 ns per bare v_fma_f64) cost one sweep; with the
+// row-split Jacobi (no LDS in its steps) the LDS broadcast is the cheapest again.
 // ---------------------------------------------------------------------------------------------
-constexpr int kWC = 8;   // Q rows per chunk
-__device__ __forceinline__ double lane_bcast(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
+constexpr int kWC = 4;   // columns of A per LDS chunk (small: the unrolled chunk body is ~100 instructions per column)
+// pins out[R0 .. R0+7] (those below KR): see pin_acc
+template <int KR, int R0>
+__device__ __forceinline__ void pin_rows8(double (&o)[KR]) {
+  if constexpr (R0 + 8 <= KR) {
+    asm volatile(""
+                 : "+v"(o[R0]), "+v"(o[R0 + 1]), "+v"(o[R0 + 2]), "+v"(o[R0 + 3]), "+v"(o[R0 + 4]), "+v"(o[R0 + 5]),
+                   "+v"(o[R0 + 6]), "+v"(o[R0 + 7])::"memory");
+  } else if constexpr (R0 < KR) {
+#pragma unroll
+    for (int r = R0; r < KR; r += 2) asm volatile("" : "+v"(o[r]), "+v"(o[r + 1])::"memory");
+  }
 }
 template <int KR, int NW>
-__device__ __forceinline__ void warm_start_product(double (&g)[KR], const double* __restrict__ uws, const int k) {
-  static_assert(NW == 1, "readlane broadcast stays inside one wavefront");
+__device__ __forceinline__ void warm_start_product(double (&g)[KR], const double* __restrict__ uws, const int k,
+                                                   double* cb) {
+  static_assert(NW == 1, "one wavefront per point");
   constexpr int NL = 64 * NW;
+  constexpr int NG = (KR + 7) / 8;
+  static_assert(NG <= 8, "pin_rows8 dispatch below");
+  const int lane = threadIdx.x & (NL - 1);
   const int ncol = (k + 1) & ~1;
   double out[KR];
 #pragma unroll
@@ -628,15 +645,51 @@ __device__ __forceinline__ void warm_start_product(double (&g)[KR], const double
     double u[kWC];
 #pragma unroll
     for (int q = 0; q < kWC; ++q) u[q] = un[q];
+    psync<NW>();
+    if (lane >= i0 && lane < i0 + kWC) {
+      double* mine = cb + (lane - i0) * KR;
+#pragma unroll
+      for (int r = 0; r < KR; r += 2) *reinterpret_cast<double2*>(&mine[r]) = double2{g[r], g[r + 1]};
+    }
+    psync<NW>();
 #pragma unroll
     for (int q = 0; q < kWC; ++q) un[q] = (i0 + kWC + q < ncol) ? uws[(size_t)(i0 + kWC + q) * NL] : 0.0;
+    // 8-row groups, the loads of group g+1 issued before the FMAs of group g
+    double2 cur[4], nxt[4];
+    auto ld = [&](const int q, const int gi, double2 (&d)[4]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (8 * gi + 2 * e < KR) d[e] = *reinterpret_cast<const double2*>(&cb[q * KR + 8 * gi + 2 * e]);   // broadcast
+    };
+    ld(0, 0, cur);
 #pragma unroll
     for (int q = 0; q < kWC; ++q) {
-      const int i = i0 + q;            // < 64: lanes >= ncol hold zero columns and meet u = 0
 #pragma unroll
-      for (int r = 0; r < KR; ++r) out[r] = fma(lane_bcast(g[r], i), u[q], out[r]);
+      for (int gi = 0; gi < NG; ++gi) {
+        const int nq = (gi + 1 < NG) ? q : q + 1, ng = (gi + 1 < NG) ? gi + 1 : 0;
+        if (nq < kWC) ld(nq, ng, nxt);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 8 * gi + 2 * e;
+          if (r < KR) {
+            out[r] = fma(cur[e].x, u[q], out[r]);
+            out[r + 1] = fma(cur[e].y, u[q], out[r + 1]);
+          }
+        }
+        if (gi == 0) pin_rows8<KR, 0>(out);
+        if (gi == 1) pin_rows8<KR, 8>(out);
+        if (gi == 2) pin_rows8<KR, 16>(out);
+        if (gi == 3) pin_rows8<KR, 24>(out);
+        if (gi == 4) pin_rows8<KR, 32>(out);
+        if (gi == 5) pin_rows8<KR, 40>(out);
+        if (gi == 6) pin_rows8<KR, 48>(out);
+        if (gi == 7) pin_rows8<KR, 56>(out);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
+      }
     }
   }
+  psync<NW>();
 #pragma unroll
   for (int r = 0; r < KR; ++r) g[r] = out[r];
 }
@@ -970,7 +1023,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
 
       // ------------------------------------------------------------ eigen-decomposition in registers
       if constexpr (WARM) {
-        if (have_u && !(A.warm_dbg & 1)) warm_start_product<KR, NW>(g, uws, k);
+        if (have_u && !(A.warm_dbg & 1)) warm_start_product<KR, NW>(g, uws, k, slice);
       }
       if constexpr (NW == 1) sweeps = jacobi_split<KR>(g, k, A.max_sweep, slice);
       else sweeps = jacobi_regs<KR, NW>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
