@@ -389,7 +389,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
   const int slot = lane & 31, par = lane >> 5;
   const int ncol = (k + 1) & ~1;               // an odd k gets one zero column as an extra (inert) participant
   const int S = ncol >> 1;                     // slots in use
-  double xa[H], xb[H];
+  double xa[H], xb[H], xf[H];
   // ---- column-per-lane -> row-split: lds[r][col], r in chunks
 #pragma unroll
   for (int r0 = 0; r0 < KR; r0 += RC) {
@@ -458,32 +458,25 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           scA = nscA;
           isB = nisB;
           scB = nscB;
-          if (__any(rot)) {
+          // the new A goes to the spare array xf, the new B is accumulated in place in xa[] (every FMA adds into the
+          // register its result stays in: no copies)
 #pragma unroll
-            for (int rr = 0; rr < H; ++rr) {
-              const double na = fma(cA, xa[rr], xb[rr]);
-              xb[rr] = fma(cB, xb[rr], xa[rr]);
-              xa[rr] = na;
-            }
-          } else {
-#pragma unroll
-            for (int rr = 0; rr < H; ++rr) {
-              const double na = xb[rr];
-              xb[rr] = xa[rr];
-              xa[rr] = na;
-            }
+          for (int rr = 0; rr < H; ++rr) {
+            // three-address form with an early-clobber destination: left to itself the compiler accumulates into
+            // xb's registers (v_fmac) and then has to copy the column out of the way of the DPP fetch below.  (No
+            // "nothing to rotate" shortcut here: its copy path made the allocator shuffle 50 registers per step pair.)
+            asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(xf[rr]) : "v"(cA), "v"(xa[rr]), "v"(xb[rr]));
+            xa[rr] = fma(cB, xb[rr], xa[rr]);
           }
         }
-        // ---------------- odd step: own B (lower position) with the right slot's A; own A with the left slot's B
+        // ---------------- odd step: own B (now in xa[]) with the right slot's A; own A (in xf[]) with the left slot's B
         {
-          double ar[H], bl[H];
           double p0 = 0.0, p1 = 0.0;
 #pragma unroll
           for (int rr = 0; rr < H; ++rr) {
-            ar[rr] = dpp_shift0<0x130>(xa[rr]);
-            bl[rr] = dpp_shift0<0x138>(xb[rr]);
-            if (rr & 1) p1 = fma(xb[rr], ar[rr], p1);
-            else p0 = fma(xb[rr], ar[rr], p0);
+            xb[rr] = dpp_shift0<0x130>(xf[rr]);                 // A of the right slot
+            if (rr & 1) p1 = fma(xa[rr], xb[rr], p1);
+            else p0 = fma(xa[rr], xb[rr], p0);
           }
           const double alAr = dpp_shift0<0x130>(alA), isAr = dpp_shift0<0x130>(isA), scAr = dpp_shift0<0x130>(scA);
           const double ga = slot_sum(p0 + p1) * (isB * isAr);
@@ -514,10 +507,14 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
             isA = q2;
             scA = q3;
           }
+          // new B into xb[] (on top of the fetched column); then the old B of the LEFT slot is pulled into xa[] --
+          // every lane reads its neighbour's xa[rr] and overwrites its own in the same instruction -- and the new A
+          // accumulated on top of it: A is back in xa[], B in xb[], xf[] is spare again
 #pragma unroll
           for (int rr = 0; rr < H; ++rr) {
-            xb[rr] = fma(coefR, xb[rr], ar[rr]);
-            xa[rr] = fma(coefL, xa[rr], bl[rr]);
+            xb[rr] = fma(coefR, xa[rr], xb[rr]);
+            xa[rr] = dpp_shift0<0x138>(xa[rr]);
+            xa[rr] = fma(coefL, xf[rr], xa[rr]);
           }
         }
         ++pairs;
