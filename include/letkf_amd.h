@@ -273,6 +273,67 @@ int letkf_member_points_dev(letkf_ctx *ctx, int32_t dir, int32_t nlev, int32_t n
 int letkf_ens_spread_dev(letkf_ctx *ctx, int32_t k, int32_t nv, int64_t npts, const double *x, int64_t sp,
                          int64_t sm, int64_t sv, double *sprd);
 
+/*---------------------------------------------------------------------------
+ * (5) set_letkf_obs on the device (scale/letkf/letkf_obs.f90): the producer of the
+ *     observation table the search (3) and the loop body (2) read.  Per rank (= GPU, = SCALE subdomain):
+ *       departure + QC          letkf_obs.f90:361-561 (build without -DH08)
+ *       bucket sort on the mesh :762-822 (+ ij_obsgrd :1186-1203)
+ *       [all-gather of the sorted buffers and cell counts over the ranks: RCCL, outside this library]
+ *       extended-subdomain plan :922-976 and copy into obsda_sort :1036-1100
+ *     Integer results (qc, counts, keys, ac_ext, row map) are identical to the reference's; the departures use the
+ *     same sequential member sum and are bit-identical too.
+ *-------------------------------------------------------------------------*/
+typedef struct {
+  int32_t member;                 /* MEMBER */
+  int32_t det_run;                /* DET_RUN: column `member` of ensval holds H(x_det), becomes y - H(x_det) (:492-494) */
+  int32_t use_radar_ref, use_radar_vr;                           /* USE_RADAR_REF, USE_RADAR_VR */
+  int32_t min_radar_ref_member, min_radar_ref_member_obsref;     /* MIN_RADAR_REF_MEMBER(_OBSREF) */
+  double radar_ref_thres_dbz;                                    /* RADAR_REF_THRES_DBZ */
+  double gross_error, gross_error_rain, gross_error_radar_ref, gross_error_radar_vr, gross_error_radar_prh,
+      gross_error_tcx, gross_error_tcy, gross_error_tcp;        /* GROSS_ERROR* */
+} letkf_qc_params;
+
+/* elm[n] = obs(set)%elm(idx), dat / err likewise (gathered per local H(x) row by the caller); ensval[n*kld + m]
+ * INOUT: H(x_m) -> H(x_m) - mean; val[n] OUT: y - mean; qc[n] INOUT (rows with qc > 0 are skipped). */
+int letkf_obs_departure_dev(letkf_ctx *ctx, const letkf_qc_params *p, int64_t nobs, const int32_t *elm,
+                            const double *dat, const double *err, double *ensval, int64_t kld, double *val,
+                            int32_t *qc);
+
+typedef struct {
+  int32_t nctype;
+  int32_t nlon, nlat;             /* subdomain size (without halo) */
+  int32_t ihalo, jhalo;           /* IHALO, JHALO: ri, rj count the halo */
+  int32_t rank_i, rank_j;         /* PRC_2Drank of this rank */
+  int32_t reserved0;
+  const int32_t *ngrd_i, *ngrd_j; /* HOST [nctype]: obsgrd(ic)%ngrd_i / ngrd_j (letkf_obs.f90:668-669) */
+} letkf_mesh;
+
+/* ctype[n]: 0-based combined type of row n (ctype_elmtyp(uid_obs(elm), typ) - 1); ri, rj: global grid coordinates.
+ * n_cell (dev, OUT): per ctype [ngrd_j][ngrd_i] counts of accepted rows, ctypes concatenated (obsgrd%n(:,:,myrank));
+ * key (dev, OUT, [nobs]): key[0 .. *nsorted) = 0-based row numbers in (ctype, j, i, row) order (obsda%key).
+ * Synchronises the stream (the count goes back to the host). */
+int letkf_obs_mesh_sort_dev(letkf_ctx *ctx, const letkf_mesh *mesh, int64_t nobs, const int32_t *ctype,
+                            const double *ri, const double *rj, const int32_t *qc, int32_t *n_cell, int32_t *key,
+                            int64_t *nsorted);
+
+typedef struct {
+  int32_t nctype, nprocs, prc_num_x, myrank;      /* rank r sits at (mod(r, prc_num_x), r / prc_num_x) */
+  const int32_t *ngrd_i, *ngrd_j, *ngrdsch_i, *ngrdsch_j;   /* HOST [nctype] */
+} letkf_halo_layout;
+
+/* n_all (dev): every rank's n_cell, rank-major (the MPI_ALLREDUCE of obsgrd%n, :826-831).  ac_ext (dev, OUT): per
+ * ctype [ngrdext_j][ngrdext_i + 1], concatenated and cumulative over ctypes -- exactly letkf_search_tables.ac_ext.
+ * src_row (dev, OUT, capacity cap): obsda_sort row r is row src_row[r] of the rank-major concatenation of all ranks'
+ * sorted buffers (the ALLGATHERV receive buffer obsbufr, :1013-1025).  *nobstotal: rows of obsda_sort.
+ * Synchronises the stream. */
+int letkf_obs_halo_plan_dev(letkf_ctx *ctx, const letkf_halo_layout *layout, const int32_t *n_all, int32_t *ac_ext,
+                            int32_t *src_row, int64_t cap, int64_t *nobstotal);
+
+/* dst[r*ld_dst + c] = src[src_row[r]*ld_src + c], c < ncols (ensval rows, val, metadata); and the int32 fields. */
+int letkf_obs_gather_rows_dev(letkf_ctx *ctx, int64_t nrows, const int32_t *src_row, int32_t ncols, const double *src,
+                              int64_t ld_src, double *dst, int64_t ld_dst);
+int letkf_obs_gather_i32_dev(letkf_ctx *ctx, int64_t nrows, const int32_t *src_row, const int32_t *src, int32_t *dst);
+
 /* Kernel timing helper for bench.py: average duration (ms) of the last
  * letkf_das_points_dev / letkf_core_batch_dev launches measured with HIP events on the
  * context's stream since the previous reset; *nlaunch receives the count. */

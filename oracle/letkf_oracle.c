@@ -849,3 +849,187 @@ void orc_ens_spread(int k, int nv, int64_t npts, const double *x, int64_t sp, in
       sprd[pt + npts * v] = sqrt(s / (double)(k - 1));
     }
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Row f2: set_letkf_obs
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+  ORC_ID_RAIN = 19999, ORC_ID_RADAR_REF = 4001, ORC_ID_RADAR_REF_ZERO = 4004, ORC_ID_RADAR_VR = 4002,
+  ORC_ID_RADAR_PRH = 4003, ORC_ID_TCLON = 99991, ORC_ID_TCLAT = 99992, ORC_ID_TCMIP = 99993,   /* common_obs_scale.f90:48-72 */
+  ORC_QC_GOOD = 0, ORC_QC_GROSS = 5, ORC_QC_REF_MEM = 12, ORC_QC_OBS_BAD = 50, ORC_QC_OTYPE = 90   /* :139-151 */
+};
+static const double ORC_UNDEF = -9.99e33;   /* common/common.f90:38 */
+
+void orc_obs_departure(const orc_qc_params *p, int64_t nobs, const int32_t *elm, const double *dat, const double *err,
+                       double *ensval, int64_t kld, double *val, int32_t *qc) {
+  const int K = p->member;
+  for (int64_t n = 0; n < nobs; ++n) {
+    if (qc[n] > 0) continue;                                               /* letkf_obs.f90:362 */
+    double *e = ensval + n * kld;
+    const int el = elm[n];
+    if (el == ORC_ID_RADAR_REF || el == ORC_ID_RADAR_REF_ZERO) {           /* :372-411 */
+      if (!p->use_radar_ref) { qc[n] = ORC_QC_OTYPE; continue; }
+      if (dat[n] == ORC_UNDEF) { qc[n] = ORC_QC_OBS_BAD; continue; }
+      int mem_ref = 0;
+      for (int i = 0; i < K; ++i)
+        if (e[i] > p->radar_ref_thres_dbz + 1.0e-6) ++mem_ref;
+      if (dat[n] > p->radar_ref_thres_dbz + 1.0e-6) {
+        if (mem_ref < p->min_radar_ref_member_obsref) { qc[n] = ORC_QC_REF_MEM; continue; }
+      } else {
+        if (mem_ref < p->min_radar_ref_member) { qc[n] = ORC_QC_REF_MEM; continue; }
+      }
+    }
+    if (el == ORC_ID_RADAR_VR && !p->use_radar_vr) { qc[n] = ORC_QC_OTYPE; continue; }   /* :413-418 */
+    double v = e[0];                                                        /* :475-479 */
+    for (int i = 1; i < K; ++i) v = v + e[i];
+    v = v / (double)K;
+    for (int i = 0; i < K; ++i) e[i] = e[i] - v;                            /* :488-490 */
+    v = dat[n] - v;                                                         /* :491 */
+    val[n] = v;
+    if (p->det_run) e[K] = dat[n] - e[K];                                   /* :492-494 */
+    double ge;                                                              /* :504-561 */
+    switch (el) {
+      case ORC_ID_RAIN: ge = p->gross_error_rain; break;
+      case ORC_ID_RADAR_REF:
+      case ORC_ID_RADAR_REF_ZERO: ge = p->gross_error_radar_ref; break;
+      case ORC_ID_RADAR_VR: ge = p->gross_error_radar_vr; break;
+      case ORC_ID_RADAR_PRH: ge = p->gross_error_radar_prh; break;
+      case ORC_ID_TCLON: ge = p->gross_error_tcx; break;
+      case ORC_ID_TCLAT: ge = p->gross_error_tcy; break;
+      case ORC_ID_TCMIP: ge = p->gross_error_tcp; break;
+      default: ge = p->gross_error;
+    }
+    if (fabs(v) > ge * err[n]) qc[n] = ORC_QC_GROSS;
+  }
+}
+
+/* ij_obsgrd, letkf_obs.f90:1186-1203 (rij_g2l: common_scale.f90:1683-1697).  The reference scales rj by ngrd_i,
+ * not ngrd_j (:1200); restated as written.  Returns 1-based mesh indices after the clamps of :768-771. */
+static void orc_ij_obsgrd(const orc_mesh *m, int ic, double ri, double rj, int *ogi, int *ogj) {
+  const double ril = ri - (double)(m->rank_i * m->nlon);
+  const double rjl = rj - (double)(m->rank_j * m->nlat);
+  int i = (int)ceil((ril - (double)m->ihalo - 0.5) * (double)m->ngrd_i[ic] / (double)m->nlon);
+  int j = (int)ceil((rjl - (double)m->jhalo - 0.5) * (double)m->ngrd_i[ic] / (double)m->nlat);
+  if (i < 1) i = 1;
+  if (i > m->ngrd_i[ic]) i = m->ngrd_i[ic];
+  if (j < 1) j = 1;
+  if (j > m->ngrd_j[ic]) j = m->ngrd_j[ic];
+  *ogi = i;
+  *ogj = j;
+}
+
+int64_t orc_obs_mesh_sort(const orc_mesh *m, int64_t nobs, const int32_t *ctype, const double *ri, const double *rj,
+                          const int32_t *qc, int32_t *n_cell, int32_t *key) {
+  int64_t ncell = 0;
+  int64_t *coff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m->nctype + 1));
+  for (int ic = 0; ic < m->nctype; ++ic) {
+    coff[ic] = ncell;
+    ncell += (int64_t)m->ngrd_i[ic] * m->ngrd_j[ic];
+  }
+  coff[m->nctype] = ncell;
+  for (int64_t c = 0; c < ncell; ++c) n_cell[c] = 0;
+  /* first scan (:762-781) */
+  for (int64_t n = 0; n < nobs; ++n) {
+    if (qc[n] != ORC_QC_GOOD) continue;
+    int i, j;
+    const int ic = ctype[n];
+    orc_ij_obsgrd(m, ic, ri[n], rj[n], &i, &j);
+    n_cell[coff[ic] + (int64_t)(j - 1) * m->ngrd_i[ic] + (i - 1)] += 1;
+  }
+  /* accumulated numbers (:786-800): cells in (ctype, j, i) order */
+  int64_t *next = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ncell > 0 ? ncell : 1));
+  int64_t acc = 0;
+  for (int64_t c = 0; c < ncell; ++c) {
+    next[c] = acc;
+    acc += n_cell[c];
+  }
+  /* second scan (:806-822) */
+  for (int64_t n = 0; n < nobs; ++n) {
+    if (qc[n] != ORC_QC_GOOD) continue;
+    int i, j;
+    const int ic = ctype[n];
+    orc_ij_obsgrd(m, ic, ri[n], rj[n], &i, &j);
+    const int64_t c = coff[ic] + (int64_t)(j - 1) * m->ngrd_i[ic] + (i - 1);
+    key[next[c]++] = (int32_t)n;
+  }
+  free(next);
+  free(coff);
+  return acc;
+}
+
+int64_t orc_obs_halo_plan(const orc_halo_layout *l, const int32_t *n_all, int32_t *ac_ext, int32_t *src_row,
+                          int64_t cap) {
+  const int nc = l->nctype, np = l->nprocs;
+  int64_t ncell = 0, nacx = 0;
+  int64_t *coff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nc + 1));
+  int64_t *xoff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nc + 1));
+  for (int ic = 0; ic < nc; ++ic) {
+    coff[ic] = ncell;
+    xoff[ic] = nacx;
+    ncell += (int64_t)l->ngrd_i[ic] * l->ngrd_j[ic];
+    nacx += (int64_t)(l->ngrd_i[ic] + 2 * l->ngrdsch_i[ic] + 1) * (l->ngrd_j[ic] + 2 * l->ngrdsch_j[ic]);
+  }
+  /* every rank's accumulated counts ac(i,j,ip) (exclusive start of each cell), and the displacements dspr (:979-984) */
+  int64_t *start = (int64_t *)malloc(sizeof(int64_t) * (size_t)(np * (ncell > 0 ? ncell : 1)));
+  int64_t *dspr = (int64_t *)malloc(sizeof(int64_t) * (size_t)(np + 1));
+  dspr[0] = 0;
+  for (int ip = 0; ip < np; ++ip) {
+    int64_t acc = 0;
+    for (int64_t c = 0; c < ncell; ++c) {
+      start[ip * ncell + c] = acc;
+      acc += n_all[ip * ncell + c];
+    }
+    dspr[ip + 1] = dspr[ip] + acc;
+  }
+  const int myp_i = l->myrank % l->prc_num_x, myp_j = l->myrank / l->prc_num_x;
+  int64_t acx = 0;       /* running ac_ext over ctypes (:946-956) */
+  int64_t rc = 0;
+  for (int ic = 0; ic < nc && rc >= 0; ++ic) {
+    const int gi = l->ngrd_i[ic], gj = l->ngrd_j[ic], si = l->ngrdsch_i[ic], sj = l->ngrdsch_j[ic];
+    const int ei = gi + 2 * si, ej = gj + 2 * sj;
+    int32_t *nx = (int32_t *)calloc((size_t)ei * ej, sizeof(int32_t));
+    int64_t *sx = (int64_t *)malloc(sizeof(int64_t) * (size_t)ei * ej);   /* source row of the first obs of the cell */
+    const int imin1 = myp_i * gi + 1 - si, imax1 = (myp_i + 1) * gi + si;  /* :925-928 */
+    const int jmin1 = myp_j * gj + 1 - sj, jmax1 = (myp_j + 1) * gj + sj;
+    for (int ip = 0; ip < np; ++ip) {
+      const int ip_i = ip % l->prc_num_x, ip_j = ip / l->prc_num_x;
+      int imin2 = imin1 - ip_i * gi, imax2 = imax1 - ip_i * gi;            /* :932-936 */
+      int jmin2 = jmin1 - ip_j * gj, jmax2 = jmax1 - ip_j * gj;
+      if (imin2 < 1) imin2 = 1;
+      if (imax2 > gi) imax2 = gi;
+      if (jmin2 < 1) jmin2 = 1;
+      if (jmax2 > gj) jmax2 = gj;
+      if (imin2 > imax2 || jmin2 > jmax2) continue;
+      const int ishift = (ip_i - myp_i) * gi + si, jshift = (ip_j - myp_j) * gj + sj;   /* :938-940 */
+      for (int j = jmin2; j <= jmax2; ++j)
+        for (int i = imin2; i <= imax2; ++i) {
+          const int64_t c = coff[ic] + (int64_t)(j - 1) * gi + (i - 1);
+          const int64_t x = (int64_t)(j + jshift - 1) * ei + (i + ishift - 1);
+          nx[x] = n_all[ip * ncell + c];
+          sx[x] = dspr[ip] + start[ip * ncell + c];
+        }
+    }
+    int32_t *ax = ac_ext + xoff[ic];                                       /* [ej][ei + 1] */
+    for (int j = 0; j < ej; ++j) {
+      ax[(int64_t)j * (ei + 1)] = (int32_t)acx;
+      for (int i = 0; i < ei; ++i) {
+        const int64_t x = (int64_t)j * ei + i;
+        if (nx[x] > 0) {
+          if (acx + nx[x] > cap) { rc = -1; break; }
+          for (int t = 0; t < nx[x]; ++t) src_row[acx + t] = (int32_t)(sx[x] + t);   /* :1060-1080, cell by cell */
+        }
+        acx += nx[x];
+        ax[(int64_t)j * (ei + 1) + i + 1] = (int32_t)acx;
+      }
+      if (rc < 0) break;
+    }
+    free(nx);
+    free(sx);
+  }
+  free(start);
+  free(dspr);
+  free(coff);
+  free(xoff);
+  return rc < 0 ? -1 : acx;
+}

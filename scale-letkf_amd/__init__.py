@@ -69,6 +69,30 @@ class SearchTables(C.Structure):
                 ("ob_err", C.c_void_p)]
 
 
+class QcParams(C.Structure):
+    """letkf_qc_params (include/letkf_amd.h section 5); defaults = the reference namelist defaults
+    (scale/common/common_nml.f90)"""
+    _fields_ = [("member", C.c_int32), ("det_run", C.c_int32), ("use_radar_ref", C.c_int32),
+                ("use_radar_vr", C.c_int32), ("min_radar_ref_member", C.c_int32),
+                ("min_radar_ref_member_obsref", C.c_int32), ("radar_ref_thres_dbz", C.c_double),
+                ("gross_error", C.c_double), ("gross_error_rain", C.c_double), ("gross_error_radar_ref", C.c_double),
+                ("gross_error_radar_vr", C.c_double), ("gross_error_radar_prh", C.c_double),
+                ("gross_error_tcx", C.c_double), ("gross_error_tcy", C.c_double), ("gross_error_tcp", C.c_double)]
+
+
+class Mesh(C.Structure):
+    """letkf_mesh (section 5); ngrd_i / ngrd_j are HOST int32 arrays"""
+    _fields_ = [("nctype", C.c_int32), ("nlon", C.c_int32), ("nlat", C.c_int32), ("ihalo", C.c_int32),
+                ("jhalo", C.c_int32), ("rank_i", C.c_int32), ("rank_j", C.c_int32), ("reserved0", C.c_int32),
+                ("ngrd_i", C.c_void_p), ("ngrd_j", C.c_void_p)]
+
+
+class HaloLayout(C.Structure):
+    """letkf_halo_layout (section 5); the four arrays are HOST int32 arrays"""
+    _fields_ = [("nctype", C.c_int32), ("nprocs", C.c_int32), ("prc_num_x", C.c_int32), ("myrank", C.c_int32),
+                ("ngrd_i", C.c_void_p), ("ngrd_j", C.c_void_p), ("ngrdsch_i", C.c_void_p), ("ngrdsch_j", C.c_void_p)]
+
+
 class StateConsts(C.Structure):
     """letkf_state_consts (include/letkf_amd.h section 4)"""
     _fields_ = [("rdry", C.c_double), ("rvap", C.c_double), ("cvdry", C.c_double), ("pre00", C.c_double),
@@ -99,6 +123,8 @@ EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", 
            "letkf_ctx_set_stream", "letkf_ctx_synchronize", "letkf_core_c", "letkf_core_batch_dev",
            "letkf_das_points_dev", "letkf_obs_search_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
            "letkf_state_trans_dev", "letkf_member_points_dev", "letkf_ens_spread_dev",
+           "letkf_obs_departure_dev", "letkf_obs_mesh_sort_dev", "letkf_obs_halo_plan_dev",
+           "letkf_obs_gather_rows_dev", "letkf_obs_gather_i32_dev",
            "letkf_ctx_timing_enable", "letkf_ctx_timing_read"]
 
 _lib = None
@@ -218,6 +244,42 @@ class Context:
                                                  _ptr(rlev), _ptr(rz), C.c_int32(1), None, _ptr(obs_off),
                                                  _ptr(obs_idx), _ptr(rdiag), _ptr(rloc)))
         return obs_off, obs_idx[:nnz], rdiag[:nnz], rloc[:nnz]
+
+    # ---- (5) set_letkf_obs on the device
+    def obs_departure(self, params, elm, dat, err, ensval, kld, val, qc):
+        self._check(self._l.letkf_obs_departure_dev(self._c, C.byref(params), C.c_int64(elm.numel()), _ptr(elm),
+                                                    _ptr(dat), _ptr(err), _ptr(ensval), C.c_int64(kld), _ptr(val),
+                                                    _ptr(qc)))
+
+    def obs_mesh_sort(self, mesh, ncell, ctype, ri, rj, qc):
+        """Returns (n_cell [ncell] int32, key [nsorted] int32) device tensors."""
+        import torch
+        nobs = ctype.numel()
+        n_cell = torch.zeros(max(ncell, 1), dtype=torch.int32, device=ctype.device)
+        key = torch.empty(max(nobs, 1), dtype=torch.int32, device=ctype.device)
+        ns = C.c_int64(0)
+        self._check(self._l.letkf_obs_mesh_sort_dev(self._c, C.byref(mesh), C.c_int64(nobs), _ptr(ctype), _ptr(ri),
+                                                    _ptr(rj), _ptr(qc), _ptr(n_cell), _ptr(key), C.byref(ns)))
+        return n_cell[:ncell], key[:ns.value]
+
+    def obs_halo_plan(self, layout, n_all, nacx, cap):
+        """Returns (ac_ext [nacx] int32, src_row [nobstotal] int32) device tensors."""
+        import torch
+        ac_ext = torch.zeros(max(nacx, 1), dtype=torch.int32, device=n_all.device)
+        src_row = torch.empty(max(cap, 1), dtype=torch.int32, device=n_all.device)
+        nt = C.c_int64(0)
+        self._check(self._l.letkf_obs_halo_plan_dev(self._c, C.byref(layout), _ptr(n_all), _ptr(ac_ext),
+                                                    _ptr(src_row), C.c_int64(cap), C.byref(nt)))
+        return ac_ext[:nacx], src_row[:nt.value]
+
+    def obs_gather_rows(self, src_row, ncols, src, ld_src, dst, ld_dst):
+        self._check(self._l.letkf_obs_gather_rows_dev(self._c, C.c_int64(src_row.numel()), _ptr(src_row),
+                                                      C.c_int32(ncols), _ptr(src), C.c_int64(ld_src), _ptr(dst),
+                                                      C.c_int64(ld_dst)))
+
+    def obs_gather_i32(self, src_row, src, dst):
+        self._check(self._l.letkf_obs_gather_i32_dev(self._c, C.c_int64(src_row.numel()), _ptr(src_row), _ptr(src),
+                                                     _ptr(dst)))
 
     # ---- (4) the steps either side of the loop
     def state_trans(self, consts, nlev, nlon, nlat, nv3d, v3dg, inverse=False):

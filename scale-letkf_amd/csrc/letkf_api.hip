@@ -421,6 +421,74 @@ int letkf_obs_search_dev(letkf_ctx* c, const letkf_search_tables* t, int64_t npt
   return LETKF_OK;
 }
 
+int letkf_obs_departure_dev(letkf_ctx* c, const letkf_qc_params* p, int64_t nobs, const int32_t* elm, const double* dat,
+                            const double* err, double* ensval, int64_t kld, double* val, int32_t* qc) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!p || nobs < 0) return fail(LETKF_E_INVALID, "params is NULL or nobs < 0");
+  if (nobs == 0) return LETKF_OK;
+  if (!elm || !dat || !err || !ensval || !val || !qc) return fail(LETKF_E_INVALID, "an observation array is NULL");
+  if (p->member < 1 || kld < p->member + (p->det_run ? 1 : 0))
+    return fail(LETKF_E_INVALID, "kld must hold MEMBER (+1 with DET_RUN) columns");
+  if ((size_t)64 * (size_t)(kld | 1) * sizeof(double) > c->lds_max) return fail(LETKF_E_INVALID, "kld too large");
+  HIP_TRY(letkf::launch_obs_departure(*p, nobs, elm, dat, err, ensval, kld, val, qc, c->num_cu, c->stream));
+  return LETKF_OK;
+}
+
+int letkf_obs_mesh_sort_dev(letkf_ctx* c, const letkf_mesh* m, int64_t nobs, const int32_t* ctype, const double* ri,
+                            const double* rj, const int32_t* qc, int32_t* n_cell, int32_t* key, int64_t* nsorted) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!m || nobs < 0 || !nsorted) return fail(LETKF_E_INVALID, "mesh / nsorted is NULL or nobs < 0");
+  if (m->nctype < 1 || !m->ngrd_i || !m->ngrd_j || m->nlon < 1 || m->nlat < 1)
+    return fail(LETKF_E_INVALID, "bad mesh description");
+  if (nobs > 0 && (!ctype || !ri || !rj || !qc || !key)) return fail(LETKF_E_INVALID, "an observation array is NULL");
+  if (!n_cell) return fail(LETKF_E_INVALID, "n_cell is NULL");
+  if (nobs >= (1LL << 31)) return fail(LETKF_E_INVALID, "more than 2^31 local observations");
+  size_t need = 0;
+  long ns = 0;
+  HIP_TRY(letkf::obs_mesh_sort(*m, nobs, ctype, ri, rj, qc, n_cell, key, &ns, nullptr, &need, c->num_cu, c->stream));
+  if (need > c->scratch_bytes) HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc = ensure_bytes(c, &c->scratch, &c->scratch_bytes, need)) return rc;
+  size_t have = c->scratch_bytes;
+  HIP_TRY(letkf::obs_mesh_sort(*m, nobs, ctype, ri, rj, qc, n_cell, key, &ns, c->scratch, &have, c->num_cu, c->stream));
+  *nsorted = ns;
+  return LETKF_OK;
+}
+
+int letkf_obs_halo_plan_dev(letkf_ctx* c, const letkf_halo_layout* l, const int32_t* n_all, int32_t* ac_ext,
+                            int32_t* src_row, int64_t cap, int64_t* nobstotal) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!l || !nobstotal || !n_all || !ac_ext) return fail(LETKF_E_INVALID, "a required pointer is NULL");
+  if (l->nctype < 1 || l->nprocs < 1 || l->prc_num_x < 1 || l->myrank < 0 || l->myrank >= l->nprocs ||
+      l->nprocs % l->prc_num_x != 0 || !l->ngrd_i || !l->ngrd_j || !l->ngrdsch_i || !l->ngrdsch_j)
+    return fail(LETKF_E_INVALID, "bad rank layout / mesh description");
+  if (cap > 0 && !src_row) return fail(LETKF_E_INVALID, "src_row is NULL");
+  long nt = 0;
+  hipError_t e = letkf::obs_halo_plan(*l, n_all, ac_ext, src_row, cap, &nt, c->num_cu, c->stream);
+  *nobstotal = nt;
+  if (e == hipErrorInvalidValue && nt > cap) return fail(LETKF_E_INVALID, "src_row capacity is smaller than nobstotal");
+  HIP_TRY(e);
+  return LETKF_OK;
+}
+
+int letkf_obs_gather_rows_dev(letkf_ctx* c, int64_t nrows, const int32_t* src_row, int32_t ncols, const double* src,
+                              int64_t ld_src, double* dst, int64_t ld_dst) {
+  if (int rc = check_ctx(c)) return rc;
+  if (nrows < 0 || ncols < 0) return fail(LETKF_E_INVALID, "negative size");
+  if (nrows == 0 || ncols == 0) return LETKF_OK;
+  if (!src_row || !src || !dst || ld_src < ncols || ld_dst < ncols) return fail(LETKF_E_INVALID, "bad argument");
+  HIP_TRY(letkf::launch_gather_rows(nrows, src_row, ncols, src, ld_src, dst, ld_dst, c->num_cu, c->stream));
+  return LETKF_OK;
+}
+
+int letkf_obs_gather_i32_dev(letkf_ctx* c, int64_t nrows, const int32_t* src_row, const int32_t* src, int32_t* dst) {
+  if (int rc = check_ctx(c)) return rc;
+  if (nrows < 0) return fail(LETKF_E_INVALID, "negative size");
+  if (nrows == 0) return LETKF_OK;
+  if (!src_row || !src || !dst) return fail(LETKF_E_INVALID, "bad argument");
+  HIP_TRY(letkf::launch_gather_i32(nrows, src_row, src, dst, c->num_cu, c->stream));
+  return LETKF_OK;
+}
+
 int letkf_state_trans_dev(letkf_ctx* c, const letkf_state_consts* k, int32_t nlev, int32_t nlon, int32_t nlat,
                           int32_t nv3d, double* v3dg, int32_t inverse) {
   if (int rc = check_ctx(c)) return rc;

@@ -85,6 +85,16 @@ hipError_t launch_point_kernel(const PointArgs& a, const LaunchPlan& p, hipStrea
 bool wave_kernel_supports(int k, int nv, int mode);
 void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, int* run_len, int* grid, size_t* ws_bytes);
 hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st);
+hipError_t launch_obs_departure(const letkf_qc_params& p, long nobs, const int* elm, const double* dat, const double* err,
+                                double* ensval, long kld, double* val, int* qc, int num_cu, hipStream_t st);
+hipError_t obs_mesh_sort(const letkf_mesh& m, long nobs, const int* ctype, const double* ri, const double* rj,
+                         const int* qc, int* n_cell, int* key, long* nsorted, void* scratch, size_t* scratch_bytes,
+                         int num_cu, hipStream_t st);
+hipError_t obs_halo_plan(const letkf_halo_layout& l, const int* n_all, int* ac_ext, int* src_row, long cap,
+                         long* nobstotal, int num_cu, hipStream_t st);
+hipError_t launch_gather_rows(long nrows, const int* src_row, int ncols, const double* src, long ld_src, double* dst,
+                              long ld_dst, int num_cu, hipStream_t st);
+hipError_t launch_gather_i32(long nrows, const int* src_row, const int* src, int* dst, int num_cu, hipStream_t st);
 hipError_t launch_ens_to_pert(int k, int nv, long npts, double* x, long sp, long sm, long sv, hipStream_t st);
 hipError_t launch_state_trans(const letkf_state_consts& c, int nlev, long nxy, int nv3d, double* v, int inverse,
                               hipStream_t st);

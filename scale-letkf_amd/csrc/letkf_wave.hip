@@ -733,7 +733,6 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
   int bmat_sz = NBP * KR;
   if (kChunk * KR > bmat_sz) bmat_sz = kChunk * KR;
   if (tile_sz + bmat_sz < 1536 * NW) bmat_sz = 1536 * NW - tile_sz;
-  double* ytile = slice;                      // [kTnW][64]
   double* vbuf = slice;                       // [KR][kVld]          (after the Gram phase)
   double* bmat = slice + tile_sz;             // [KR][NBP]
   double* cbuf = bmat + bmat_sz;              // [kChunk][NBP]

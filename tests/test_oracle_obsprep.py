@@ -1,0 +1,109 @@
+"""CPU checks of the oracle's set_letkf_obs restatement (row f2: scale/letkf/letkf_obs.f90:361-561 departures + QC,
+:762-822 bucket sort, :922-976 / :1036-1100 extended-subdomain plan) against independent brute-force formulations."""
+import numpy as np
+import pytest
+
+from _obsprep import ID_RADAR_REF, ID_RADAR_VR, UNDEF, make_world, oracle_plan, oracle_rank_stage12
+
+
+def test_departure_and_qc_rules():
+    w = make_world(1, px=1, py=1, nobs=4000)
+    rk = w["ranks"][0]
+    o = oracle_rank_stage12(w, rk)
+    k, kld = w["k"], w["kld"]
+    e0, qc0 = rk["ensval"], rk["qc"]
+    seen = set()
+    for n in range(len(qc0)):
+        if qc0[n] > 0:                                   # untouched rows
+            assert o["qc"][n] == qc0[n] and np.array_equal(o["ensval"][n], e0[n])
+            continue
+        el, d = rk["elm"][n], rk["dat"][n]
+        if el == ID_RADAR_REF:
+            if d == UNDEF:
+                assert o["qc"][n] == 50
+                seen.add("undef")
+                continue
+            mem = int((e0[n, :k] > 15.0 + 1e-6).sum())
+            need = 2 if d > 15.0 + 1e-6 else 3
+            if mem < need:
+                assert o["qc"][n] == 12 and np.array_equal(o["ensval"][n], e0[n])
+                seen.add("refmem")
+                continue
+        mean = e0[n, 0]
+        for i in range(1, k):
+            mean = mean + e0[n, i]
+        mean = mean / k
+        assert np.array_equal(o["ensval"][n, :k], e0[n, :k] - mean)
+        assert o["val"][n] == d - mean
+        assert o["ensval"][n, k] == d - e0[n, k]         # DET_RUN column
+        ge = {ID_RADAR_REF: 3.0, ID_RADAR_VR: 2.5}.get(el, 5.0)
+        gross = abs(d - mean) > ge * rk["err"][n]
+        assert o["qc"][n] == (5 if gross else 0)
+        seen.add("gross" if gross else "good")
+    assert seen == {"undef", "refmem", "gross", "good"}
+
+
+@pytest.mark.parametrize("ngrd", [((4, 4), (6, 6), (3, 3)), ((4, 6), (6, 3), (3, 4))])
+def test_bucket_sort_is_the_stable_counting_sort(ngrd):
+    w = make_world(2, px=2, py=1, ngrd=ngrd)
+    for rk in w["ranks"]:
+        o = oracle_rank_stage12(w, rk)
+        good = np.nonzero(o["qc"] == 0)[0]
+        assert sorted(o["key"].tolist()) == good.tolist()
+        # cell of every row, written independently (note the reference's ngrd_i in the j formula, :1200)
+        gi, gj = w["ngrd_i"][rk["ctype"]], w["ngrd_j"][rk["ctype"]]
+        ril = rk["ri"] - rk["pi"] * w["nlon"] - w["ihalo"] - 0.5
+        rjl = rk["rj"] - rk["pj"] * w["nlat"] - w["ihalo"] - 0.5
+        ci = np.clip(np.ceil(ril * gi / w["nlon"]).astype(int), 1, gi)
+        cj = np.clip(np.ceil(rjl * gi / w["nlat"]).astype(int), 1, gj)
+        coff = np.concatenate([[0], np.cumsum(w["ngrd_i"].astype(int) * w["ngrd_j"])])
+        cell = coff[rk["ctype"]] + (cj - 1) * gi + (ci - 1)
+        order = good[np.lexsort((good, cell[good]))]
+        assert np.array_equal(o["key"], order)
+        assert np.array_equal(o["n_cell"], np.bincount(cell[good], minlength=w["ncell"]))
+
+
+@pytest.mark.parametrize("px,py", [(1, 1), (2, 2), (3, 2)])
+def test_extended_subdomain_plan_matches_global_brute_force(px, py):
+    w = make_world(3, px=px, py=py, nobs=5000)
+    st = [oracle_rank_stage12(w, rk) for rk in w["ranks"]]
+    n_all = np.stack([s["n_cell"] for s in st])
+    # the ALLGATHERV receive buffer: every rank's sorted rows, rank-major; remember the global obs number of each row
+    bufr_gidx = np.concatenate([rk["gidx"][s["key"]] for rk, s in zip(w["ranks"], st)])
+    g = w["glob"]
+    for me, rk in enumerate(w["ranks"]):
+        ac_ext, src_row, nt = oracle_plan(w, me, n_all, cap=len(bufr_gidx))
+        assert nt == len(src_row) and nt >= len(st[me]["key"])
+        got = bufr_gidx[src_row]
+        # brute force: for every ctype, every extended cell, the accepted global obs that fall into it, in
+        # (owner rank, local row) = (owner rank, global number) order
+        off = 0
+        pos = 0
+        for ic in range(w["nctype"]):
+            gi, gj, si, sj = (int(w[f][ic]) for f in ("ngrd_i", "ngrd_j", "ngrdsch_i", "ngrdsch_j"))
+            ei, ej = gi + 2 * si, gj + 2 * sj
+            ac = ac_ext[off:off + (ei + 1) * ej].reshape(ej, ei + 1)
+            off += (ei + 1) * ej
+            sel = np.nonzero(g["ctype"] == ic)[0]
+            accepted = np.zeros(w["nobs"], bool)
+            for rk2, s in zip(w["ranks"], st):
+                accepted[rk2["gidx"][s["key"]]] = True
+            sel = sel[accepted[sel]]
+            x = g["ri"][sel] - w["ihalo"] - 0.5
+            y = g["rj"][sel] - w["ihalo"] - 0.5
+            owner_i = np.clip(np.ceil(x / w["nlon"]).astype(int) - 1, 0, px - 1)
+            owner_j = np.clip(np.ceil(y / w["nlat"]).astype(int) - 1, 0, py - 1)
+            ci = np.clip(np.ceil((x - owner_i * w["nlon"]) * gi / w["nlon"]).astype(int), 1, gi)
+            cj = np.clip(np.ceil((y - owner_j * w["nlat"]) * gi / w["nlat"]).astype(int), 1, gj)
+            xi = ci + (owner_i - rk["pi"]) * gi + si          # extended mesh index, 1-based
+            xj = cj + (owner_j - rk["pj"]) * gj + sj
+            inside = (xi >= 1) & (xi <= ei) & (xj >= 1) & (xj <= ej)
+            for j in range(1, ej + 1):
+                assert ac[j - 1, 0] == pos
+                for i in range(1, ei + 1):
+                    want = np.sort(sel[inside & (xi == i) & (xj == j)])
+                    n = ac[j - 1, i] - ac[j - 1, i - 1]
+                    assert n == len(want)
+                    assert np.array_equal(got[pos:pos + n], want)
+                    pos += n
+        assert pos == nt
