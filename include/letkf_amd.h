@@ -334,6 +334,34 @@ int letkf_obs_gather_rows_dev(letkf_ctx *ctx, int64_t nrows, const int32_t *src_
                               int64_t ld_src, double *dst, int64_t ld_dst);
 int letkf_obs_gather_i32_dev(letkf_ctx *ctx, int64_t nrows, const int32_t *src_row, const int32_t *src, int32_t *dst);
 
+/*---------------------------------------------------------------------------
+ * (6) After the loop
+ *-------------------------------------------------------------------------*/
+/* monit_dep, scale/common/common_obs_scale.f90:1851-1895: per observation element (elem_uid, HOST [nid], the ids of
+ * common_obs_scale.f90:74-77 in that order) the count, mean and rms of dep over rows with qc == 0; Tv is counted as
+ * T and RE0 as REF (:1871-1876); elements without rows get undef (-9.99e33).  elm[n] = NINT(obs%elm).  Outputs are
+ * device arrays [nid].  Sums are taken in a fixed two-level order (reproducible run to run; differs from the
+ * reference's sequential order in the last bits, below the ES12.3 the reference prints). */
+int letkf_monit_dep_dev(letkf_ctx *ctx, int32_t nid, const int32_t *elem_uid, int64_t nn, const int32_t *elm,
+                        const double *dep, const int32_t *qc, int32_t *nobs, double *bias, double *rmse);
+
+/* Additive inflation, scale/letkf/letkf_tools.f90:884-913, on the strided ensemble layout of section 2:
+ *   anal(p,m,v) += add(p,mshuf(m),v) * infl_add * weight(ij) [* qmean(p,v) for iv_q_first <= v <= iv_q_last]
+ * add: the additive ensemble as PERTURBATIONS (read_ens_mpi_addiinfl + ensmean_grd + the subtraction of :862-871 =
+ * letkf_ens_mean_dev + letkf_ens_to_perturbations_dev), same strides as anal; weight: [nij1] addinfl_weight or NULL
+ * (= 1); qmean: INFL_ADD_Q_RATIO field, element (p,v) at p*q_sp + v*q_sv (pass gues + k*sm with q_sp = sp,
+ * q_sv = sv for gues3d(:,:,mmean,:)), or NULL; ishuf: dev [k] 0-based INFL_ADD_SHUFFLE permutation or NULL. */
+int letkf_additive_inflation_dev(letkf_ctx *ctx, int32_t k, int32_t nv, int64_t npts, int64_t nij1, double *anal,
+                                 const double *add, int64_t sp, int64_t sm, int64_t sv, double infl_add,
+                                 const double *weight, const double *qmean, int64_t q_sp, int64_t q_sv,
+                                 int32_t iv_q_first, int32_t iv_q_last, const int32_t *ishuf);
+
+/* addinfl_weight of INFL_ADD_REF_ONLY (:813-838): w(ij) = exp(-d2/2) with d2 = min over the reflectivity rows
+ * [0, nob) of ((rig-ri)DX)^2 + ((rjg-rj)DY)^2, over hori_loc^2, and 0 beyond dist_zero_fac_square. */
+int letkf_addinfl_weight_dev(letkf_ctx *ctx, int64_t nij1, const double *rig, const double *rjg, int64_t nob,
+                             const double *ob_ri, const double *ob_rj, double dx, double dy, double hori_loc,
+                             double *weight);
+
 /* Kernel timing helper for bench.py: average duration (ms) of the last
  * letkf_das_points_dev / letkf_core_batch_dev launches measured with HIP events on the
  * context's stream since the previous reset; *nlaunch receives the count. */

@@ -1033,3 +1033,68 @@ int64_t orc_obs_halo_plan(const orc_halo_layout *l, const int32_t *n_all, int32_
   free(xoff);
   return rc < 0 ? -1 : acx;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Row f4
+ * ---------------------------------------------------------------------------------------------- */
+void orc_monit_dep(int nid, const int32_t *elem_uid, int64_t nn, const int32_t *elm, const double *dep,
+                   const int32_t *qc, int32_t *nobs, double *bias, double *rmse) {
+  for (int i = 0; i < nid; ++i) {
+    nobs[i] = 0;
+    bias[i] = 0.0;
+    rmse[i] = 0.0;
+  }
+  for (int64_t n = 0; n < nn; ++n) {                                   /* common_obs_scale.f90:1867-1882 */
+    if (qc[n] != ORC_QC_GOOD) continue;
+    int ielm = elm[n];
+    if (ielm == 3074) ielm = 3073;                                     /* Tv as T */
+    if (ielm == ORC_ID_RADAR_REF_ZERO) ielm = ORC_ID_RADAR_REF;        /* RE0 as REF */
+    int i = -1;
+    for (int u = 0; u < nid; ++u)
+      if (elem_uid[u] == ielm) i = u;
+    if (i < 0) continue;
+    nobs[i] += 1;
+    bias[i] = bias[i] + dep[n];
+    rmse[i] = rmse[i] + dep[n] * dep[n];
+  }
+  for (int i = 0; i < nid; ++i) {                                      /* :1884-1892 */
+    if (nobs[i] == 0) {
+      bias[i] = ORC_UNDEF;
+      rmse[i] = ORC_UNDEF;
+    } else {
+      bias[i] = bias[i] / (double)nobs[i];
+      rmse[i] = sqrt(rmse[i] / (double)nobs[i]);
+    }
+  }
+}
+
+void orc_additive_inflation(int k, int nv, int64_t npts, int64_t nij1, double *anal, const double *add, int64_t sp,
+                            int64_t sm, int64_t sv, double infl_add, const double *weight, const double *qmean,
+                            int64_t q_sp, int64_t q_sv, int iv_q_first, int iv_q_last, const int32_t *ishuf) {
+  for (int v = 0; v < nv; ++v)                                         /* letkf_tools.f90:884-913 */
+    for (int m = 0; m < k; ++m) {
+      const int ms = ishuf ? ishuf[m] : m;
+      for (int64_t p = 0; p < npts; ++p) {
+        double x = add[p * sp + ms * sm + v * sv] * infl_add;
+        x = x * (weight ? weight[p % nij1] : 1.0);
+        if (qmean && v >= iv_q_first && v <= iv_q_last) x = x * qmean[p * q_sp + v * q_sv];
+        anal[p * sp + m * sm + v * sv] = anal[p * sp + m * sm + v * sv] + x;
+      }
+    }
+}
+
+void orc_addinfl_weight(int64_t nij1, const double *rig, const double *rjg, int64_t nob, const double *ob_ri,
+                        const double *ob_rj, double dx, double dy, double hori_loc, double *w) {
+  const double cut2 = (double)13.33333333f;                            /* dist_zero_fac_square, letkf_obs.f90:28 */
+  for (int64_t ij = 0; ij < nij1; ++ij) {                              /* letkf_tools.f90:818-836 */
+    double ref_min_dist = 1.0e33;
+    for (int64_t o = 0; o < nob; ++o) {
+      const double rdx = (rig[ij] - ob_ri[o]) * dx, rdy = (rjg[ij] - ob_rj[o]) * dy;
+      const double rdxy = rdx * rdx + rdy * rdy;
+      if (rdxy < ref_min_dist) ref_min_dist = rdxy;
+    }
+    ref_min_dist = ref_min_dist / (hori_loc * hori_loc);
+    w[ij] = ref_min_dist <= cut2 ? exp(-0.5 * ref_min_dist) : 0.0;
+  }
+}

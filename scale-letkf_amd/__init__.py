@@ -124,7 +124,8 @@ EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", 
            "letkf_das_points_dev", "letkf_obs_search_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
            "letkf_state_trans_dev", "letkf_member_points_dev", "letkf_ens_spread_dev",
            "letkf_obs_departure_dev", "letkf_obs_mesh_sort_dev", "letkf_obs_halo_plan_dev",
-           "letkf_obs_gather_rows_dev", "letkf_obs_gather_i32_dev",
+           "letkf_obs_gather_rows_dev", "letkf_obs_gather_i32_dev", "letkf_monit_dep_dev",
+           "letkf_additive_inflation_dev", "letkf_addinfl_weight_dev",
            "letkf_ctx_timing_enable", "letkf_ctx_timing_read"]
 
 _lib = None
@@ -280,6 +281,36 @@ class Context:
     def obs_gather_i32(self, src_row, src, dst):
         self._check(self._l.letkf_obs_gather_i32_dev(self._c, C.c_int64(src_row.numel()), _ptr(src_row), _ptr(src),
                                                      _ptr(dst)))
+
+    # ---- (6) after the loop
+    def monit_dep(self, elem_uid, elm, dep, qc):
+        """Returns (nobs int32 [nid], bias, rmse) device tensors."""
+        import numpy as np
+        import torch
+        ids = np.ascontiguousarray(elem_uid, dtype=np.int32)
+        nid = len(ids)
+        nobs = torch.zeros(nid, dtype=torch.int32, device=dep.device)
+        bias = torch.zeros(nid, dtype=torch.float64, device=dep.device)
+        rmse = torch.zeros(nid, dtype=torch.float64, device=dep.device)
+        self._check(self._l.letkf_monit_dep_dev(self._c, C.c_int32(nid), ids.ctypes.data_as(C.c_void_p),
+                                                C.c_int64(dep.numel()), _ptr(elm), _ptr(dep), _ptr(qc), _ptr(nobs),
+                                                _ptr(bias), _ptr(rmse)))
+        return nobs, bias, rmse
+
+    def additive_inflation(self, k, nv, npts, nij1, anal, add, sp, sm, sv, infl_add, weight=None, qmean=None, q_sp=0,
+                           q_sv=0, iv_q_first=5, iv_q_last=10, ishuf=None):
+        self._check(self._l.letkf_additive_inflation_dev(
+            self._c, C.c_int32(k), C.c_int32(nv), C.c_int64(npts), C.c_int64(nij1), _ptr(anal), _ptr(add),
+            C.c_int64(sp), C.c_int64(sm), C.c_int64(sv), C.c_double(infl_add), _ptr(weight), _ptr(qmean),
+            C.c_int64(q_sp), C.c_int64(q_sv), C.c_int32(iv_q_first), C.c_int32(iv_q_last), _ptr(ishuf)))
+
+    def addinfl_weight(self, rig, rjg, ob_ri, ob_rj, dx, dy, hori_loc):
+        import torch
+        w = torch.zeros(rig.numel(), dtype=torch.float64, device=rig.device)
+        self._check(self._l.letkf_addinfl_weight_dev(self._c, C.c_int64(rig.numel()), _ptr(rig), _ptr(rjg),
+                                                     C.c_int64(ob_ri.numel()), _ptr(ob_ri), _ptr(ob_rj),
+                                                     C.c_double(dx), C.c_double(dy), C.c_double(hori_loc), _ptr(w)))
+        return w
 
     # ---- (4) the steps either side of the loop
     def state_trans(self, consts, nlev, nlon, nlat, nv3d, v3dg, inverse=False):

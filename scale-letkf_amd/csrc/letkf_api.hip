@@ -489,6 +489,44 @@ int letkf_obs_gather_i32_dev(letkf_ctx* c, int64_t nrows, const int32_t* src_row
   return LETKF_OK;
 }
 
+int letkf_monit_dep_dev(letkf_ctx* c, int32_t nid, const int32_t* elem_uid, int64_t nn, const int32_t* elm,
+                        const double* dep, const int32_t* qc, int32_t* nobs, double* bias, double* rmse) {
+  if (int rc = check_ctx(c)) return rc;
+  if (nid < 1 || nid > 32 || !elem_uid || nn < 0 || !nobs || !bias || !rmse)
+    return fail(LETKF_E_INVALID, "bad element table / outputs");
+  if (nn > 0 && (!elm || !dep || !qc)) return fail(LETKF_E_INVALID, "an observation array is NULL");
+  const size_t need = letkf::monit_scratch_bytes(nid, c->num_cu);
+  if (need > c->scratch_bytes) HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc = ensure_bytes(c, &c->scratch, &c->scratch_bytes, need)) return rc;
+  HIP_TRY(letkf::launch_monit_dep(nid, elem_uid, nn, elm, dep, qc, nobs, bias, rmse, c->scratch, c->num_cu, c->stream));
+  return LETKF_OK;
+}
+
+int letkf_additive_inflation_dev(letkf_ctx* c, int32_t k, int32_t nv, int64_t npts, int64_t nij1, double* anal,
+                                 const double* add, int64_t sp, int64_t sm, int64_t sv, double infl_add,
+                                 const double* weight, const double* qmean, int64_t q_sp, int64_t q_sv,
+                                 int32_t iv_q_first, int32_t iv_q_last, const int32_t* ishuf) {
+  if (int rc = check_ctx(c)) return rc;
+  if (k < 1 || nv < 1 || npts < 0 || nij1 < 1 || !anal || !add) return fail(LETKF_E_INVALID, "bad argument");
+  if (npts % nij1 != 0) return fail(LETKF_E_INVALID, "npts must be nij1 * nlev");
+  HIP_TRY(letkf::launch_additive(k, nv, npts, nij1, anal, add, sp, sm, sv, infl_add, weight, qmean, q_sp, q_sv,
+                                 iv_q_first, iv_q_last, ishuf, c->num_cu, c->stream));
+  return LETKF_OK;
+}
+
+int letkf_addinfl_weight_dev(letkf_ctx* c, int64_t nij1, const double* rig, const double* rjg, int64_t nob,
+                             const double* ob_ri, const double* ob_rj, double dx, double dy, double hori_loc,
+                             double* weight) {
+  if (int rc = check_ctx(c)) return rc;
+  if (nij1 < 0 || nob < 0 || !(hori_loc > 0.0)) return fail(LETKF_E_INVALID, "bad argument");
+  if (nij1 == 0) return LETKF_OK;
+  if (!rig || !rjg || !weight || (nob > 0 && (!ob_ri || !ob_rj))) return fail(LETKF_E_INVALID, "a pointer is NULL");
+  const double cut2 = (double)13.33333333f;   // dist_zero_fac_square, a single-precision literal (letkf_obs.f90:28)
+  HIP_TRY(letkf::launch_addinfl_weight(nij1, rig, rjg, nob, ob_ri, ob_rj, dx, dy, hori_loc, cut2, weight, c->num_cu,
+                                       c->stream));
+  return LETKF_OK;
+}
+
 int letkf_state_trans_dev(letkf_ctx* c, const letkf_state_consts* k, int32_t nlev, int32_t nlon, int32_t nlat,
                           int32_t nv3d, double* v3dg, int32_t inverse) {
   if (int rc = check_ctx(c)) return rc;

@@ -95,6 +95,15 @@ hipError_t obs_halo_plan(const letkf_halo_layout& l, const int* n_all, int* ac_e
 hipError_t launch_gather_rows(long nrows, const int* src_row, int ncols, const double* src, long ld_src, double* dst,
                               long ld_dst, int num_cu, hipStream_t st);
 hipError_t launch_gather_i32(long nrows, const int* src_row, const int* src, int* dst, int num_cu, hipStream_t st);
+size_t monit_scratch_bytes(int nid, int num_cu);
+hipError_t launch_monit_dep(int nid, const int* elem_uid, long nn, const int* elm, const double* dep, const int* qc,
+                            int* nobs, double* bias, double* rmse, void* scratch, int num_cu, hipStream_t st);
+hipError_t launch_additive(int k, int nv, long npts, long nij1, double* anal, const double* add, long sp, long sm,
+                           long sv, double infl_add, const double* weight, const double* qmean, long q_sp, long q_sv,
+                           int iv_q_first, int iv_q_last, const int* ishuf, int num_cu, hipStream_t st);
+hipError_t launch_addinfl_weight(long nij1, const double* rig, const double* rjg, long nob, const double* ob_ri,
+                                 const double* ob_rj, double dx, double dy, double hori_loc, double cut2, double* w,
+                                 int num_cu, hipStream_t st);
 hipError_t launch_ens_to_pert(int k, int nv, long npts, double* x, long sp, long sm, long sv, hipStream_t st);
 hipError_t launch_state_trans(const letkf_state_consts& c, int nlev, long nxy, int nv3d, double* v, int inverse,
                               hipStream_t st);

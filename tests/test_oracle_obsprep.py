@@ -107,3 +107,48 @@ def test_extended_subdomain_plan_matches_global_brute_force(px, py):
                     assert np.array_equal(got[pos:pos + n], want)
                     pos += n
         assert pos == nt
+
+
+def test_monit_dep_and_additive_inflation_restatements():
+    """row f4 restatements against numpy one-liners (common_obs_scale.f90:1851-1895, letkf_tools.f90:884-913)"""
+    import ctypes as C
+    import _oracle
+    lib = _oracle.oracle()
+    rng = np.random.default_rng(4)
+    ids = np.array([2819, 3073, 3074, 4001, 4004, 4002], dtype=np.int32)
+    nn = 5000
+    elm = rng.choice(ids, nn).astype(np.int32)
+    dep = rng.normal(0.5, 2.0, nn)
+    qc = np.where(rng.random(nn) < 0.3, 5, 0).astype(np.int32)
+    nobs, bias, rmse = np.zeros(6, np.int32), np.zeros(6), np.zeros(6)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    lib.orc_monit_dep(C.c_int(6), p(ids, C.c_int32), C.c_int64(nn), p(elm, C.c_int32), p(dep, C.c_double),
+                      p(qc, C.c_int32), p(nobs, C.c_int32), p(bias, C.c_double), p(rmse, C.c_double))
+    merged = np.where(elm == 3074, 3073, np.where(elm == 4004, 4001, elm))
+    for u, i in enumerate(ids):
+        sel = (merged == i) & (qc == 0)
+        if i in (3074, 4004):
+            assert nobs[u] == 0 and bias[u] == -9.99e33 and rmse[u] == -9.99e33
+        else:
+            assert nobs[u] == sel.sum()
+            assert np.isclose(bias[u], dep[sel].mean(), rtol=1e-12) and np.isclose(rmse[u], np.sqrt((dep[sel] ** 2).mean()), rtol=1e-12)
+    k, nv, nij1, nlev = 4, 7, 10, 3
+    npts, nens = nij1 * nlev, k + 1
+    anal = rng.normal(size=(nv, nens, npts))
+    add = rng.normal(size=(nv, nens, npts))
+    w = rng.uniform(0, 1, nij1)
+    q = rng.uniform(1e-3, 1e-2, (nv, npts))
+    sh = rng.permutation(k).astype(np.int32)
+    want = anal.copy()
+    for v in range(nv):
+        for m in range(k):
+            x = add[v, sh[m]] * 0.25 * np.tile(w, nlev)
+            if 5 <= v <= 6:
+                x = x * q[v]
+            want[v, m] += x
+    got = anal.copy()
+    lib.orc_additive_inflation(C.c_int(k), C.c_int(nv), C.c_int64(npts), C.c_int64(nij1), p(got, C.c_double),
+                               p(add, C.c_double), C.c_int64(1), C.c_int64(npts), C.c_int64(npts * nens),
+                               C.c_double(0.25), p(w, C.c_double), p(q, C.c_double), C.c_int64(1), C.c_int64(npts),
+                               C.c_int(5), C.c_int(6), p(sh, C.c_int32))
+    assert np.allclose(got, want, rtol=1e-15, atol=0)
