@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LETKF_AMD_ABI_VERSION 2
+#define LETKF_AMD_ABI_VERSION 3
 
 /* host-side errors (function return values) */
 #define LETKF_OK 0
@@ -167,6 +167,11 @@ typedef struct {
                                 from the eigenvectors of the point before it (same results to rounding; fewer sweeps
                                 when consecutive points are spatial neighbours, as in gues3d's ij-fastest order).
                                 0 = library default (runs of up to 16), 1 = off, n > 1 = runs of n points */
+  uint32_t var_mask;         /* variables (bit v, v < nv) of THIS variable-localisation class; 0 = all.  With several
+                                classes (var_local_n2nc_max > 1, scale/letkf/letkf_tools.f90:130-157) the driver makes
+                                one call per class with the class's local lists (its var_local factors enter rloc /
+                                rdiag through letkf_search_tables.varloc); variables outside the mask, their infl and
+                                rtps_infl_out entries are not touched */
 } letkf_das_args;
 int letkf_das_points_dev(letkf_ctx *ctx, const letkf_das_args *args);
 

@@ -521,8 +521,10 @@ static int das_point(const orc_das_params *p, int64_t pt, int nobsl, const int32
   double *a0 = anal + pt * sp;
   int rc = 0;
 
+  const unsigned vmask = p->var_mask ? p->var_mask : ~0u;
   if (beta == 0.0) {                                 /* :333-359 */
     for (int v = 0; v < nv; ++v) {
+      if (!((vmask >> v) & 1u)) continue;
       for (int m = 0; m < k; ++m) a0[m * sm + v * sv] = g0[k * sm + v * sv] + g0[m * sm + v * sv];
       if (p->det_run) a0[(k + 1) * sm + v * sv] = g0[(k + 1) * sm + v * sv];
     }
@@ -530,6 +532,7 @@ static int das_point(const orc_das_params *p, int64_t pt, int nobsl, const int32
   }
   int done = 0;
   for (int v = 0; v < nv; ++v) {                     /* :366 */
+    if (!((vmask >> v) & 1u)) continue;              /* another class: its own call */
     double *infl_v = infl + pt + npts * v;
     if (p->q_update_top > 0.0 && g0[k * sm + p->iv_p * sv] < p->q_update_top && v >= p->iv_q_first &&
         v <= p->iv_q_last) {                         /* :371-385 */

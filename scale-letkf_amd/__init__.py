@@ -53,7 +53,7 @@ class DasArgs(C.Structure):
                 ("anal", C.c_void_p), ("sp", C.c_int64), ("sm", C.c_int64), ("sv", C.c_int64),
                 ("trans_out", C.c_void_p), ("transm_out", C.c_void_p), ("pa_out", C.c_void_p),
                 ("status", C.c_void_p), ("nsweep", C.c_void_p), ("rtps_infl_out", C.c_void_p),
-                ("warm_run", C.c_int32)]
+                ("warm_run", C.c_int32), ("var_mask", C.c_uint32)]
 
 
 class SearchTables(C.Structure):
@@ -209,7 +209,7 @@ class Context:
                    beta=None, det_run=False, infl_adaptive=False, relax_to_inflated_prior=False, relax_alpha=0.0,
                    relax_alpha_spread=0.0, q_update_top=0.0, q_sprd_max=0.0, iv_p=4, iv_q_first=5, iv_q_last=10,
                    trans_out=None, transm_out=None, pa_out=None, status=None, nsweep=None, rtps_infl_out=None,
-                   warm_run=0):
+                   warm_run=0, var_mask=0):
         a = DasArgs()
         a.k, a.nv, a.det_run, a.infl_adaptive = k, nv, int(bool(det_run)), int(bool(infl_adaptive))
         a.relax_to_inflated_prior = int(bool(relax_to_inflated_prior))
@@ -224,6 +224,7 @@ class Context:
         a.status, a.nsweep = _ptr(status), _ptr(nsweep)
         a.rtps_infl_out = _ptr(rtps_infl_out)
         a.warm_run = int(warm_run)
+        a.var_mask = int(var_mask)
         self._check(self._l.letkf_das_points_dev(self._c, C.byref(a)))
 
     # ---- (3) obs_local on the device: two-phase CSR build (count, scan, fill)

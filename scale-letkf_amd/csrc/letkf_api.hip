@@ -300,6 +300,7 @@ int letkf_core_batch_dev(letkf_ctx* c, const letkf_core_batch_args* g) {
   std::memset(&a, 0, sizeof(a));
   a.k = g->ne;
   a.nv = 0;
+  a.var_mask = ~0u;
   a.mode = 1;
   a.npts = g->nbatch;
   a.nobsl = g->nobsl;
@@ -372,6 +373,7 @@ int letkf_das_points_dev(letkf_ctx* c, const letkf_das_args* g) {
   a.status = g->status;
   a.nsweep = g->nsweep;
   a.rtps_out = g->rtps_infl_out;
+  a.var_mask = g->var_mask ? g->var_mask : ~0u;
   return launch(c, a, p, g->warm_run < 0 ? 0 : g->warm_run);
 }
 

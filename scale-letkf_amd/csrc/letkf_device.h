@@ -34,6 +34,7 @@ struct PointArgs {
   int det_run, infl_adaptive, relax_to_inflated_prior;
   int iv_p, iv_q_first, iv_q_last;
   int add_wbar_to_trans;
+  unsigned var_mask;   // variables of this variable-localisation class (all ones = every variable)
   int max_sweep;       // Jacobi sweep cap (60); lowered only by the LETKF_AMD_MAX_SWEEP profiling knob
   double relax_alpha, relax_alpha_spread, q_update_top, q_sprd_max;
   // state

@@ -302,12 +302,14 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) letkf_point_kernel(const Poi
     if (A.mode == 0 && beta == 0.0) {            // letkf_tools.f90:333-359
       for (int e = tid; e < nv * k; e += nthr) {
         const int v = e / k, mm = e - v * k;
-        a0[mm * A.sm + v * A.sv] = g0[k * A.sm + v * A.sv] + g0[mm * A.sm + v * A.sv];
+        if ((A.var_mask >> v) & 1u) a0[mm * A.sm + v * A.sv] = g0[k * A.sm + v * A.sv] + g0[mm * A.sm + v * A.sv];
       }
       if (A.det_run)
-        for (int v = tid; v < nv; v += nthr) a0[(k + 1) * A.sm + v * A.sv] = g0[(k + 1) * A.sm + v * A.sv];
+        for (int v = tid; v < nv; v += nthr)
+          if ((A.var_mask >> v) & 1u) a0[(k + 1) * A.sm + v * A.sv] = g0[(k + 1) * A.sm + v * A.sv];
       if (A.rtps_out)
-        for (int v = tid; v < nv; v += nthr) A.rtps_out[pt + A.npts * (long)v] = 1.0;
+        for (int v = tid; v < nv; v += nthr)
+          if ((A.var_mask >> v) & 1u) A.rtps_out[pt + A.npts * (long)v] = 1.0;
       if (tid == 0) {
         if (A.status) A.status[pt] = 0;
         if (A.nsweep) A.nsweep[pt] = 0;
@@ -318,9 +320,8 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) letkf_point_kernel(const Poi
     // variable skip mask for Q_UPDATE_TOP (letkf_tools.f90:371) and the solve's inflation slot
     bool qskip = false;
     if (A.mode == 0 && A.q_update_top > 0.0) qskip = g0[k * A.sm + A.iv_p * A.sv] < A.q_update_top;
-    int v0 = 0;                                  // first variable that is actually updated
-    if (qskip)
-      while (v0 < nv && v0 >= A.iv_q_first && v0 <= A.iv_q_last) ++v0;
+    int v0 = 0;                                  // first variable of this class that is actually updated
+    while (v0 < nv && (!((A.var_mask >> v0) & 1u) || (qskip && v0 >= A.iv_q_first && v0 <= A.iv_q_last))) ++v0;
     double* infl_p = nullptr;
     if (A.mode == 0) infl_p = (v0 < nv) ? &A.infl[pt + A.npts * (long)v0] : nullptr;
     else infl_p = &A.infl[pt];
@@ -565,7 +566,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) letkf_point_kernel(const Poi
         }
         cfac[v] = cf;
         cdiag[v] = cd;
-        if (A.rtps_out) {                            // work3da (letkf_tools.f90:460-462)
+        if (A.rtps_out && ((A.var_mask >> v) & 1u)) {   // work3da (letkf_tools.f90:460-462)
           const bool skipv = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
           A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cf : 1.0;
         }
@@ -609,15 +610,16 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) letkf_point_kernel(const Poi
           out = xmean[v] + beta * (pert + sdot[v]) + (1.0 - beta) * X[e];
         }
         if (A.q_sprd_max > 0.0 && v == A.iv_q_first && !skip) X[e] = out;   // keep for the clamp
-        else a0[mm * A.sm + v * A.sv] = out;
+        else if ((A.var_mask >> v) & 1u) a0[mm * A.sm + v * A.sv] = out;
       }
       if (A.det_run) {
         for (int v = tid; v < nv; v += nthr) {
           const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
-          a0[(k + 1) * A.sm + v * A.sv] = skip ? xdet[v] : xdet[v] + sdotd[v] * beta;   // :489-497
+          if ((A.var_mask >> v) & 1u)
+            a0[(k + 1) * A.sm + v * A.sv] = skip ? xdet[v] : xdet[v] + sdotd[v] * beta;   // :489-497
         }
       }
-      if (A.q_sprd_max > 0.0 && !(qskip)) {      // :500-513, variable iv3d_q only
+      if (A.q_sprd_max > 0.0 && !(qskip) && ((A.var_mask >> A.iv_q_first) & 1u)) {   // :500-513, variable iv3d_q only
         __syncthreads();
         const int v = A.iv_q_first;
         if (tid < 64) {
@@ -639,10 +641,10 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) letkf_point_kernel(const Poi
           }
         }
       }
-      if (A.infl_adaptive && n > 0) {            // :396-398: every updated variable gets the new value
+      if (A.infl_adaptive) {                     // :396-398: every updated variable of the class gets its first slot's value
         for (int v = tid; v < nv; v += nthr) {
           const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
-          if (!skip) A.infl[pt + A.npts * (long)v] = infl_new;
+          if (!skip && ((A.var_mask >> v) & 1u)) A.infl[pt + A.npts * (long)v] = infl_new;
         }
       }
     } else if (A.infl_adaptive && n > 0 && tid == 0) {

@@ -777,10 +777,11 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
 
     if (A.mode == 0 && beta == 0.0) {          // letkf_tools.f90:333-359
       for (int v = 0; v < nv; ++v) {
-        if (lane < k) a0[moff + v * A.sv] = g0[k * A.sm + v * A.sv] + g0[moff + v * A.sv];
+        if (lane < k && ((A.var_mask >> v) & 1u)) a0[moff + v * A.sv] = g0[k * A.sm + v * A.sv] + g0[moff + v * A.sv];
       }
-      if (A.det_run && lane < nv) a0[(k + 1) * A.sm + lane * A.sv] = g0[(k + 1) * A.sm + lane * A.sv];
-      if (A.rtps_out && lane < nv) A.rtps_out[pt + A.npts * (long)lane] = 1.0;
+      const bool mine = lane < nv && ((A.var_mask >> lane) & 1u);
+      if (A.det_run && mine) a0[(k + 1) * A.sm + lane * A.sv] = g0[(k + 1) * A.sm + lane * A.sv];
+      if (A.rtps_out && mine) A.rtps_out[pt + A.npts * (long)lane] = 1.0;
       if (lane == 0) {
         if (A.status) A.status[pt] = 0;
         if (A.nsweep) A.nsweep[pt] = 0;
@@ -790,9 +791,9 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
 
     bool qskip = false;
     if (A.mode == 0 && A.q_update_top > 0.0) qskip = g0[k * A.sm + A.iv_p * A.sv] < A.q_update_top;
+    // first variable of this variable-localisation class that is actually updated: its inflation slot drives the solve
     int v0 = 0;
-    if (qskip)
-      while (v0 < nv && v0 >= A.iv_q_first && v0 <= A.iv_q_last) ++v0;
+    while (v0 < nv && (!((A.var_mask >> v0) & 1u) || (qskip && v0 >= A.iv_q_first && v0 <= A.iv_q_last))) ++v0;
     double* infl_p = (A.mode == 0) ? ((v0 < nv) ? &A.infl[pt + A.npts * (long)v0] : nullptr) : &A.infl[pt];
     const double infl_old = infl_p ? *infl_p : 1.0;
 
@@ -1131,7 +1132,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
             cfv = A.relax_alpha_spread * sqrt(var_g * parm / (var_a * km1)) - A.relax_alpha_spread + 1.0;
         }
         cf[v] = uniform(cfv);
-        if (A.rtps_out && lane == 0) {                     // work3da (letkf_tools.f90:460-462); skipped variables keep 1
+        if (A.rtps_out && lane == 0 && ((A.var_mask >> v) & 1u)) {   // work3da (letkf_tools.f90:460-462); skipped variables keep 1
           const bool skipv = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
           A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cfv : 1.0;
         }
@@ -1174,16 +1175,17 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
             if (q_sprd > A.q_sprd_max) val = q_mean + dq * A.q_sprd_max / q_sprd;
           }
         }
-        if (lane < k) *ap = val;
+        const bool inclass = (A.var_mask >> v) & 1u;
+        if (lane < k && inclass) *ap = val;
         ap += A.sv;
-        if (A.det_run && lane == 0)
+        if (A.det_run && lane == 0 && inclass)
           a0[(k + 1) * A.sm + v * A.sv] = skip ? xdet[v] : xdet[v] + sdotd * beta;     // :489-497
       }
-      if (A.infl_adaptive && n > 0) {              // :396-398, after every parm read above
+      if (A.infl_adaptive) {                       // :396-398 (also without obs: the class copies its first slot), after every parm read above
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
-          if (!skip && lane == 0) A.infl[pt + A.npts * (long)v] = infl_new;
+          if (!skip && lane == 0 && ((A.var_mask >> v) & 1u)) A.infl[pt + A.npts * (long)v] = infl_new;
         }
       }
     } else if (A.infl_adaptive && n > 0 && lane == 0) {

@@ -117,7 +117,8 @@ class DasParams(C.Structure):
     _fields_ = [("k", C.c_int), ("nv", C.c_int), ("det_run", C.c_int), ("infl_adaptive", C.c_int),
                 ("relax_to_inflated_prior", C.c_int), ("relax_alpha", C.c_double),
                 ("relax_alpha_spread", C.c_double), ("q_update_top", C.c_double), ("q_sprd_max", C.c_double),
-                ("iv_p", C.c_int), ("iv_q_first", C.c_int), ("iv_q_last", C.c_int), ("nthreads", C.c_int)]
+                ("iv_p", C.c_int), ("iv_q_first", C.c_int), ("iv_q_last", C.c_int), ("nthreads", C.c_int),
+                ("var_mask", C.c_uint)]
 
 
 def das_points(params, obs_off, obs_idx, rdiag_l, rloc_l, ensval, dep, beta, infl, gues, sp, sm, sv,

@@ -33,7 +33,7 @@ def test_header_symbols_exported(pkg):
 
 
 def test_abi_version(pkg):
-    assert pkg.lib().letkf_amd_abi_version() == 2
+    assert pkg.lib().letkf_amd_abi_version() == 3
 
 
 def test_fails_loudly_without_device(pkg):

@@ -188,3 +188,58 @@ def test_warm_start_cuts_sweeps_on_neighbouring_points():
         scale = max(x[v, k].abs().max().item(), x[v, :k].abs().max().item())
         assert (a_cold[v] - a_warm[v]).abs().max().item() <= 1e-10 * scale
     assert s_warm < s_cold - 1.5, (s_warm, s_cold)
+
+
+@pytest.mark.parametrize("k,nv", [(50, 11), (20, 11), (100, 11), (33, 7)])
+@pytest.mark.parametrize("name", ["rtps_adaptive_det", "rtps_qtop", "rtpp_qclamp"])
+def test_two_variable_localisation_classes(name, k, nv):
+    """var_local_n2nc_max = 2 (letkf_tools.f90:130-157, :372-439): one call per class with the class's own local lists
+    (here the second class sees the same observations with VAR_LOCAL = 0.6: rloc * 0.6, rdiag / 0.6) and var_mask;
+    every variable, inflation slot and RTPS factor must come out as the oracle's two-pass restatement."""
+    from _gpu import ctx, dev
+    cfg = CONFIGS[name]
+    det = bool(cfg.get("det_run", 0))
+    npts = 30
+    c = das_case(k=k, nv=nv, npts=npts, nobs_tot=500, n_mean=90, seed=40 + k, det_run=det, infl0=1.07)
+    c["infl"] = c["infl"] * (1.0 + 0.01 * np.arange(c["infl"].size) / c["infl"].size)   # distinct slots
+    mask_a = 0b0011111 if nv == 7 else 0b00000011111
+    mask_b = ((1 << nv) - 1) & ~mask_a
+    lists = {mask_a: (c["rdiag"], c["rloc"]), mask_b: (c["rdiag"] / 0.6, c["rloc"] * 0.6)}
+    want_anal = np.full_like(c["gues"], np.nan)
+    want_infl = c["infl"].copy()
+    want_rtps = np.full(npts * nv, np.nan)
+    for mask, (rd, rl) in lists.items():
+        prm = _oracle.DasParams(k=k, nv=nv, det_run=int(det), infl_adaptive=cfg.get("infl_adaptive", 0),
+                                relax_to_inflated_prior=cfg.get("relax_to_inflated_prior", 0),
+                                relax_alpha=cfg.get("relax_alpha", 0.0),
+                                relax_alpha_spread=cfg.get("relax_alpha_spread", 0.0),
+                                q_update_top=cfg.get("q_update_top", 0.0), q_sprd_max=cfg.get("q_sprd_max", 0.0),
+                                iv_p=4, iv_q_first=5, iv_q_last=min(10, nv - 1), nthreads=4, var_mask=mask)
+        r = _oracle.das_points(prm, c["obs_off"], c["obs_idx"], rd, rl, c["ensval"], c["dep"], c["beta"], want_infl,
+                               c["gues"], c["sp"], c["sm"], c["sv"], want_rtps=True)
+        assert r["rc"] == 0
+        sel = np.array([(mask >> v) & 1 for v in range(nv)], bool)
+        wa, ra = want_anal.reshape(nv, -1), r["anal"].reshape(nv, -1)
+        wa[sel] = ra[sel]
+        want_infl = r["infl"]
+        want_rtps.reshape(nv, npts)[sel] = r["rtps"].reshape(nv, npts)[sel]
+    anal = torch.full((c["gues"].size,), float("nan"), dtype=torch.float64, device="cuda")
+    infl = dev(c["infl"])
+    rtps = torch.full((npts * nv,), float("nan"), dtype=torch.float64, device="cuda")
+    status = torch.full((npts,), -1, dtype=torch.int32, device="cuda")
+    for mask, (rd, rl) in lists.items():
+        ctx().das_points(k, nv, dev(c["obs_off"]), dev(c["obs_idx"]), dev(rd), dev(rl), dev(c["ensval"]), c["kld"],
+                         dev(c["dep"]), infl, dev(c["gues"]), anal, c["sp"], c["sm"], c["sv"], beta=dev(c["beta"]),
+                         det_run=det, infl_adaptive=cfg.get("infl_adaptive", 0),
+                         relax_to_inflated_prior=cfg.get("relax_to_inflated_prior", 0),
+                         relax_alpha=cfg.get("relax_alpha", 0.0), relax_alpha_spread=cfg.get("relax_alpha_spread", 0.0),
+                         q_update_top=cfg.get("q_update_top", 0.0), q_sprd_max=cfg.get("q_sprd_max", 0.0), iv_p=4,
+                         iv_q_first=5, iv_q_last=min(10, nv - 1), status=status, rtps_infl_out=rtps, var_mask=mask)
+        torch.cuda.synchronize()
+        assert (status.cpu().numpy() == 0).all()
+    compare_anal(c, dict(anal=want_anal), anal.cpu().numpy(), k, nv, det)
+    assert np.abs(infl.cpu().numpy() - want_infl).max() <= 1e-12
+    if cfg.get("relax_alpha_spread", 0.0) != 0.0:
+        g = rtps.cpu().numpy()
+        live = ~np.isnan(want_rtps) & (want_rtps != 0.0)
+        assert np.allclose(g[live], want_rtps[live], rtol=1e-9, atol=0)
