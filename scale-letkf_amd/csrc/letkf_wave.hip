@@ -382,26 +382,48 @@ __device__ __forceinline__ double slot_sum(double v) {
   return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
 
-template <int KR>
+// sum of the two lanes of a slot.  One wave: lanes (m, m + 32) through v_permlane32_swap.  Two waves (k > 62): the
+// same lane of the two waves, through LDS and a workgroup barrier; the two exchange buffers alternate, so that a buffer
+// is rewritten only after the barrier that follows everybody's read of it.
+template <int NW>
+__device__ __forceinline__ double slot_sum_nw(double v, double* xs, int& ph) {
+  if constexpr (NW == 1) {
+    return slot_sum(v);
+  } else {
+    const int t = threadIdx.x & 127;
+    xs[ph * 128 + t] = v;
+    __syncthreads();
+    const double o = xs[ph * 128 + (t ^ 64)];
+    ph ^= 1;
+    return v + o;
+  }
+}
+
+// NW = 2 (62 < k <= 100): slot m = lane m of both waves (wave 0 the even rows, wave 1 the odd rows); everything
+// else as for one wave -- the DPP shifts stay inside a wave, only the inner-product halves and the convergence vote
+// cross waves (three workgroup barriers per step pair).
+template <int KR, int NW>
 __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const int max_sweep, double* lds) {
   static_assert(KR % 2 == 0, "row halves");
   constexpr int H = KR / 2;
-  constexpr int RC = 24;                       // rows per conversion chunk: 24 * 64 doubles of LDS
-  const int lane = threadIdx.x & 63;
-  const int slot = lane & 31, par = lane >> 5;
+  constexpr int RC = 24;                       // rows per conversion chunk: 24 * 64 NW doubles of LDS
+  constexpr int NL = 64 * NW;
+  const int lane = threadIdx.x & (NL - 1);
+  const int slot = (NW == 1) ? (lane & 31) : (lane & 63), par = (NW == 1) ? (lane >> 5) : (lane >> 6);
+  int ph = 0;
   const int ncol = (k + 1) & ~1;               // an odd k gets one zero column as an extra (inert) participant
   const int S = ncol >> 1;                     // slots in use
   double xa[H], xb[H], xf[H];
   // ---- column-per-lane -> row-split: lds[r][col], r in chunks
 #pragma unroll
   for (int r0 = 0; r0 < KR; r0 += RC) {
-    wave_lds_sync();
+    psync<NW>();
 #pragma unroll
-    for (int r = r0; r < r0 + RC && r < KR; ++r) lds[(r - r0) * 64 + lane] = g[r];
-    wave_lds_sync();
+    for (int r = r0; r < r0 + RC && r < KR; ++r) lds[(r - r0) * NL + lane] = g[r];
+    psync<NW>();
 #pragma unroll
     for (int rr = r0 / 2; rr < (r0 + RC) / 2 && rr < H; ++rr) {
-      const double2 v2 = *reinterpret_cast<const double2*>(&lds[(2 * rr + par - r0) * 64 + 2 * slot]);
+      const double2 v2 = *reinterpret_cast<const double2*>(&lds[(2 * rr + par - r0) * NL + 2 * slot]);
       xa[rr] = v2.x;
       xb[rr] = v2.y;
     }
@@ -425,8 +447,8 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
         a0 = fma(xa[rr], xa[rr], a0);
         b0 = fma(xb[rr], xb[rr], b0);
       }
-      alA = slot_sum(a0);
-      alB = slot_sum(b0);
+      alA = slot_sum_nw<NW>(a0, lds, ph);
+      alB = slot_sum_nw<NW>(b0, lds, ph);
       isA = isB = scA = scB = 1.0;
       for (int t = 0; t < ncol && !done; t += 2) {
         bool notconv = false;
@@ -438,7 +460,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
             if (rr & 1) p1 = fma(xa[rr], xb[rr], p1);
             else p0 = fma(xa[rr], xb[rr], p0);
           }
-          const double ga = slot_sum(p0 + p1) * (isA * isB);
+          const double ga = slot_sum_nw<NW>(p0 + p1, lds, ph) * (isA * isB);
           const double a = alA, b = alB;
           const double g2 = ga * ga, ab = a * b;
           notconv |= g2 > kStopTol2W * ab;
@@ -481,7 +503,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
             else p0 = fma(xa[rr], xb[rr], p0);
           }
           const double alAr = dpp_shift0<0x130>(alA), isAr = dpp_shift0<0x130>(isA), scAr = dpp_shift0<0x130>(scA);
-          const double ga = slot_sum(p0 + p1) * (isB * isAr);
+          const double ga = slot_sum_nw<NW>(p0 + p1, lds, ph) * (isB * isAr);
           const double a = alB, b = alAr;
           const double g2 = ga * ga, ab = a * b;
           notconv |= hasR && g2 > kStopTol2W * ab;
@@ -520,7 +542,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           }
         }
         ++pairs;
-        quiet = __any(notconv) ? 0 : quiet + 1;
+        quiet = pany<NW>(notconv) ? 0 : quiet + 1;
         done = quiet >= S;
       }
     }
@@ -535,15 +557,15 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
   // ---- row-split -> column-per-lane
 #pragma unroll
   for (int r0 = 0; r0 < KR; r0 += RC) {
-    wave_lds_sync();
+    psync<NW>();
 #pragma unroll
     for (int rr = r0 / 2; rr < (r0 + RC) / 2 && rr < H; ++rr)
-      *reinterpret_cast<double2*>(&lds[(2 * rr + par - r0) * 64 + 2 * slot]) = double2{xa[rr], xb[rr]};
-    wave_lds_sync();
+      *reinterpret_cast<double2*>(&lds[(2 * rr + par - r0) * NL + 2 * slot]) = double2{xa[rr], xb[rr]};
+    psync<NW>();
 #pragma unroll
-    for (int r = r0; r < r0 + RC && r < KR; ++r) g[r] = lds[(r - r0) * 64 + lane];
+    for (int r = r0; r < r0 + RC && r < KR; ++r) g[r] = lds[(r - r0) * NL + lane];
   }
-  wave_lds_sync();
+  psync<NW>();
   return sweep;
 }
 
@@ -627,10 +649,9 @@ __device__ __forceinline__ void pin_rows8(double (&o)[KR]) {
 template <int KR, int NW>
 __device__ __forceinline__ void warm_start_product(double (&g)[KR], const double* __restrict__ uws, const int k,
                                                    double* cb) {
-  static_assert(NW == 1, "one wavefront per point");
   constexpr int NL = 64 * NW;
   constexpr int NG = (KR + 7) / 8;
-  static_assert(NG <= 8, "pin_rows8 dispatch below");
+  static_assert(NG <= 13, "pin_rows8 dispatch below");
   const int lane = threadIdx.x & (NL - 1);
   const int ncol = (k + 1) & ~1;
   double out[KR];
@@ -683,6 +704,11 @@ __device__ __forceinline__ void warm_start_product(double (&g)[KR], const double
         if (gi == 5) pin_rows8<KR, 40>(out);
         if (gi == 6) pin_rows8<KR, 48>(out);
         if (gi == 7) pin_rows8<KR, 56>(out);
+        if (gi == 8) pin_rows8<KR, 64>(out);
+        if (gi == 9) pin_rows8<KR, 72>(out);
+        if (gi == 10) pin_rows8<KR, 80>(out);
+        if (gi == 11) pin_rows8<KR, 88>(out);
+        if (gi == 12) pin_rows8<KR, 96>(out);
 #pragma unroll
         for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
       }
@@ -746,7 +772,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
   // Each wave walks a RUN of run_len consecutive points (warm-started eigensolves, see warm_start_product); the 4
   // runs of a workgroup are consecutive too, and workgroups are dealt over the XCDs so that neighbouring points
   // (which gather almost the same obs rows) hit the same L2
-  constexpr bool WARM = (NW == 1);
+  constexpr bool WARM = true;
   constexpr int PPW = (NW == 1) ? 4 : 1;      // points in flight per workgroup
   const int run_len = WARM ? A.run_len : 1;
   const long per_wg = (long)PPW * run_len;
@@ -1024,8 +1050,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       if constexpr (WARM) {
         if (have_u && !(A.warm_dbg & 1)) warm_start_product<KR, NW>(g, uws, k, slice);
       }
-      if constexpr (NW == 1) sweeps = jacobi_split<KR>(g, k, A.max_sweep, slice);
-      else sweeps = jacobi_regs<KR, NW>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
+      sweeps = jacobi_split<KR, NW>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
 
       double ss = 0.0;
 #pragma unroll
@@ -1282,23 +1307,25 @@ static int wave_kr(int k) {
 // n > 1 = runs of n points.
 void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, int* run_len, int* grid, size_t* ws_bytes) {
   const bool one_wave = k <= 62;
+  const long ppw = one_wave ? 4 : 1;           // points in flight per workgroup
   int R = 1;
-  if (one_wave && mode == 0) {
+  if (mode == 0) {
     if (run_req > 0) R = run_req;
     else {
       // runs of 16 (first point of a run is a cold start), shortened until there are >= 4 workgroups per CU
-      long r = npts / (4L * num_cu * 4);
+      long r = npts / (ppw * num_cu * 4);
       R = (int)(r < 1 ? 1 : r > 16 ? 16 : r);
     }
     if (R > 4096) R = 4096;
   }
-  const long per_wg = (one_wave ? 4L : 1L) * R;
+  const long per_wg = ppw * R;
   const long nwg = (npts + per_wg - 1) / per_wg;
   long g = (long)num_cu * 16;   // 8x oversubscribed: the static block stride balances better (measured 573 ms at 2x, 541 at 16x)
   if (const char* e = std::getenv("LETKF_AMD_WAVE_GRID")) g = (long)num_cu * std::atoi(e);   // experiments
   *grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
   *run_len = R;
-  *ws_bytes = (R > 1) ? (size_t)*grid * 4 * (size_t)wave_kr(k) * 64 * sizeof(double) : 0;
+  // one [KR][lanes of a point] slot per wave-group of the grid
+  *ws_bytes = (R > 1) ? (size_t)*grid * ppw * (size_t)wave_kr(k) * (one_wave ? 64 : 128) * sizeof(double) : 0;
 }
 
 hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st) {
