@@ -1,23 +1,20 @@
-// letkf_wave.hip -- wavefront-per-grid-point LETKF kernel for k <= 64 (gfx950).
+// letkf_wave.hip -- wavefront-per-grid-point LETKF kernel for k <= 62, two wavefronts for 65 <= k <= 100 (gfx950).
 //
-// One 64-lane wavefront solves one grid point; the 4 waves of a workgroup are fully
-// independent (no workgroup barrier anywhere), so a CU keeps 8 points in flight.
+// One 64-lane wavefront solves one grid point; the 4 waves of a workgroup are fully independent (no workgroup
+// barrier anywhere), so a CU keeps 8 points in flight.  Each wave walks a run of consecutive points.
 //
-// Data layout inside the wave: lane j owns column j of the k x k work matrix
-//   G = A = Ys^T Ys + (k-1)/rho I      (common/common_letkf.f90:127-143)
-// as KR doubles in VGPRs.  The symmetric eigenproblem (reference: common_mtx.f90:41 ->
-// EISPACK rs, netlib.f:524) is solved by one-sided (Hestenes) Jacobi directly on those
-// registers with an odd-even transposition pair ordering: every lane only ever pairs with a
-// neighbouring lane, fetches that column with DPP moves on the VALU, and both lanes of a pair
-// apply the same plane rotation (see jacobi_regs).  No LDS traffic, no barriers, all control
-// flow wave-uniform.  Columns converge to lambda_j v_j, so lambda_j = |g_j| and V needs no
-// accumulation.
-//
-// Afterwards (lane j still holds v_j):
-//   U[j][b] = v_j . B_b        B = [Ys^T d, Ys^T d_det, x'_1 .. x'_nv]  (LDS broadcast reads)
-//   Out = V (D U)              through 8-column LDS transposition chunks, lane m gets row m
-//   -> w-bar, w-bar_det, T x'_v;  RTPP/RTPS, beta, det member, q clamp as
-//      scale/letkf/letkf_tools.f90:457-513.  T / Pa themselves are only formed on request.
+// Per point:
+//   Gram         A = Ys^T Ys + (k-1)/rho I (common/common_letkf.f90:127-143) on the FP64 matrix cores, observation
+//                rows straight from the obs table into MFMA operand layout; accumulator tiles -> lane j = column j
+//   warm start   G0 = A Q, Q = eigenvectors of the previous point of the run (global workspace slot)
+//   eigen-solve  (reference: common_mtx.f90:41 -> EISPACK rs, netlib.f:524) one-sided (Hestenes) Jacobi in registers,
+//                row-split layout, odd-even transposition ordering, DPP exchanges only (jacobi_split).  Columns
+//                converge to lambda_j v_j, so lambda_j = |g_j| and V needs no accumulation.
+//   apply        (lane j holds v_j)
+//                U[j][b] = v_j . B_b        B = [Ys^T d, Ys^T d_det, x'_1 .. x'_nv]  (LDS broadcast reads)
+//                Out = V (D U)              through 8-column LDS transposition chunks, lane m gets row m
+//                -> w-bar, w-bar_det, T x'_v;  RTPP/RTPS, beta, det member, q clamp as
+//                   scale/letkf/letkf_tools.f90:457-513.  T / Pa themselves are only formed on request.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -173,191 +170,18 @@ __device__ __forceinline__ double fast_rcp(double x) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// One-sided (Hestenes) Jacobi on register-resident columns.  Returns sweeps used.
+// One-sided (Hestenes) Jacobi on register-resident columns.
 //
-// Pair ordering = odd-even transposition on the lane line: even steps pair lanes (0,1)(2,3)..., odd steps
-// (1,2)(3,4)...; after its rotation a pair SWAPS places (each lane simply computes the partner's new column
-// instead of its own).  After k steps every one of the k(k-1)/2 column pairs has met exactly once, for any k,
-// and the only partners a lane ever has are its two neighbours -- so the 2*KR-dword column fetch is a DPP
-// move on the VALU (quad_perm[1,0,3,2] / wave_shl:1 / wave_shr:1) instead of ds_bpermute through the LDS
-// crossbar, which at 4 LDS cycles per dword-move and 4 SIMDs per CU was what bounded the XOR-tournament
-// version (measured 1.6 ms -> 0.7 ms per sweep on the C2-mini workload).
+// Pair ordering = odd-even transposition on a line of column positions: even steps pair positions (0,1)(2,3)...,
+// odd steps (1,2)(3,4)...; after its rotation a pair SWAPS places.  After k steps every one of the k(k-1)/2 column
+// pairs has met exactly once, for any k, and the only partners a column ever has are its two neighbours.
+// The rotation itself is a "fast" scaled rotation G' = H + coef * G (one FMA per element): the cosine is not
+// multiplied into the column but accumulated in a per-column inverse scale `is`, and the squared norms alpha follow
+// the rotation identities alpha' = alpha -/+ t*gamma.  Both are refreshed once per sweep.
+// (Earlier layouts, measured and replaced -- see DESIGN.md 4.1: a workgroup per point with G in LDS; lane = column
+// with a ds_bpermute XOR tournament; lane = column with DPP even steps and LDS-chunk odd steps.)
 //
-// The rotation itself is a "fast" scaled rotation G' = H + coef * G (KR FMAs): the cosine is not multiplied
-// into the column but accumulated in a per-column inverse scale `is`, and the squared norms alpha follow the
-// rotation identities alpha' = alpha -/+ t*gamma.  Both are refreshed once per sweep.
-// ---------------------------------------------------------------------------------------------
-// One Jacobi step.  `own` holds this lane's column, the partner's column is fetched into `oth`, and the lane's NEW
-// column (the partner's rotated one: rotate-and-swap) is left in `oth` -- the caller ping-pongs the two arrays, so
-// the update is a single v_fmac per element with no register copy (the first version updated in place and paid
-// 50 v_mov_b64 per step for it).  Lanes without a partner in this step (the two ends of the line in odd steps, and
-// every lane beyond the last column) are made their own partner: they fetch their own column and all formulas
-// degenerate to the identity (gamma-driven t = 0), so no branch on `has` is needed.
-template <int KR, bool ODD, int NW>
-__device__ __forceinline__ bool jacobi_step(double (&own)[KR], double (&oth)[KR], double& al, double& is, double& sc,
-                                            const int ncol, double* xbuf) {
-  constexpr int NL = 64 * NW;                            // lanes of the point
-  const int lane = threadIdx.x & (NL - 1);
-  const bool oddlane = (lane & 1) != 0;
-  double be, isq, scq;
-  double ga0 = 0.0, ga1 = 0.0;
-  int pl;
-  if (!ODD) {
-    pl = lane ^ 1;                                       // ncol is even: every lane < ncol has its partner
-#pragma unroll
-    for (int r = 0; r < KR; r += 2) {
-      oth[r] = dpp_mov<0xB1>(own[r]);
-      oth[r + 1] = dpp_mov<0xB1>(own[r + 1]);
-      ga0 = fma(own[r], oth[r], ga0);
-      ga1 = fma(own[r + 1], oth[r + 1], ga1);
-    }
-    be = dpp_mov<0xB1>(al);
-    isq = dpp_mov<0xB1>(is);
-    scq = dpp_mov<0xB1>(sc);
-  } else {
-    // partner is lane+1 (odd lanes) / lane-1 (even lanes): through LDS in row chunks with b128 accesses (conflict-free
-    // at a lane stride of 10 doubles) -- the VALU alternative is 2 DPP moves + a select per dword (measured slower)
-    pl = oddlane ? lane + 1 : lane - 1;
-    if (lane >= ncol || pl < 0 || pl >= ncol) pl = lane;
-    constexpr int CR = (KR % 10 == 0) ? 10 : 8;          // rows per chunk
-    constexpr int LS = 10;                                // lane stride in doubles
-    constexpr int NCH = (KR + CR - 1) / CR;
-    // two chunk slots, software pipelined.  DS instructions of one wave execute in order, so a later ds_read sees
-    // every earlier ds_write of the wave; only the compiler must keep program order (it has to: the two pointers may
-    // alias as far as it can tell).  With two waves per point the pair (63, 64) straddles the waves: then every
-    // chunk hand-off is a workgroup barrier (read c, barrier, write c+2 into the slot just read).
-    double* smine = xbuf + 2 * NL * LS + lane * 4;
-    const double* stheirs = xbuf + 2 * NL * LS + pl * 4;
-    smine[0] = al;
-    smine[1] = is;
-    smine[2] = sc;
-    auto put = [&](int c) {
-      double* mine = xbuf + (c & 1) * NL * LS + lane * LS;
-#pragma unroll
-      for (int e = 0; e < CR; e += 2)
-        if (c * CR + e < KR) *reinterpret_cast<double2*>(&mine[e]) = double2{own[c * CR + e], own[c * CR + e + 1]};
-    };
-    auto get = [&](int c) {
-      const double* theirs = xbuf + (c & 1) * NL * LS + pl * LS;
-#pragma unroll
-      for (int e = 0; e < CR; e += 2) {
-        if (c * CR + e < KR) {
-          const double2 t2 = *reinterpret_cast<const double2*>(&theirs[e]);
-          oth[c * CR + e] = t2.x;
-          oth[c * CR + e + 1] = t2.y;
-          ga0 = fma(own[c * CR + e], t2.x, ga0);
-          ga1 = fma(own[c * CR + e + 1], t2.y, ga1);
-        }
-      }
-    };
-    if constexpr (NW == 1) {
-      put(0);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        if (c + 1 < NCH) put(c + 1);
-        __builtin_amdgcn_wave_barrier();
-        get(c);
-      }
-      be = stheirs[0];
-      isq = stheirs[1];
-      scq = stheirs[2];
-      __builtin_amdgcn_wave_barrier();
-    } else {
-      put(0);
-      if (NCH > 1) put(1);
-      __syncthreads();
-      be = stheirs[0];
-      isq = stheirs[1];
-      scq = stheirs[2];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        get(c);
-        __syncthreads();
-        if (c + 2 < NCH) put(c + 2);
-      }
-    }
-  }
-  const double ga = (ga0 + ga1) * (is * isq);            // true inner product
-  const bool lo = lane <= pl;
-  const double a = lo ? al : be, b = lo ? be : al;       // both lanes of a pair see the same (a, b, ga)
-  const double g2 = ga * ga, ab = a * b;
-  const bool real_pair = pl != lane;
-  const bool notconv = real_pair && g2 > kStopTol2W * ab;
-  const bool rot = real_pair && g2 > kRotTol2W * ab;
-  // tan(2 theta) = 2 ga / (b - a);  t = 2 ga sgn(d) / (|d| + sqrt(d^2 + 4 ga^2))
-  const double d = b - a;
-  const double x = fma(d, d, 4.0 * g2);
-  const double hh = x * fast_rsqrt1(x);
-  double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
-  tt = rot ? tt : 0.0;
-  const double w = fma(tt, tt, 1.0);
-  const double c = fast_rsqrt(w);                        // cos (exactly 1 when tt == 0)
-  // rotate and swap: this lane takes over the PARTNER's new column.  True columns g_p' = c (g_p - t g_q),
-  // g_q' = c (g_q + t g_p); in the partner's scaled storage that is  G' = H +/- t (is_own / is_partner) G.
-  const double tg = tt * ga;
-  al = lo ? b + tg : a - tg;
-  const double coef = (lo ? tt : -tt) * (is * scq);
-  is = isq * c;
-  sc = scq * (w * c);                                    // 1/cos = sqrt(1 + t^2)
-  if (__any(rot)) {
-#pragma unroll
-    for (int r = 0; r < KR; ++r) oth[r] = fma(coef, own[r], oth[r]);
-  }
-  return notconv;
-}
-
-// ---------------------------------------------------------------------------------------------
-// One-sided (Hestenes) Jacobi on register-resident columns.  Returns sweeps used.
-//
-// Pair ordering = odd-even transposition on the lane line: even steps pair lanes (0,1)(2,3)..., odd steps
-// (1,2)(3,4)...; after its rotation a pair SWAPS places (each lane simply computes the partner's new column
-// instead of its own).  After ncol steps every one of the column pairs has met exactly once, for any ncol,
-// and the only partners a lane ever has are its two neighbours -- so the column fetch is a DPP move on the VALU
-// (quad_perm[1,0,3,2], even steps) or a b128 round trip through LDS (odd steps) instead of ds_bpermute through
-// the LDS crossbar, which at 4 LDS cycles per dword-move and 4 SIMDs per CU was what bounded the XOR-tournament
-// version (measured 1.6 ms -> 0.84 ms per sweep on the C2-mini workload).
-//
-// The rotation itself is a "fast" scaled rotation G' = H + coef * G (KR FMAs): the cosine is not multiplied
-// into the column but accumulated in a per-column inverse scale `is`, and the squared norms alpha follow the
-// rotation identities alpha' = alpha -/+ t*gamma.  Both are refreshed once per sweep.
-// ---------------------------------------------------------------------------------------------
-template <int KR, int NW>
-__device__ __forceinline__ int jacobi_regs(double (&g)[KR], const int k, const int max_sweep, double* xbuf) {
-  const int ncol = (k + 1) & ~1;   // an odd k gets one zero column as an extra (inert) participant
-  double h[KR];
-  int sweep = 0;
-  double is = 1.0, sc = 1.0;       // true column = is * g ; sc = 1/is
-  for (; sweep < max_sweep; ++sweep) {
-    // refresh: fold the scale back, recompute the squared norm
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-    for (int r = 0; r < KR; r += 2) {
-      g[r] *= is;
-      g[r + 1] *= is;
-      a0 = fma(g[r], g[r], a0);
-      a1 = fma(g[r + 1], g[r + 1], a1);
-    }
-    double al = a0 + a1;
-    is = 1.0;
-    sc = 1.0;
-    bool notconv = false;
-    for (int t = 0; t < ncol; t += 2) {
-      notconv |= jacobi_step<KR, false, NW>(g, h, al, is, sc, ncol, xbuf);
-      notconv |= jacobi_step<KR, true, NW>(h, g, al, is, sc, ncol, xbuf);
-    }
-    if (!pany<NW>(notconv)) {
-      ++sweep;
-      break;
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < KR; ++r) g[r] *= is;
-  return sweep;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Row-split variant of the same iteration for one wave (k <= 62).  Same pair ordering, same fast scaled rotations,
-// same cached norms -- but a SLOT of two lanes (m, m + 32) owns the two columns at line positions (2m, 2m + 1),
+// Row-split layout: a SLOT of two lanes (m, m + 32) owns the two columns at line positions (2m, 2m + 1),
 // lane m their even rows, lane m + 32 their odd rows:
 //   even steps pair the two columns of a slot: no column moves at all, KR/2 FMAs for the inner product (the two
 //     halves meet through v_permlane32_swap) and KR FMAs for the two half-columns;
@@ -579,7 +403,7 @@ __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const dou
   const int lane = threadIdx.x & (64 * NW - 1);
 #pragma unroll
   for (int b = 0; b < NB; ++b) out[b] = 0.0;
-  const int ncol = (k + 1) & ~1;                 // columns live in lanes [0, ncol) (see jacobi_regs)
+  const int ncol = (k + 1) & ~1;                 // columns live in lanes [0, ncol) (see jacobi_split)
   for (int j0 = 0; j0 < ncol; j0 += kChunk) {
     psync<NW>();
     if (lane >= j0 && lane < j0 + kChunk) {
