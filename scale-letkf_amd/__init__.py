@@ -30,7 +30,7 @@ def build(force=False):
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:
-        subprocess.check_call(["make", "-C", HERE] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-j4", "-C", HERE] + (["-B"] if force else []))
     return LIB_PATH
 
 
