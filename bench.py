@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--lists", default="torch", choices=["torch", "search"],
                     help="where the local-obs lists come from: the torch workload builder, or letkf_obs_search_dev "
                          "(on-device obs_local; its time is reported separately as search_ms)")
+    ap.add_argument("--search-in-step", action="store_true",
+                    help="with --lists search: rebuild the local lists with the device search inside every timed step")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(affinity, cgroup quota, 16 = the box's CPU share)")
     args = ap.parse_args()
 
@@ -99,6 +101,9 @@ def main():
         ens = w["ensval"]
         if world > 1:
             ens, _ = sharding.allgatherv_rows(shard)
+        if args.lists == "search" and args.search_in_step:
+            # the whole das_letkf-equivalent call: obs_local for every point, then the batched loop body
+            w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"] = ctx.obs_search(t_s, *pts_s)
         ctx.das_points(k, nv, w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"], ens, w["kld"], w["dep"], infl,
                        w["gues"], anal, w["sp"], w["sm"], w["sv"], status=status, nsweep=nsweep, **relax)
 
@@ -173,6 +178,7 @@ def main():
                           "parallelism": f"grid-point shard x{n_gpus}" + (" + RCCL obs all-gather" if world > 1 else "")},
                "analysis_wall_s": elapsed / args.steps, "nonzero_status_points": bad,
                "jacobi_sweeps_mean": sweeps_mean, "lists": args.lists, "search_ms": search_ms,
+               "search_in_step": bool(args.lists == "search" and args.search_in_step),
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
