@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--relax", default="rtps", choices=["rtps", "rtpp", "none"])
-    ap.add_argument("--lists", default="torch", choices=["torch", "search"],
+    ap.add_argument("--lists", default="torch", choices=["torch", "search", "fused"],
                     help="where the local-obs lists come from: the torch workload builder, or letkf_obs_search_dev "
                          "(on-device obs_local; its time is reported separately as search_ms)")
     ap.add_argument("--search-in-step", action="store_true",
@@ -67,6 +67,11 @@ def main():
     ctx.ens_mean(k, nv, npts, w["gues"], w["sp"], w["sm"], w["sv"])
     ctx.to_perturbations(k, nv, npts, w["gues"], w["sp"], w["sm"], w["sv"])
     search_ms = None
+    if args.lists == "fused":
+        # obs_local fused into the loop body (letkf_das_points_fused_dev): no lists at all
+        t_s, keep_s, order_s, pts_s = bw.search_tables(w, pkg, dev)
+        w["ensval"] = w["ensval"][order_s].contiguous()
+        w["dep"] = w["dep"][order_s].contiguous()
     if args.lists == "search":
         # obs_local on the device: rebuild the lists with the search kernel on the mesh-sorted table
         t_s, keep_s, order_s, pts_s = bw.search_tables(w, pkg, dev)
@@ -104,8 +109,12 @@ def main():
         if args.lists == "search" and args.search_in_step:
             # the whole das_letkf-equivalent call: obs_local for every point, then the batched loop body
             w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"] = ctx.obs_search(t_s, *pts_s)
-        ctx.das_points(k, nv, w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"], ens, w["kld"], w["dep"], infl,
-                       w["gues"], anal, w["sp"], w["sm"], w["sv"], status=status, nsweep=nsweep, **relax)
+        if args.lists == "fused":
+            ctx.das_points(k, nv, None, None, None, None, ens, w["kld"], w["dep"], infl, w["gues"], anal, w["sp"],
+                           w["sm"], w["sv"], status=status, nsweep=nsweep, fused=(t_s, *pts_s), **relax)
+        else:
+            ctx.das_points(k, nv, w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"], ens, w["kld"], w["dep"], infl,
+                           w["gues"], anal, w["sp"], w["sm"], w["sv"], status=status, nsweep=nsweep, **relax)
 
     def barrier():
         if world > 1:

@@ -240,6 +240,18 @@ int letkf_obs_search_dev(letkf_ctx *ctx, const letkf_search_tables *tables, int6
                          const int64_t *obs_off, int32_t *obs_idx, double *rdiag_l, double *rloc_l);
 
 
+/* (3b) The loop body with obs_local FUSED IN: no local lists at all -- every wavefront walks the sorting mesh of
+ * `tables` for its own point (same candidate order as letkf_obs_search_dev, so the results are bit-identical to
+ * search + letkf_das_points_dev) and feeds the accepted rows straight into the Gram stage.  Saves the two search
+ * passes and the list traffic (C2: 14 GB written and read back per analysis; at C4 sizes the lists do not fit).
+ * Restrictions: no MAX_NOBS_PER_GRID limit on any ctype (no-limit mode, letkf_tools.f90:1438-1476), k <= 62 and
+ * nv = 11 (the one-wave kernel); otherwise LETKF_E_INVALID -- use (3) + (2).  args->obs_off / obs_idx / rdiag_l /
+ * rloc_l are ignored; ri, rj, rlev, rz as in (3); nobs_out (dev [npts] or NULL) receives nobsl of every point.
+ * Synchronises the stream once (it checks max_nobs). */
+int letkf_das_points_fused_dev(letkf_ctx *ctx, const letkf_das_args *args, const letkf_search_tables *tables,
+                               const double *ri, const double *rj, const double *rlev, const double *rz,
+                               int32_t *nobs_out);
+
 /*---------------------------------------------------------------------------
  * (4) The steps either side of the loop, all pure-bandwidth kernels:
  *     state_trans / state_trans_inv   scale/common/common_scale.f90:1181-1224 / :1229-1280

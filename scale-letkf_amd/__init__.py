@@ -121,7 +121,7 @@ def scale_rm_consts(clamp=True):
 
 EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", "letkf_ctx_destroy",
            "letkf_ctx_set_stream", "letkf_ctx_synchronize", "letkf_core_c", "letkf_core_batch_dev",
-           "letkf_das_points_dev", "letkf_obs_search_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
+           "letkf_das_points_dev", "letkf_das_points_fused_dev", "letkf_obs_search_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
            "letkf_state_trans_dev", "letkf_member_points_dev", "letkf_ens_spread_dev",
            "letkf_obs_departure_dev", "letkf_obs_mesh_sort_dev", "letkf_obs_halo_plan_dev",
            "letkf_obs_gather_rows_dev", "letkf_obs_gather_i32_dev", "letkf_monit_dep_dev",
@@ -209,14 +209,15 @@ class Context:
                    beta=None, det_run=False, infl_adaptive=False, relax_to_inflated_prior=False, relax_alpha=0.0,
                    relax_alpha_spread=0.0, q_update_top=0.0, q_sprd_max=0.0, iv_p=4, iv_q_first=5, iv_q_last=10,
                    trans_out=None, transm_out=None, pa_out=None, status=None, nsweep=None, rtps_infl_out=None,
-                   warm_run=0, var_mask=0):
+                   warm_run=0, var_mask=0, fused=None, nobs_out=None):
+        """fused = (tables, ri, rj, rlev, rz): obs_local fused into the kernel (obs_off .. rloc_l may be None)"""
         a = DasArgs()
         a.k, a.nv, a.det_run, a.infl_adaptive = k, nv, int(bool(det_run)), int(bool(infl_adaptive))
         a.relax_to_inflated_prior = int(bool(relax_to_inflated_prior))
         a.iv_p, a.iv_q_first, a.iv_q_last = iv_p, iv_q_first, iv_q_last
         a.relax_alpha, a.relax_alpha_spread = relax_alpha, relax_alpha_spread
         a.q_update_top, a.q_sprd_max = q_update_top, q_sprd_max
-        a.npts = obs_off.numel() - 1
+        a.npts = (obs_off.numel() - 1) if fused is None else fused[1].numel()
         a.obs_off, a.obs_idx, a.rdiag_l, a.rloc_l = _ptr(obs_off), _ptr(obs_idx), _ptr(rdiag_l), _ptr(rloc_l)
         a.ensval, a.kld, a.dep, a.beta, a.infl = _ptr(ensval), kld, _ptr(dep), _ptr(beta), _ptr(infl)
         a.gues, a.anal, a.sp, a.sm, a.sv = _ptr(gues), _ptr(anal), sp, sm, sv
@@ -225,7 +226,12 @@ class Context:
         a.rtps_infl_out = _ptr(rtps_infl_out)
         a.warm_run = int(warm_run)
         a.var_mask = int(var_mask)
-        self._check(self._l.letkf_das_points_dev(self._c, C.byref(a)))
+        if fused is None:
+            self._check(self._l.letkf_das_points_dev(self._c, C.byref(a)))
+        else:
+            t, ri, rj, rlev, rz = fused
+            self._check(self._l.letkf_das_points_fused_dev(self._c, C.byref(a), C.byref(t), _ptr(ri), _ptr(rj),
+                                                           _ptr(rlev), _ptr(rz), _ptr(nobs_out)))
 
     # ---- (3) obs_local on the device: two-phase CSR build (count, scan, fill)
     def obs_search(self, tables, ri, rj, rlev, rz):

@@ -160,6 +160,7 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
   // k <= 64: one wavefront per grid point, matrix in registers (letkf_wave.hip); otherwise one workgroup per
   // point with the matrix in LDS, or in the HBM workspace for large k (letkf_kernels.hip)
   static const bool force_block = std::getenv("LETKF_AMD_FORCE_BLOCK") != nullptr;
+  if (a.mode == 2 && force_block) return fail(LETKF_E_INVALID, "LETKF_AMD_FORCE_BLOCK: the workgroup kernel has no fused search");
   if (!force_block && letkf::wave_kernel_supports(a.k, a.nv, a.mode)) {
     int run_req = warm_run;
     if (const char* e = std::getenv("LETKF_AMD_RUN_LEN")) run_req = std::atoi(e);   // experiments: 1 = all cold
@@ -324,12 +325,17 @@ int letkf_core_batch_dev(letkf_ctx* c, const letkf_core_batch_args* g) {
   return launch(c, a, p);
 }
 
-int letkf_das_points_dev(letkf_ctx* c, const letkf_das_args* g) {
+namespace {
+
+// shared by the list-driven and the fused-search entry
+int das_points_impl(letkf_ctx* c, const letkf_das_args* g, const letkf_search_tables* t, const double* ri,
+                    const double* rj, const double* rlev, const double* rz, int32_t* nobs_out) {
   if (int rc = check_ctx(c)) return rc;
   if (!g) return fail(LETKF_E_INVALID, "args is NULL");
   if (g->npts == 0) return LETKF_OK;
   if (g->k < 2 || g->nv < 1 || g->npts < 0) return fail(LETKF_E_INVALID, "bad k/nv/npts");
-  if (!g->obs_off || !g->gues || !g->anal || !g->infl) return fail(LETKF_E_INVALID, "a required device pointer is NULL");
+  if ((!t && !g->obs_off) || !g->gues || !g->anal || !g->infl)
+    return fail(LETKF_E_INVALID, "a required device pointer is NULL");
   if (g->kld < g->k + (g->det_run ? 1 : 0)) return fail(LETKF_E_INVALID, "kld too small for k (+1 with det_run)");
   if (g->iv_p < 0 || g->iv_p >= g->nv) {
     if (g->q_update_top > 0.0) return fail(LETKF_E_INVALID, "iv_p out of range");
@@ -374,7 +380,42 @@ int letkf_das_points_dev(letkf_ctx* c, const letkf_das_args* g) {
   a.nsweep = g->nsweep;
   a.rtps_out = g->rtps_infl_out;
   a.var_mask = g->var_mask ? g->var_mask : ~0u;
+  if (t) {
+    if (!ri || !rj || !rlev || !rz) return fail(LETKF_E_INVALID, "a point coordinate array is NULL");
+    if (t->nctype < 1 || t->ngroup < 1) return fail(LETKF_E_INVALID, "bad nctype / ngroup");
+    if (!letkf::wave_kernel_supports(g->k, g->nv, 2))
+      return fail(LETKF_E_INVALID, "the fused search needs the one-wave kernel (k <= 62, nv = 11): build lists with "
+                                   "letkf_obs_search_dev and call letkf_das_points_dev instead");
+    // only the no-limit mode of obs_local is fused (letkf_tools.f90:1438-1476)
+    std::vector<int32_t> mx(t->nctype);
+    HIP_TRY(hipMemcpyAsync(mx.data(), t->max_nobs, sizeof(int32_t) * t->nctype, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int ic = 0; ic < t->nctype; ++ic)
+      if (mx[ic] > 0)
+        return fail(LETKF_E_INVALID, "MAX_NOBS_PER_GRID > 0: build lists with letkf_obs_search_dev (radix select) "
+                                     "and call letkf_das_points_dev");
+    if (g->trans_out || g->pa_out) return fail(LETKF_E_INVALID, "the fused search has no k x k outputs");
+    a.mode = 2;
+    a.stab = *t;
+    a.pri = ri;
+    a.prj = rj;
+    a.prlev = rlev;
+    a.prz = rz;
+    a.nobs_out = nobs_out;
+  }
   return launch(c, a, p, g->warm_run < 0 ? 0 : g->warm_run);
+}
+
+}  // namespace
+
+int letkf_das_points_dev(letkf_ctx* c, const letkf_das_args* g) {
+  return das_points_impl(c, g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+int letkf_das_points_fused_dev(letkf_ctx* c, const letkf_das_args* g, const letkf_search_tables* t, const double* ri,
+                               const double* rj, const double* rlev, const double* rz, int32_t* nobs_out) {
+  if (!t) return fail(LETKF_E_INVALID, "tables is NULL");
+  return das_points_impl(c, g, t, ri, rj, rlev, rz, nobs_out);
 }
 
 int letkf_ens_to_perturbations_dev(letkf_ctx* c, int32_t k, int32_t nv, int64_t npts, double* x, int64_t sp,

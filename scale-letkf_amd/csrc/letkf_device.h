@@ -10,7 +10,8 @@ namespace letkf {
 
 struct PointArgs {
   int k, nv;
-  int mode;            // 0: CSR gather from the obs table (das_letkf body); 1: dense hdxb batch (letkf_core)
+  int mode;            // 0: CSR gather from the obs table (das_letkf body); 1: dense hdxb batch (letkf_core);
+                       // 2: das_letkf body with obs_local fused in (no lists: the kernel walks the sorting mesh itself)
   int ldg, ldy, tn;    // leading dims of G / obs tile, obs rows per LDS tile
   long npts;
   // mode 0 observations
@@ -54,6 +55,10 @@ struct PointArgs {
   // large-k workspace
   double* ws;
   long ws_per_block;   // doubles
+  // mode 2: the search tables and the points' coordinates (rig1, rjg1, p mean, hgt1)
+  letkf_search_tables stab;
+  const double *pri, *prj, *prlev, *prz;
+  int* nobs_out;       // [npts] local observation count (mode 2), or null
   // wave kernel: launch shape and warm-start workspace (wave_launch_shape)
   double* warm_ws;
   int run_len, wave_grid, warm_dbg;

@@ -15,53 +15,13 @@
 
 #include "../../include/letkf_amd.h"
 #include "letkf_device.h"
+#include "letkf_search_dev.h"
 
 namespace letkf {
 
 namespace {
 
-constexpr double kDistZeroFac = (double)3.651483717f;          // letkf_obs.f90:27 (single-precision literal)
-constexpr double kDistZeroFacSq = (double)13.33333333f;        // :28
-constexpr double kTiny = 2.2250738585072014e-308;              // tiny(var_local)
-
-struct CalOut {
-  double rloc, rdiag, ndist;
-};
-
-// scale/letkf/letkf_tools.f90:1793-1906
-__device__ __forceinline__ CalOut local_cal(const letkf_search_tables& t, int ic, double ri, double rj, double rlev,
-                                            double rz, int row) {
-  CalOut o{0.0, -1.0, -1.0};
-  double nrloc = t.varloc[ic];                                 // :1840
-  if (nrloc < kTiny) return o;                                 // :1843
-  const double vloc = t.vert_loc[ic];
-  double nd_v;
-  const int vm = t.vmode[ic];
-  if (vloc == 0.0) nd_v = 0.0;                                 // :1851-1865
-  else if (vm == 2) nd_v = fabs(log(t.ob_dat[row]) - log(rlev)) / vloc;
-  else if (vm == 3) nd_v = fabs(log(t.rain_base) - log(rlev)) / vloc;
-  else if (vm == 1) nd_v = fabs(t.ob_lev[row] - rz) / vloc;
-  else nd_v = fabs(log(t.ob_lev[row]) - log(rlev)) / vloc;
-  if (nd_v > kDistZeroFac) return o;                           // :1869
-  const double rdx = (ri - t.ob_ri[row]) * t.dx;               // :1876-1878
-  const double rdy = (rj - t.ob_rj[row]) * t.dy;
-  const double nd_h = sqrt(rdx * rdx + rdy * rdy) / t.hori_loc[ic];
-  if (nd_h > kDistZeroFac) return o;                           // :1881
-  const double nd = nd_h * nd_h + nd_v * nd_v;                 // :1888
-  if (nd > kDistZeroFacSq) return o;                           // :1891
-  nrloc = nrloc * exp(-0.5 * nd);                              // :1899
-  const double err = t.ob_err[row];
-  o.rloc = nrloc;
-  o.rdiag = err * err / nrloc;                                 // :1903
-  o.ndist = nd;
-  return o;
-}
-
-__device__ __forceinline__ void ij_obsgrd_ext(const letkf_search_tables& t, int ic, double ri, double rj, int& ogi,
-                                              int& ogj) {       // letkf_obs.f90:1221-1224
-  ogi = (int)ceil((ri - t.i_org) * (double)t.ngrd_i[ic] / (double)t.nlon) + t.ngrdsch_i[ic];
-  ogj = (int)ceil((rj - t.j_org) * (double)t.ngrd_j[ic] / (double)t.nlat) + t.ngrdsch_j[ic];
-}
+using namespace search_dev;
 
 __device__ __forceinline__ unsigned long long key_bits(int criterion, const CalOut& c) {
   // monotone map key -> uint64 (all keys are positive doubles): smaller pattern == better candidate

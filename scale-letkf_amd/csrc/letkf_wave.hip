@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "letkf_device.h"
+#include "letkf_search_dev.h"
 
 namespace letkf {
 
@@ -563,7 +564,9 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
 
 // KKOUT: also materialise T / Pa (fine boundary, parity, diagnostics) -- a separate instantiation so that the
 // production kernel carries neither the code nor the registers for it.
-template <int KR, int NV, bool KKOUT, int NW>
+// FUSED: obs_local walked inside the kernel (mode 2) -- its own instantiation as well: carried by the list-driven kernel
+// the extra code cost 15 % of its speed (registers / instruction cache), measured.
+template <int KR, int NV, bool KKOUT, int NW, bool FUSED>
 __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wave_kernel(const PointArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NB = NV + 2;
@@ -612,9 +615,13 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     long o0 = 0;
     int n = 0;
     double beta = 1.0;
+    const bool das = A.mode != 1;              // the das_letkf loop body (lists given: 0, search fused in: 2)
     if (A.mode == 0) {
       o0 = A.obs_off[pt];
       n = (int)(A.obs_off[pt + 1] - o0);
+      if (A.beta) beta = A.beta[pt];
+    } else if (FUSED && A.mode == 2) {
+      n = -1;                                  // known after the kernel's own walk over the sorting mesh
       if (A.beta) beta = A.beta[pt];
     } else {
       n = A.nobsl[pt];
@@ -625,7 +632,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     const double* g0 = A.gues ? A.gues + pt * A.sp : nullptr;
     double* a0 = A.anal ? A.anal + pt * A.sp : nullptr;
 
-    if (A.mode == 0 && beta == 0.0) {          // letkf_tools.f90:333-359
+    if (das && beta == 0.0) {                  // letkf_tools.f90:333-359
       for (int v = 0; v < nv; ++v) {
         if (lane < k && ((A.var_mask >> v) & 1u)) a0[moff + v * A.sv] = g0[k * A.sm + v * A.sv] + g0[moff + v * A.sv];
       }
@@ -635,16 +642,17 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       if (lane == 0) {
         if (A.status) A.status[pt] = 0;
         if (A.nsweep) A.nsweep[pt] = 0;
+        if (A.nobs_out) A.nobs_out[pt] = 0;
       }
       continue;
     }
 
     bool qskip = false;
-    if (A.mode == 0 && A.q_update_top > 0.0) qskip = g0[k * A.sm + A.iv_p * A.sv] < A.q_update_top;
+    if (das && A.q_update_top > 0.0) qskip = g0[k * A.sm + A.iv_p * A.sv] < A.q_update_top;
     // first variable of this variable-localisation class that is actually updated: its inflation slot drives the solve
     int v0 = 0;
     while (v0 < nv && (!((A.var_mask >> v0) & 1u) || (qskip && v0 >= A.iv_q_first && v0 <= A.iv_q_last))) ++v0;
-    double* infl_p = (A.mode == 0) ? ((v0 < nv) ? &A.infl[pt + A.npts * (long)v0] : nullptr) : &A.infl[pt];
+    double* infl_p = das ? ((v0 < nv) ? &A.infl[pt + A.npts * (long)v0] : nullptr) : &A.infl[pt];
     const double infl_old = infl_p ? *infl_p : 1.0;
 
     // ------------------------------------------------------------ Gram on the FP64 matrix cores
@@ -660,7 +668,8 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     double lam = km1 / infl_old;               // n == 0: T = sqrt(rho) I, Pa = rho/(k-1) I (common_letkf.f90:89-107)
     bool colvalid = lane < k;                  // does this lane hold an eigen-column?
 
-    if (n > 0) {
+    bool solved = false;
+    if (n != 0) {
       constexpr int NBLK = (KR + 2 + 15) / 16;                 // member blocks incl. the 2 augmented columns
       constexpr int NTILE = NBLK * (NBLK + 1) / 2;
       v4d acc[NTILE];
@@ -676,7 +685,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       //   MFMA : per 4-obs step 2 ds_read_b128 + NBLK row loads (three steps in flight) + NBLK multiplies
       constexpr int kSC = 256;                                 // obs per batch (4 kSC doubles <= 1536 NW of the slice)
       double* stg = slice;
-      const bool mode0 = A.mode == 0;
+      const bool mode0 = A.mode != 1;                          // rows come from the obs table (member-fastest)
       const double* ybase = mode0 ? A.ensval : A.hdxb;
       bool rowok[NBLK];
       long mo[NBLK];
@@ -694,6 +703,199 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         double sw, dsw, ddsw;
       };
 
+      // MFMA steps of 4 obs over the first nsp (multiple of 4) staged entries; with two waves each takes every other step
+      auto run_steps = [&](const int nsp) {
+        const int nch = nsp >> 2;
+        auto fetch = [&](const int c, Step& t) {
+          const bool ok = c < nch;
+          const int i = 4 * (ok ? c : 0) + q;
+          const double2 a2 = *reinterpret_cast<const double2*>(&stg[4 * i]);
+          const double2 b2 = *reinterpret_cast<const double2*>(&stg[4 * i + 2]);
+          const long rb = __double_as_longlong(a2.x);
+          t.sw = ok ? a2.y : 0.0;
+          t.dsw = ok ? b2.x : 0.0;
+          t.ddsw = ok ? b2.y : 0.0;
+#pragma unroll
+          for (int I = 0; I < NBLK; ++I) t.f[I] = ybase[rb + mo[I]];
+        };
+        auto mma = [&](const Step& t) {
+          double y[NBLK];
+#pragma unroll
+          for (int I = 0; I < NBLK; ++I) {
+            double v = t.f[I] * t.sw;
+            if (16 * (I + 1) > k) {                            // wave-uniform: block reaches past the members
+              v = rowok[I] ? v : 0.0;
+              if (I == blk_d && is_d) v = t.dsw;
+              if (I == blk_dd && is_dd) v = t.ddsw;
+            }
+            y[I] = v;
+          }
+          int tt = 0;
+#pragma unroll
+          for (int I = 0; I < NBLK; ++I)
+#pragma unroll
+            for (int J = I; J < NBLK; ++J) {
+              acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[I], y[J], acc[tt], 0, 0, 0);
+              ++tt;
+            }
+        };
+        Step t0, t1, t2;
+        fetch(wvp, t0);
+        fetch(wvp + NW, t1);
+        fetch(wvp + 2 * NW, t2);
+        for (int c = wvp; c < nch; c += 3 * NW) {
+          mma(t0);
+          fetch(c + 3 * NW, t0);
+          if (c + NW < nch) {
+            mma(t1);
+            fetch(c + 4 * NW, t1);
+          }
+          if (c + 2 * NW < nch) {
+            mma(t2);
+            fetch(c + 5 * NW, t2);
+          }
+        }
+      };
+
+      if (FUSED && A.mode == 2) {
+        // ---- obs_local fused in (no-limit mode, scale/letkf/letkf_tools.f90:1438-1476): walk the rectangle of
+        // sorting-mesh cells of every observation type exactly like letkf_search_kernel, evaluate obs_local_cal per
+        // lane for 64 candidate rows at a time, and append the accepted ones (ballot + prefix popcount: the
+        // reference's list order) straight to the staging buffer -- the local list never exists in memory.
+        if constexpr (NW == 1 && FUSED) {
+          using namespace search_dev;
+          const letkf_search_tables& t = A.stab;
+          const double ri = A.pri[pt], rj = A.prj[pt], rlev = A.prlev[pt], rz = A.prz[pt];
+          const unsigned long long lt_mask = (wlane == 0) ? 0ull : (~0ull >> (64 - wlane));
+          int cnt = 0, ntot = 0, nconv = 0;                   // staged entries / accepted so far / entries at the front
+                                                              // that are already in final form (wave-uniform)
+          // stage buffer, phase A: (row, rdiag, rloc) as the candidates are accepted; phase B (convert): lane = entry,
+          // all dep / dep_det gathers of the batch in flight together -> (row base, sqrt(w), sqrt(w) dep, sqrt(w) dep_det)
+          auto convert = [&]() {
+            for (int i = nconv + wlane; i < cnt; i += 64) {
+              const double2 a2 = *reinterpret_cast<const double2*>(&stg[4 * i]);
+              const double rloc_ = stg[4 * i + 2];
+              const long row = __double_as_longlong(a2.x);
+              const long rb = row * A.kld;
+              const double d = A.dep[row];
+              const double dd = A.det_run ? A.ensval[rb + k] : 0.0;
+              const double sw = fast_rsqrt(a2.y);
+              p3 += rloc_;
+              *reinterpret_cast<double2*>(&stg[4 * i]) = double2{__longlong_as_double(rb), sw};
+              *reinterpret_cast<double2*>(&stg[4 * i + 2]) = double2{d * sw, dd * sw};
+            }
+          };
+          struct Meta {
+            double lev, dat, ori, orj, err;
+          };
+          psync<NW>();
+          for (int m = 0; m < t.group_start[t.ngroup]; ++m) {
+            const int ic = t.group_member[m];
+            const int vm = t.vmode[ic];
+            const double dzi = t.hori_loc[ic] * kDistZeroFac / t.dx;        // obs_local_range :1775-1778
+            const double dzj = t.hori_loc[ic] * kDistZeroFac / t.dy;
+            int imin, imax, jmin, jmax;
+            ij_obsgrd_ext(t, ic, ri - dzi, rj - dzj, imin, jmin);
+            ij_obsgrd_ext(t, ic, ri + dzi, rj + dzj, imax, jmax);
+            imin = max(imin, 1);
+            jmin = max(jmin, 1);
+            imax = min(imax, t.ngrdext_i[ic]);
+            jmax = min(jmax, t.ngrdext_j[ic]);
+            if (imin > imax || jmin > jmax) continue;
+            const long acb = t.ac_off[ic];
+            const int ld = t.ngrdext_i[ic] + 1;
+            // metadata of the candidate rows [base, base + 64): loaded one chunk AHEAD of its evaluation (the first
+            // version loaded and evaluated chunk by chunk and waited three dependent memory round trips per chunk --
+            // 165 ms per C2 analysis against 59 ms for the stand-alone search kernel)
+            auto load_meta = [&](const int base, const int hi) -> Meta {
+              Meta q_{1.0, 1.0, 0.0, 0.0, 1.0};
+              const int row = base + wlane;
+              if (row < hi) {
+                if (vm != 2 && vm != 3) q_.lev = t.ob_lev[row];
+                if (vm == 2) q_.dat = t.ob_dat[row];
+                q_.ori = t.ob_ri[row];
+                q_.orj = t.ob_rj[row];
+                q_.err = t.ob_err[row];
+              }
+              return q_;
+            };
+            for (int j0 = jmin; j0 <= jmax; j0 += 64) {                      // 64 mesh rows at a time: lane = row
+              const int nr = min(64, jmax - j0 + 1);
+              int lo_l = 0, hi_l = 0;
+              if (wlane < nr) {
+                lo_l = t.ac_ext[acb + (imin - 1) + (long)ld * (j0 + wlane - 1)];
+                hi_l = t.ac_ext[acb + imax + (long)ld * (j0 + wlane - 1)];
+              }
+              int r = 0;
+              int base = __shfl(lo_l, 0, 64), hi = __shfl(hi_l, 0, 64);
+              auto skip_empty = [&]() {
+                while (r < nr && base >= hi) {
+                  ++r;
+                  if (r < nr) {
+                    base = __shfl(lo_l, r, 64);
+                    hi = __shfl(hi_l, r, 64);
+                  }
+                }
+              };
+              skip_empty();
+              Meta cur{1.0, 1.0, 0.0, 0.0, 1.0};
+              if (r < nr) cur = load_meta(base, hi);
+              while (r < nr) {
+                const int cb = base, chi = hi;
+                base += 64;
+                skip_empty();
+                Meta nxt{1.0, 1.0, 0.0, 0.0, 1.0};
+                if (r < nr) nxt = load_meta(base, hi);
+                const int row = cb + wlane;
+                CalOut c{0.0, -1.0, -1.0};
+                if (row < chi) c = local_cal_v(t, ic, ri, rj, rlev, rz, cur.lev, cur.dat, cur.ori, cur.orj, cur.err);
+                const bool acc_ = c.rloc != 0.0;                             // :1460
+                const unsigned long long mk = __ballot(acc_);
+                if (acc_) {
+                  const int i = cnt + __popcll(mk & lt_mask);
+                  *reinterpret_cast<double2*>(&stg[4 * i]) = double2{__longlong_as_double((long)row), c.rdiag};
+                  stg[4 * i + 2] = c.rloc;
+                }
+                const int na = __popcll(mk);
+                cnt += na;
+                ntot += na;
+                if (cnt > kSC - 64) {                                        // room for one more chunk is gone
+                  const int nuse = cnt & ~3;
+                  psync<NW>();
+                  convert();
+                  psync<NW>();
+                  run_steps(nuse);
+                  psync<NW>();
+                  // the 0..3 left-over entries (already converted) move to the front
+                  double2 l0{0.0, 0.0}, l1{0.0, 0.0};
+                  if (wlane < cnt - nuse) {
+                    l0 = *reinterpret_cast<const double2*>(&stg[4 * (nuse + wlane)]);
+                    l1 = *reinterpret_cast<const double2*>(&stg[4 * (nuse + wlane) + 2]);
+                  }
+                  psync<NW>();
+                  if (wlane < cnt - nuse) {
+                    *reinterpret_cast<double2*>(&stg[4 * wlane]) = l0;
+                    *reinterpret_cast<double2*>(&stg[4 * wlane + 2]) = l1;
+                  }
+                  cnt -= nuse;
+                  nconv = cnt;
+                }
+                cur = nxt;
+              }
+            }
+          }
+          psync<NW>();
+          convert();
+          const int nsp = (cnt + 3) & ~3;
+          if (wlane < nsp - cnt) {                                           // pad the last step with weight-0 rows
+            *reinterpret_cast<double2*>(&stg[4 * (cnt + wlane)]) = double2{0.0, 0.0};
+            *reinterpret_cast<double2*>(&stg[4 * (cnt + wlane) + 2]) = double2{0.0, 0.0};
+          }
+          psync<NW>();
+          if (nsp > 0) run_steps(nsp);                                       // (an empty buffer has no valid row to prefetch)
+          n = ntot;
+        }
+      } else
       for (int s0 = 0; s0 < n; s0 += kSC) {
         const int ns = min(kSC, n - s0);
         const int nsp = (ns + 3) & ~3;
@@ -753,59 +955,10 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
           }
         }
         psync<NW>();
-        // ---- MFMA steps of 4 obs; with two waves each takes every other step
-        const int nch = nsp >> 2;
-        auto fetch = [&](const int c, Step& t) {
-          const bool ok = c < nch;
-          const int i = 4 * (ok ? c : 0) + q;
-          const double2 a2 = *reinterpret_cast<const double2*>(&stg[4 * i]);
-          const double2 b2 = *reinterpret_cast<const double2*>(&stg[4 * i + 2]);
-          const long rb = __double_as_longlong(a2.x);
-          t.sw = ok ? a2.y : 0.0;
-          t.dsw = ok ? b2.x : 0.0;
-          t.ddsw = ok ? b2.y : 0.0;
-#pragma unroll
-          for (int I = 0; I < NBLK; ++I) t.f[I] = ybase[rb + mo[I]];
-        };
-        auto mma = [&](const Step& t) {
-          double y[NBLK];
-#pragma unroll
-          for (int I = 0; I < NBLK; ++I) {
-            double v = t.f[I] * t.sw;
-            if (16 * (I + 1) > k) {                            // wave-uniform: block reaches past the members
-              v = rowok[I] ? v : 0.0;
-              if (I == blk_d && is_d) v = t.dsw;
-              if (I == blk_dd && is_dd) v = t.ddsw;
-            }
-            y[I] = v;
-          }
-          int tt = 0;
-#pragma unroll
-          for (int I = 0; I < NBLK; ++I)
-#pragma unroll
-            for (int J = I; J < NBLK; ++J) {
-              acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[I], y[J], acc[tt], 0, 0, 0);
-              ++tt;
-            }
-        };
-        Step t0, t1, t2;
-        fetch(wvp, t0);
-        fetch(wvp + NW, t1);
-        fetch(wvp + 2 * NW, t2);
-        for (int c = wvp; c < nch; c += 3 * NW) {
-          mma(t0);
-          fetch(c + 3 * NW, t0);
-          if (c + NW < nch) {
-            mma(t1);
-            fetch(c + 4 * NW, t1);
-          }
-          if (c + 2 * NW < nch) {
-            mma(t2);
-            fetch(c + 5 * NW, t2);
-          }
-        }
+        run_steps(nsp);
       }
-
+      if (n > 0) {
+      solved = true;
       // accumulator tiles -> "lane j owns column j": 16 rows at a time through LDS.  C/D layout of the f64 MFMA:
       // lane l holds rows (l>>4) + 4*reg, column l&15 of its 16x16 tile.
       constexpr int LDA = 18;
@@ -894,7 +1047,9 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         const double gain = 0.04 * 0.04 / (sigma_o + 0.04 * 0.04);
         p1 = infl_old + gain * parm4;            // reuse p1 as infl_new
       }
-    } else {
+      }
+    }
+    if (!solved) {
 #pragma unroll
       for (int r = 0; r < KR; ++r) g[r] = (r == lane && lane < k) ? 1.0 : 0.0;
     }
@@ -997,7 +1152,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     rows_times_c<KR, NB, NW>(g, crow, out, k, vbuf, cbuf);   // lane m: out[0] = w-bar_m, out[1] = w-bar_det_m, out[2+v] = (T x'_v)_m
 
     // ------------------------------------------------------------ analysis members (letkf_tools.f90:472-513)
-    if (NV > 0 && A.mode == 0) {
+    if (NV > 0 && das) {
       double* ap = a0 + moff;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
@@ -1094,21 +1249,22 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     if (lane == 0) {
       if (A.status) A.status[pt] = st;
       if (A.nsweep) A.nsweep[pt] = sweeps;
+      if (A.nobs_out) A.nobs_out[pt] = n;
     }
    }
   }
 }
 
 // ------------------------------------------------------------------ host launcher
-template <int KR, int NV, bool KKOUT, int NW>
+template <int KR, int NV, bool KKOUT, int NW, bool FUSED = false>
 static hipError_t launch_wave(const PointArgs& a, int num_cu, hipStream_t st) {
   const size_t lds = (size_t)(NW == 1 ? 4 : 1) * wave_slice_doubles(KR, NV, NW) * sizeof(double);
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_wave_kernel<KR, NV, KKOUT, NW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_wave_kernel<KR, NV, KKOUT, NW, FUSED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((letkf_wave_kernel<KR, NV, KKOUT, NW>), dim3(a.wave_grid), dim3(NW == 1 ? 256 : 128), lds, st, a);
+  hipLaunchKernelGGL((letkf_wave_kernel<KR, NV, KKOUT, NW, FUSED>), dim3(a.wave_grid), dim3(NW == 1 ? 256 : 128), lds, st, a);
   (void)num_cu;
   return hipGetLastError();
 }
@@ -1118,6 +1274,7 @@ bool wave_kernel_supports(int k, int nv, int mode) {
   // columns no longer fit the 256 VALU-addressable VGPRs twice and part of them lives in AGPRs (measured: 170 k
   // solves/s at k = 100 against 79 k for the workgroup kernel; at k = 63, 64 the workgroup kernel is still ahead)
   if (k > 100 || k == 63 || k == 64) return false;
+  if (mode == 2) return nv == 11 && k <= 62;   // the fused search is written for one wave per point
   if (mode == 0) return nv == 11;
   return nv == 0;
 }
@@ -1133,7 +1290,7 @@ void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, int*
   const bool one_wave = k <= 62;
   const long ppw = one_wave ? 4 : 1;           // points in flight per workgroup
   int R = 1;
-  if (mode == 0) {
+  if (mode != 1) {
     if (run_req > 0) R = run_req;
     else {
       // runs of 16 (first point of a run is a cold start), shortened until there are >= 4 workgroups per CU
@@ -1157,7 +1314,10 @@ hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st) {
   const bool kkout = a.trans_out || a.pa_out;
 #define LETKF_WAVE_CASE(KR, NW)                                                                                 \
   if (k <= (NW == 1 ? (KR < 62 ? KR : 62) : KR)) {                                                              \
-    if (a.mode == 0)                                                                                            \
+    if constexpr (NW == 1) {                                                                                    \
+      if (a.mode == 2) return launch_wave<KR, 11, false, NW, true>(a, num_cu, st);                              \
+    }                                                                                                           \
+    if (a.mode != 1)                                                                                            \
       return kkout ? launch_wave<KR, 11, true, NW>(a, num_cu, st) : launch_wave<KR, 11, false, NW>(a, num_cu, st); \
     return launch_wave<KR, 0, true, NW>(a, num_cu, st);                                                         \
   }
