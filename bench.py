@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--relax", default="rtps", choices=["rtps", "rtpp", "none"])
-    ap.add_argument("--lists", default="torch", choices=["torch", "search", "fused"],
+    ap.add_argument("--lists", default="torch", choices=["torch", "search", "columns", "fused"],
                     help="where the local-obs lists come from: the torch workload builder, or letkf_obs_search_dev "
                          "(on-device obs_local; its time is reported separately as search_ms)")
     ap.add_argument("--search-in-step", action="store_true",
@@ -72,16 +72,24 @@ def main():
         t_s, keep_s, order_s, pts_s = bw.search_tables(w, pkg, dev)
         w["ensval"] = w["ensval"][order_s].contiguous()
         w["dep"] = w["dep"][order_s].contiguous()
-    if args.lists == "search":
+    if args.lists in ("search", "columns"):
         # obs_local on the device: rebuild the lists with the search kernel on the mesh-sorted table
         t_s, keep_s, order_s, pts_s = bw.search_tables(w, pkg, dev)
         n_torch = int(w["obs_off"][-1].item())
         w["ensval"] = w["ensval"][order_s].contiguous()
         w["dep"] = w["dep"][order_s].contiguous()
+        nij_s = w["cfg"]["nx"] * w["cfg"]["ny"]
+
+        def do_search():
+            if args.lists == "columns":   # one wave per horizontal point, all levels (letkf_obs_search_columns_dev)
+                return ctx.obs_search_columns(t_s, nij_s, w["cfg"]["nz"], pts_s[0][:nij_s].contiguous(),
+                                              pts_s[1][:nij_s].contiguous(), pts_s[2], pts_s[3])
+            return ctx.obs_search(t_s, *pts_s)
+
         for rep in range(2):
             torch.cuda.synchronize()
             t0s = time.perf_counter()
-            off_s, idx_s, rd_s, rl_s = ctx.obs_search(t_s, *pts_s)
+            off_s, idx_s, rd_s, rl_s = do_search()
             torch.cuda.synchronize()
             search_ms = (time.perf_counter() - t0s) * 1e3
         assert int(off_s[-1].item()) == n_torch, "device search and torch builder disagree on the list sizes"
@@ -106,9 +114,9 @@ def main():
         ens = w["ensval"]
         if world > 1:
             ens, _ = sharding.allgatherv_rows(shard)
-        if args.lists == "search" and args.search_in_step:
+        if args.lists in ("search", "columns") and args.search_in_step:
             # the whole das_letkf-equivalent call: obs_local for every point, then the batched loop body
-            w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"] = ctx.obs_search(t_s, *pts_s)
+            w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"] = do_search()
         if args.lists == "fused":
             ctx.das_points(k, nv, None, None, None, None, ens, w["kld"], w["dep"], infl, w["gues"], anal, w["sp"],
                            w["sm"], w["sv"], status=status, nsweep=nsweep, fused=(t_s, *pts_s), **relax)
@@ -187,7 +195,7 @@ def main():
                           "parallelism": f"grid-point shard x{n_gpus}" + (" + RCCL obs all-gather" if world > 1 else "")},
                "analysis_wall_s": elapsed / args.steps, "nonzero_status_points": bad,
                "jacobi_sweeps_mean": sweeps_mean, "lists": args.lists, "search_ms": search_ms,
-               "search_in_step": bool(args.lists == "search" and args.search_in_step),
+               "search_in_step": bool(args.lists in ("search", "columns") and args.search_in_step),
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:

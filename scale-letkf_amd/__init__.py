@@ -121,7 +121,7 @@ def scale_rm_consts(clamp=True):
 
 EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", "letkf_ctx_destroy",
            "letkf_ctx_set_stream", "letkf_ctx_synchronize", "letkf_core_c", "letkf_core_batch_dev",
-           "letkf_das_points_dev", "letkf_das_points_fused_dev", "letkf_obs_search_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
+           "letkf_das_points_dev", "letkf_das_points_fused_dev", "letkf_obs_search_dev", "letkf_obs_search_columns_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
            "letkf_state_trans_dev", "letkf_member_points_dev", "letkf_ens_spread_dev",
            "letkf_obs_departure_dev", "letkf_obs_mesh_sort_dev", "letkf_obs_halo_plan_dev",
            "letkf_obs_gather_rows_dev", "letkf_obs_gather_i32_dev", "letkf_monit_dep_dev",
@@ -251,6 +251,24 @@ class Context:
         self._check(self._l.letkf_obs_search_dev(self._c, C.byref(tables), C.c_int64(npts), _ptr(ri), _ptr(rj),
                                                  _ptr(rlev), _ptr(rz), C.c_int32(1), None, _ptr(obs_off),
                                                  _ptr(obs_idx), _ptr(rdiag), _ptr(rloc)))
+        return obs_off, obs_idx[:nnz], rdiag[:nnz], rloc[:nnz]
+
+    def obs_search_columns(self, tables, nij1, nlev, rig, rjg, rlev, rz):
+        """Column-cooperative obs_local for points p = ij + nij1*lev; same return as obs_search."""
+        import torch
+        npts = nij1 * nlev
+        counts = torch.zeros(npts, dtype=torch.int32, device=rig.device)
+        f = self._l.letkf_obs_search_columns_dev
+        self._check(f(self._c, C.byref(tables), C.c_int64(nij1), C.c_int32(nlev), _ptr(rig), _ptr(rjg), _ptr(rlev),
+                      _ptr(rz), C.c_int32(0), _ptr(counts), None, None, None, None))
+        obs_off = torch.zeros(npts + 1, dtype=torch.int64, device=rig.device)
+        obs_off[1:] = torch.cumsum(counts.to(torch.int64), 0)
+        nnz = int(obs_off[-1].item())
+        obs_idx = torch.empty(max(nnz, 1), dtype=torch.int32, device=rig.device)
+        rdiag = torch.empty(max(nnz, 1), dtype=torch.float64, device=rig.device)
+        rloc = torch.empty(max(nnz, 1), dtype=torch.float64, device=rig.device)
+        self._check(f(self._c, C.byref(tables), C.c_int64(nij1), C.c_int32(nlev), _ptr(rig), _ptr(rjg), _ptr(rlev),
+                      _ptr(rz), C.c_int32(1), None, _ptr(obs_off), _ptr(obs_idx), _ptr(rdiag), _ptr(rloc)))
         return obs_off, obs_idx[:nnz], rdiag[:nnz], rloc[:nnz]
 
     # ---- (5) set_letkf_obs on the device

@@ -180,6 +180,186 @@ __global__ void __launch_bounds__(256) letkf_search_kernel(const SearchArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Column-cooperative search (no-limit mode): one wavefront per horizontal point ij does ALL its levels.
+// The horizontal part of obs_local_cal (two subtractions, a square root, a division, the cut-off test) depends only
+// on (ij, observation), so it is evaluated once per column and observation instead of once per level (60 times at
+// C2); the survivors wait in LDS with everything the vertical part needs (row, nd_h, the vertical coordinate already
+// through its log where the type calls for one, the error) and every level then runs only
+//   nd_v = |v_obs - v_point| / vert_loc,  nd = nd_h^2 + nd_v^2,  rloc = varloc exp(-nd/2),  rdiag = err^2 / rloc
+// over them.  Same expressions in the same order as local_cal_v (compiled without fusion), same candidate order, so
+// the lists are identical to the per-point kernel's, entry for entry.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSurv = 512;                  // survivors buffered per wave (32 B each)
+
+struct ColArgs {
+  letkf_search_tables t;
+  long nij1;
+  int nlev;
+  const double* rig;
+  const double* rjg;
+  const double* rlev;    // [nij1 * nlev], point p = ij + nij1 * lev
+  const double* rz;
+  int fill;
+  int* counts;
+  const long* obs_off;
+  int* obs_idx;
+  double* rdiag_l;
+  double* rloc_l;
+};
+
+__global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs A) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) double smem_col[];
+  const letkf_search_tables& t = A.t;
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int nlev = A.nlev;
+  const int cstride = 4 * kSurv + ((nlev + 1) & ~1);             // doubles per wave: survivors + level counters
+  double* sb = smem_col + (size_t)wv * cstride;                  // [kSurv][4]: row bits, nd_h, v_obs, err
+  int* cntl = reinterpret_cast<int*>(sb + 4 * kSurv);            // [nlev] entries emitted so far per level
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  for (long col = (long)blockIdx.x * 4 + wv; col < A.nij1; col += (long)gridDim.x * 4) {
+    const double ri = A.rig[col], rj = A.rjg[col];
+    for (int l = lane; l < nlev; l += 64) cntl[l] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    for (int m = 0; m < t.group_start[t.ngroup]; ++m) {
+      const int ic = t.group_member[m];
+      const double varloc = t.varloc[ic];
+      if (varloc < kTiny) continue;                               // local_cal :1843
+      const int vm = t.vmode[ic];
+      const double vloc = t.vert_loc[ic], hloc = t.hori_loc[ic];
+      const double dzi = hloc * kDistZeroFac / t.dx, dzj = hloc * kDistZeroFac / t.dy;
+      int imin, imax, jmin, jmax;
+      ij_obsgrd_ext(t, ic, ri - dzi, rj - dzj, imin, jmin);
+      ij_obsgrd_ext(t, ic, ri + dzi, rj + dzj, imax, jmax);
+      imin = max(imin, 1);
+      jmin = max(jmin, 1);
+      imax = min(imax, t.ngrdext_i[ic]);
+      jmax = min(jmax, t.ngrdext_j[ic]);
+      if (imin > imax || jmin > jmax) continue;
+      const long acb = t.ac_off[ic];
+      const int ld = t.ngrdext_i[ic] + 1;
+      int ns = 0;                                                 // survivors in the buffer
+
+      // every level against the buffered survivors, then the buffer is empty again
+      auto vertical = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int lev = 0; lev < nlev; ++lev) {
+          const long p = col + A.nij1 * (long)lev;
+          double vref = 0.0;
+          if (vloc != 0.0) {
+            if (vm == 1) vref = A.rz[p];
+            else vref = log(A.rlev[p]);
+          }
+          const double vconst = (vm == 3 && vloc != 0.0) ? fabs(log(t.rain_base) - vref) / vloc : 0.0;
+          int emitted = cntl[lev];
+          const long out = A.fill ? A.obs_off[p] : 0;
+          for (int s0 = 0; s0 < ns; s0 += 64) {
+            const int si = s0 + lane;
+            bool acc = false;
+            double rloc = 0.0, rdiag = 0.0;
+            int row = 0;
+            if (si < ns) {
+              const double2 a2 = *reinterpret_cast<const double2*>(&sb[4 * si]);
+              const double2 b2 = *reinterpret_cast<const double2*>(&sb[4 * si + 2]);
+              row = (int)__double_as_longlong(a2.x);
+              const double nd_h = a2.y;
+              double nd_v;
+              if (vloc == 0.0) nd_v = 0.0;                        // :1851-1865
+              else if (vm == 3) nd_v = vconst;
+              else nd_v = fabs(b2.x - vref) / vloc;
+              if (!(nd_v > kDistZeroFac)) {                       // :1869
+                const double nd = nd_h * nd_h + nd_v * nd_v;      // :1888
+                if (!(nd > kDistZeroFacSq)) {                     // :1891
+                  rloc = varloc * exp(-0.5 * nd);                 // :1899
+                  rdiag = b2.y * b2.y / rloc;                     // :1903
+                  acc = rloc != 0.0;                              // letkf_tools.f90:1460
+                }
+              }
+            }
+            const unsigned long long mk = __ballot(acc);
+            if (A.fill && acc) {
+              const long o = out + emitted + __popcll(mk & lt_mask);
+              A.obs_idx[o] = row;
+              A.rdiag_l[o] = rdiag;
+              A.rloc_l[o] = rloc;
+            }
+            emitted += __popcll(mk);
+          }
+          if (lane == 0) cntl[lev] = emitted;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ns = 0;
+      };
+
+      for (int j = jmin; j <= jmax; ++j) {
+        const int lo = t.ac_ext[acb + (imin - 1) + (long)ld * (j - 1)];
+        const int hi = t.ac_ext[acb + imax + (long)ld * (j - 1)];
+        for (int base = lo; base < hi; base += 64) {
+          const int row = base + lane;
+          bool ok = false;
+          double nd_h = 0.0, vobs = 0.0, err = 0.0;
+          if (row < hi) {
+            const double rdx = (ri - t.ob_ri[row]) * t.dx;        // :1876-1878
+            const double rdy = (rj - t.ob_rj[row]) * t.dy;
+            nd_h = sqrt(rdx * rdx + rdy * rdy) / hloc;
+            ok = !(nd_h > kDistZeroFac);                          // :1881
+            if (ok) {
+              if (vloc != 0.0) {
+                if (vm == 1) vobs = t.ob_lev[row];
+                else if (vm == 2) vobs = log(t.ob_dat[row]);
+                else if (vm != 3) vobs = log(t.ob_lev[row]);
+              }
+              err = t.ob_err[row];
+            }
+          }
+          const unsigned long long mk = __ballot(ok);
+          if (ok) {
+            const int si = ns + __popcll(mk & lt_mask);
+            *reinterpret_cast<double2*>(&sb[4 * si]) = double2{__longlong_as_double((long)row), nd_h};
+            *reinterpret_cast<double2*>(&sb[4 * si + 2]) = double2{vobs, err};
+          }
+          ns += __popcll(mk);
+          if (ns > kSurv - 64) vertical();
+        }
+      }
+      if (ns > 0) vertical();
+    }
+    if (!A.fill)
+      for (int l = lane; l < nlev; l += 64) A.counts[col + A.nij1 * (long)l] = cntl[l];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+hipError_t launch_search_columns(const letkf_search_tables& t, long nij1, int nlev, const double* rig,
+                                 const double* rjg, const double* rlev, const double* rz, int fill, int* counts,
+                                 const long* obs_off, int* obs_idx, double* rdiag_l, double* rloc_l, int num_cu,
+                                 hipStream_t st) {
+  ColArgs a{t, nij1, nlev, rig, rjg, rlev, rz, fill, counts, obs_off, obs_idx, rdiag_l, rloc_l};
+  const size_t lds = (size_t)4 * (4 * kSurv + ((nlev + 1) & ~1)) * sizeof(double);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_search_columns_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const long nwg = (nij1 + 3) / 4;
+  const long g = (long)num_cu * 8;
+  const int grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
+  hipLaunchKernelGGL(letkf_search_columns_kernel, dim3(grid), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_search(const SearchArgs& a, int num_cu, hipStream_t st) {
   const long nwg = (a.npts + 3) / 4;
   const long g = (long)num_cu * 8;

@@ -59,3 +59,29 @@ def test_search_empty_and_dense_points():
         assert g[0].tolist() == e[0].tolist()
     assert max(len(e[0]) for e in exp) > 64          # more than one 64-lane batch per mesh row somewhere
     assert min(len(e[0]) for e in exp) >= 0
+
+
+@pytest.mark.parametrize("nlev", [1, 7, 60])
+def test_column_search_equals_point_search(nlev):
+    """letkf_obs_search_columns_dev (one wave per horizontal point, horizontal part of obs_local_cal once per
+    observation) must give the per-point kernel's lists entry for entry, weights to the last bit."""
+    from _gpu import ctx, dev
+    case = build_case(31, npts=90)
+    t, keep = device_struct(case, "cuda")
+    p = case["pts"]
+    nij1 = 90
+    rng = np.random.default_rng(nlev)
+    rig, rjg = p["ri"], p["rj"]
+    rlev = rng.uniform(2.5e4, 1.0e5, nij1 * nlev)
+    rz = rng.uniform(0.0, 12000.0, nij1 * nlev)
+    c = ctx()
+    o1, i1, d1, l1 = c.obs_search(t, dev(np.tile(rig, nlev)), dev(np.tile(rjg, nlev)), dev(rlev), dev(rz))
+    o2, i2, d2, l2 = c.obs_search_columns(t, nij1, nlev, dev(rig), dev(rjg), dev(rlev), dev(rz))
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and int(o1[-1]) > 100 * nlev
+    assert torch.equal(i1, i2)
+    assert torch.equal(d1, d2) and torch.equal(l1, l2)
+    limited = build_case(31, npts=90, max_nobs=(25, 25, 10, 5))
+    t2, keep2 = device_struct(limited, "cuda")
+    with pytest.raises(RuntimeError):
+        c.obs_search_columns(t2, nij1, nlev, dev(rig), dev(rjg), dev(rlev), dev(rz))
