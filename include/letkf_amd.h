@@ -244,12 +244,14 @@ int letkf_obs_search_dev(letkf_ctx *ctx, const letkf_search_tables *tables, int6
  * (rig1, rjg1), rlev / rz [nij1*nlev] (gues3d(:,:,mmean,iv3d_p), hgt1).  One wavefront per horizontal point evaluates
  * the horizontal part of obs_local_cal once per observation and only the vertical part per level; lists identical,
  * entry for entry, to letkf_obs_search_dev on the expanded coordinates.  No-limit mode only (every max_nobs == 0),
- * else LETKF_E_INVALID.  Same two-phase protocol (fill = 0: counts[nij1*nlev]; fill = 1: write).  Synchronises the
- * stream once (it checks max_nobs). */
+ * else LETKF_E_INVALID.  Same two-phase protocol (fill = 0: counts[nij1*nlev]; fill = 1: write).  nobs_ctype (dev
+ * [nij1*nlev][nctype] or NULL, either phase): accepted rows per combined type = nobsl_t of obs_local
+ * (letkf_tools.f90:1473-1475), the input of the NOBS_OUT diagnostic (:440-447; its cut-off distances are the constants
+ * hori_loc * dist_zero_fac in this mode, :1384-1389).  Synchronises the stream once (it checks max_nobs). */
 int letkf_obs_search_columns_dev(letkf_ctx *ctx, const letkf_search_tables *tables, int64_t nij1, int32_t nlev,
                                  const double *rig, const double *rjg, const double *rlev, const double *rz,
                                  int32_t fill, int32_t *counts, const int64_t *obs_off, int32_t *obs_idx,
-                                 double *rdiag_l, double *rloc_l);
+                                 double *rdiag_l, double *rloc_l, int32_t *nobs_ctype);
 
 /* (3b) The loop body with obs_local FUSED IN: no local lists at all -- every wavefront walks the sorting mesh of
  * `tables` for its own point (same candidate order as letkf_obs_search_dev, so the results are bit-identical to

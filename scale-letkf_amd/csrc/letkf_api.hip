@@ -467,7 +467,7 @@ int letkf_obs_search_dev(letkf_ctx* c, const letkf_search_tables* t, int64_t npt
 int letkf_obs_search_columns_dev(letkf_ctx* c, const letkf_search_tables* t, int64_t nij1, int32_t nlev,
                                  const double* rig, const double* rjg, const double* rlev, const double* rz,
                                  int32_t fill, int32_t* counts, const int64_t* obs_off, int32_t* obs_idx,
-                                 double* rdiag_l, double* rloc_l) {
+                                 double* rdiag_l, double* rloc_l, int32_t* nobs_ctype) {
   if (int rc = check_ctx(c)) return rc;
   if (!t || nij1 < 0 || nlev < 1) return fail(LETKF_E_INVALID, "tables is NULL or bad nij1 / nlev");
   if (nij1 == 0) return LETKF_OK;
@@ -475,7 +475,7 @@ int letkf_obs_search_columns_dev(letkf_ctx* c, const letkf_search_tables* t, int
   if (t->nctype < 1 || t->ngroup < 1) return fail(LETKF_E_INVALID, "bad nctype / ngroup");
   if (fill ? (!obs_off || !obs_idx || !rdiag_l || !rloc_l) : !counts)
     return fail(LETKF_E_INVALID, "missing output array for this phase");
-  if ((size_t)4 * (4 * 512 + ((nlev + 1) & ~1)) * sizeof(double) > c->lds_max)
+  if ((size_t)4 * (4 * 512 + 2 * ((nlev + 1) & ~1)) * sizeof(double) > c->lds_max)
     return fail(LETKF_E_INVALID, "too many levels for the column kernel's LDS counters");
   std::vector<int32_t> mx(t->nctype);
   HIP_TRY(hipMemcpyAsync(mx.data(), t->max_nobs, sizeof(int32_t) * t->nctype, hipMemcpyDeviceToHost, c->stream));
@@ -484,8 +484,8 @@ int letkf_obs_search_columns_dev(letkf_ctx* c, const letkf_search_tables* t, int
     if (mx[ic] > 0)
       return fail(LETKF_E_INVALID, "MAX_NOBS_PER_GRID > 0: use letkf_obs_search_dev (per-point radix select)");
   HIP_TRY(letkf::launch_search_columns(*t, nij1, nlev, rig, rjg, rlev, rz, fill, counts,
-                                       reinterpret_cast<const long*>(obs_off), obs_idx, rdiag_l, rloc_l, c->num_cu,
-                                       c->stream));
+                                       reinterpret_cast<const long*>(obs_off), obs_idx, rdiag_l, rloc_l, nobs_ctype,
+                                       c->num_cu, c->stream));
   return LETKF_OK;
 }
 

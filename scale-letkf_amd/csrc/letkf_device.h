@@ -88,8 +88,8 @@ struct SearchArgs {
 hipError_t launch_search(const SearchArgs& a, int num_cu, hipStream_t st);
 hipError_t launch_search_columns(const letkf_search_tables& t, long nij1, int nlev, const double* rig,
                                  const double* rjg, const double* rlev, const double* rz, int fill, int* counts,
-                                 const long* obs_off, int* obs_idx, double* rdiag_l, double* rloc_l, int num_cu,
-                                 hipStream_t st);
+                                 const long* obs_off, int* obs_idx, double* rdiag_l, double* rloc_l, int* nobs_ctype,
+                                 int num_cu, hipStream_t st);
 
 hipError_t launch_point_kernel(const PointArgs& a, const LaunchPlan& p, hipStream_t st);
 bool wave_kernel_supports(int k, int nv, int mode);

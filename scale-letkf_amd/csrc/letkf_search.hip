@@ -206,6 +206,7 @@ struct ColArgs {
   int* obs_idx;
   double* rdiag_l;
   double* rloc_l;
+  int* nobs_ctype;       // [npts][nctype] accepted rows per combined type (nobsl_t of obs_local), or null
 };
 
 __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs A) {
@@ -215,9 +216,10 @@ __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int nlev = A.nlev;
-  const int cstride = 4 * kSurv + ((nlev + 1) & ~1);             // doubles per wave: survivors + level counters
+  const int cstride = 4 * kSurv + 2 * ((nlev + 1) & ~1);         // doubles per wave: survivors + 2 level counter arrays
   double* sb = smem_col + (size_t)wv * cstride;                  // [kSurv][4]: row bits, nd_h, v_obs, err
   int* cntl = reinterpret_cast<int*>(sb + 4 * kSurv);            // [nlev] entries emitted so far per level
+  int* cprev = cntl + 2 * ((nlev + 1) & ~1);                     // [nlev] the same at the start of the current ctype
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
   for (long col = (long)blockIdx.x * 4 + wv; col < A.nij1; col += (long)gridDim.x * 4) {
@@ -245,6 +247,8 @@ __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs
       const long acb = t.ac_off[ic];
       const int ld = t.ngrdext_i[ic] + 1;
       int ns = 0;                                                 // survivors in the buffer
+      if (A.nobs_ctype)
+        for (int l = lane; l < nlev; l += 64) cprev[l] = cntl[l];
 
       // every level against the buffered survivors, then the buffer is empty again
       auto vertical = [&]() {
@@ -333,6 +337,9 @@ __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs
         }
       }
       if (ns > 0) vertical();
+      if (A.nobs_ctype)                                           // nobsl_t (letkf_tools.f90:1473-1475)
+        for (int l = lane; l < nlev; l += 64)
+          A.nobs_ctype[(col + A.nij1 * (long)l) * t.nctype + ic] = cntl[l] - cprev[l];
     }
     if (!A.fill)
       for (int l = lane; l < nlev; l += 64) A.counts[col + A.nij1 * (long)l] = cntl[l];
@@ -344,10 +351,10 @@ __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs
 
 hipError_t launch_search_columns(const letkf_search_tables& t, long nij1, int nlev, const double* rig,
                                  const double* rjg, const double* rlev, const double* rz, int fill, int* counts,
-                                 const long* obs_off, int* obs_idx, double* rdiag_l, double* rloc_l, int num_cu,
-                                 hipStream_t st) {
-  ColArgs a{t, nij1, nlev, rig, rjg, rlev, rz, fill, counts, obs_off, obs_idx, rdiag_l, rloc_l};
-  const size_t lds = (size_t)4 * (4 * kSurv + ((nlev + 1) & ~1)) * sizeof(double);
+                                 const long* obs_off, int* obs_idx, double* rdiag_l, double* rloc_l, int* nobs_ctype,
+                                 int num_cu, hipStream_t st) {
+  ColArgs a{t, nij1, nlev, rig, rjg, rlev, rz, fill, counts, obs_off, obs_idx, rdiag_l, rloc_l, nobs_ctype};
+  const size_t lds = (size_t)4 * (4 * kSurv + 2 * ((nlev + 1) & ~1)) * sizeof(double);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_search_columns_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

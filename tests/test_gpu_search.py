@@ -76,8 +76,16 @@ def test_column_search_equals_point_search(nlev):
     rz = rng.uniform(0.0, 12000.0, nij1 * nlev)
     c = ctx()
     o1, i1, d1, l1 = c.obs_search(t, dev(np.tile(rig, nlev)), dev(np.tile(rjg, nlev)), dev(rlev), dev(rz))
-    o2, i2, d2, l2 = c.obs_search_columns(t, nij1, nlev, dev(rig), dev(rjg), dev(rlev), dev(rz))
+    nct = torch.full((nij1 * nlev, 4), -1, dtype=torch.int32, device="cuda")
+    o2, i2, d2, l2 = c.obs_search_columns(t, nij1, nlev, dev(rig), dev(rjg), dev(rlev), dev(rz), nobs_ctype=nct)
     torch.cuda.synchronize()
+    # nobsl_t: entries of each point's list per combined type (rows of ctype ic are [ctype_rows[ic], ctype_rows[ic+1]))
+    edges = torch.tensor(case["ctype_rows"], device="cuda")
+    which = torch.bucketize(i1.long(), edges, right=True) - 1
+    pt_of = torch.repeat_interleave(torch.arange(nij1 * nlev, device="cuda"), (o1[1:] - o1[:-1]))
+    want = torch.zeros(nij1 * nlev, 4, dtype=torch.int32, device="cuda")
+    want.index_put_((pt_of, which), torch.ones_like(which, dtype=torch.int32), accumulate=True)
+    assert torch.equal(nct, want)
     assert torch.equal(o1, o2) and int(o1[-1]) > 100 * nlev
     assert torch.equal(i1, i2)
     assert torch.equal(d1, d2) and torch.equal(l1, l2)
