@@ -138,6 +138,10 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise LetkfError(f"{LIB_PATH} not built: run `make -C scale-letkf_amd` (no CPU fallback exists)")
+        try:            # make torch's HIP runtime the process's one BEFORE ours binds /opt/rocm's copy: loaded the other
+            import torch  # noqa: F401  way round, the two runtimes coexist and ours sees no device
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.letkf_amd_last_error.restype = C.c_char_p
         for name in EXPORTS:
