@@ -117,12 +117,175 @@ __device__ __forceinline__ int sweep_group(const SearchArgs& A, const int gs, co
   return cnt;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Limited mode, fast path: ONE sweep evaluates obs_local_cal for the group's candidates and keeps the accepted ones
+// (key, row, rdiag, rloc: 32 B) in LDS; the radix select and the emission then run on that cache.  The first version
+// re-swept all candidates for each of the 8 histogram rounds and once more to emit (10 evaluations of obs_local_cal
+// per candidate: 634 ms for C2 with two ctypes limited to 100, more than the solve).  A group whose accepted
+// candidates do not fit the cache (kCacheCap) falls back to that multi-sweep path.
+// ---------------------------------------------------------------------------------------------
+// In which of the 256 histogram bins does the `want`-th smallest key (1-based) fall, and how many keys lie in the bins
+// before it?  Lane l owns bins 4l..4l+3; a wave prefix sum over the lane totals finds the lane, the lane its bin.
+// (The first version walked the 256 bins one dependent LDS read at a time: 8 rounds x 256 reads per group dominated
+// the limited-mode search.)
+__device__ __forceinline__ void find_bin(const unsigned int* hist, const int want, int& bsel, int& before) {
+  const int lane = threadIdx.x & 63;
+  const uint4 h = *reinterpret_cast<const uint4*>(&hist[4 * lane]);
+  const int s = (int)(h.x + h.y + h.z + h.w);
+  int incl = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  const int excl = incl - s;
+  const bool here = excl < want && incl >= want;
+  int b = 4 * lane, cum = excl;
+  if (cum + (int)h.x < want) {
+    cum += (int)h.x;
+    ++b;
+    if (cum + (int)h.y < want) {
+      cum += (int)h.y;
+      ++b;
+      if (cum + (int)h.z < want) {
+        cum += (int)h.z;
+        ++b;
+      }
+    }
+  }
+  const unsigned long long mk = __ballot(here);
+  if (mk == 0ull) {            // want exceeds the population (cannot happen for want <= count); keep the old default
+    bsel = 255;
+    before = __shfl(incl, 63, 64) - (int)hist[255];
+    return;
+  }
+  const int src = __ffsll((long long)mk) - 1;
+  bsel = __shfl(b, src, 64);
+  before = __shfl(cum, src, 64);
+}
+
+constexpr int kCacheCap = 512;
+
+// returns the number of cached (= accepted) candidates, or -1 on overflow
+__device__ __forceinline__ int cache_group(const SearchArgs& A, const int gs, const int ge, const double ri,
+                                           const double rj, const double rlev, const double rz, double* cache) {
+  const letkf_search_tables& t = A.t;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int cnt = 0;
+  for (int m = gs; m < ge; ++m) {
+    const int ic = t.group_member[m];
+    const double dzi = t.hori_loc[ic] * kDistZeroFac / t.dx;
+    const double dzj = t.hori_loc[ic] * kDistZeroFac / t.dy;
+    int imin, imax, jmin, jmax;
+    ij_obsgrd_ext(t, ic, ri - dzi, rj - dzj, imin, jmin);
+    ij_obsgrd_ext(t, ic, ri + dzi, rj + dzj, imax, jmax);
+    imin = max(imin, 1);
+    jmin = max(jmin, 1);
+    imax = min(imax, t.ngrdext_i[ic]);
+    jmax = min(jmax, t.ngrdext_j[ic]);
+    if (imin > imax || jmin > jmax) continue;
+    const long acb = t.ac_off[ic];
+    const int ld = t.ngrdext_i[ic] + 1;
+    for (int j = jmin; j <= jmax; ++j) {
+      const int lo = t.ac_ext[acb + (imin - 1) + (long)ld * (j - 1)];
+      const int hi = t.ac_ext[acb + imax + (long)ld * (j - 1)];
+      for (int base = lo; base < hi; base += 64) {
+        const int row = base + lane;
+        CalOut c{0.0, -1.0, -1.0};
+        if (row < hi) c = local_cal(t, ic, ri, rj, rlev, rz, row);
+        const bool acc = c.rloc != 0.0;
+        const unsigned long long mk = __ballot(acc);
+        const int na = __popcll(mk);
+        if (cnt + na > kCacheCap) return -1;              // wave-uniform
+        if (acc) {
+          const int e = cnt + __popcll(mk & lt_mask);
+          *reinterpret_cast<double2*>(&cache[4 * e]) =
+              double2{__longlong_as_double((long long)key_bits(t.criterion, c)), __longlong_as_double((long long)row)};
+          *reinterpret_cast<double2*>(&cache[4 * e + 2]) = double2{c.rdiag, c.rloc};
+        }
+        cnt += na;
+      }
+    }
+  }
+  return cnt;
+}
+
+// emits the nmax best of the nc cached candidates (all of them if nc <= nmax) in candidate order; returns the number emitted
+__device__ __forceinline__ int select_from_cache(const SearchArgs& A, const int nc, const int nmax, const long out,
+                                                 const double* cache, unsigned int* hist) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  unsigned long long thresh = ~0ull;
+  int tie_budget = 0;
+  if (nc > nmax) {
+    unsigned long long prefix = 0ull;
+    int want = nmax;
+    for (int round = 0; round < 8; ++round) {
+      for (int b = lane; b < 256; b += 64) hist[b] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int shift = 56 - 8 * round;
+      for (int e = lane; e < nc; e += 64) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(cache[4 * e]);
+        if (round == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(unsigned int)(key >> shift) & 0xFFu], 1u);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      int cum = 0, bsel = 255;
+      find_bin(hist, want, bsel, cum);
+      want -= cum;
+      prefix = (round == 0) ? (unsigned long long)bsel : ((prefix << 8) | (unsigned long long)bsel);
+    }
+    thresh = prefix;
+    tie_budget = want;
+  }
+  int emitted = 0;
+  for (int e0 = 0; e0 < nc; e0 += 64) {
+    const int e = e0 + lane;
+    bool acc = false, tie = false;
+    double2 a2{0.0, 0.0}, b2{0.0, 0.0};
+    if (e < nc) {
+      a2 = *reinterpret_cast<const double2*>(&cache[4 * e]);
+      b2 = *reinterpret_cast<const double2*>(&cache[4 * e + 2]);
+      const unsigned long long key = (unsigned long long)__double_as_longlong(a2.x);
+      acc = nc <= nmax || key < thresh;
+      tie = nc > nmax && key == thresh;
+    }
+    const unsigned long long mk = __ballot(acc);
+    if (acc) {
+      const long o = out + emitted + __popcll(mk & lt_mask);
+      A.obs_idx[o] = (int)__double_as_longlong(a2.y);
+      A.rdiag_l[o] = b2.x;
+      A.rloc_l[o] = b2.y;
+    }
+    emitted += __popcll(mk);
+    const unsigned long long tk = __ballot(tie);                  // ties at the threshold: first come, first served
+    const int tpos = __popcll(tk & lt_mask);
+    if (tie && tpos < tie_budget) {
+      const long o = out + emitted + tpos;
+      A.obs_idx[o] = (int)__double_as_longlong(a2.y);
+      A.rdiag_l[o] = b2.x;
+      A.rloc_l[o] = b2.y;
+    }
+    const int nt = min(__popcll(tk), tie_budget);
+    tie_budget -= nt;
+    emitted += nt;
+  }
+  return emitted;
+}
+
 __global__ void __launch_bounds__(256) letkf_search_kernel(const SearchArgs A) {
   __shared__ unsigned int hist_all[4][256];
+  extern __shared__ __attribute__((aligned(16))) double cache_all[];       // [4][kCacheCap][4]
   const letkf_search_tables& t = A.t;
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   unsigned int* hist = hist_all[wv];
+  double* cache = cache_all + (size_t)wv * 4 * kCacheCap;
 
   for (long pt = (long)blockIdx.x * 4 + wv; pt < A.npts; pt += (long)gridDim.x * 4) {
     const double ri = A.ri[pt], rj = A.rj[pt], rlev = A.rlev[pt], rz = A.rz[pt];
@@ -137,6 +300,10 @@ __global__ void __launch_bounds__(256) letkf_search_kernel(const SearchArgs A) {
       if (nmax <= 0) {                                         // no limit: :1438-1476
         ngrp = A.fill ? sweep_group<kEmitAll>(A, gs, ge, ri, rj, rlev, rz, out, st, hist)
                       : sweep_group<kCount>(A, gs, ge, ri, rj, rlev, rz, out, st, hist);
+      } else if (A.fill && (ngrp = cache_group(A, gs, ge, ri, rj, rlev, rz, cache)) >= 0) {
+        ngrp = select_from_cache(A, ngrp, nmax, out, cache, hist);   // one sweep; select and emit from LDS
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       } else {
         const int cnt = sweep_group<kCount>(A, gs, ge, ri, rj, rlev, rz, out, st, hist);
         if (cnt <= nmax) {
@@ -156,14 +323,7 @@ __global__ void __launch_bounds__(256) letkf_search_kernel(const SearchArgs A) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             int cum = 0, bsel = 255;
-            for (int b = 0; b < 256; ++b) {                    // wave-uniform scan of the 256 bins
-              const int hb = (int)hist[b];
-              if (cum + hb >= want) {
-                bsel = b;
-                break;
-              }
-              cum += hb;
-            }
+            find_bin(hist, want, bsel, cum);
             want -= cum;
             st.prefix = (round == 0) ? (unsigned long long)bsel : ((st.prefix << 8) | (unsigned long long)bsel);
           }
@@ -371,7 +531,11 @@ hipError_t launch_search(const SearchArgs& a, int num_cu, hipStream_t st) {
   const long nwg = (a.npts + 3) / 4;
   const long g = (long)num_cu * 8;
   const int grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
-  hipLaunchKernelGGL(letkf_search_kernel, dim3(grid), dim3(256), 0, st, a);
+  const size_t lds = (size_t)4 * 4 * kCacheCap * sizeof(double);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_search_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(letkf_search_kernel, dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
