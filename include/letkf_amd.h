@@ -234,7 +234,8 @@ typedef struct {
 /* Points: fractional grid indices ri, rj (rig1, rjg1), pressure rlev (gues3d mean of iv3d_p), height rz (hgt1).
  * Two-phase CSR build: call with fill = 0 to get counts[npts]; exclusive-scan them into obs_off[npts+1] (any
  * scan; torch.cumsum in the harness); call again with fill = 1 to write obs_idx / rdiag_l / rloc_l.
- * All pointers are device pointers (the tables struct itself is passed by value from the host). */
+ * All pointers are device pointers (the tables struct itself is passed by value from the host).  Synchronises the
+ * stream once (max_nobs is read back: tables with a limit get an LDS candidate cache). */
 int letkf_obs_search_dev(letkf_ctx *ctx, const letkf_search_tables *tables, int64_t npts, const double *ri,
                          const double *rj, const double *rlev, const double *rz, int32_t fill, int32_t *counts,
                          const int64_t *obs_off, int32_t *obs_idx, double *rdiag_l, double *rloc_l);

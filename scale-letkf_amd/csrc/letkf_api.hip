@@ -460,6 +460,13 @@ int letkf_obs_search_dev(letkf_ctx* c, const letkf_search_tables* t, int64_t npt
   a.obs_idx = obs_idx;
   a.rdiag_l = rdiag_l;
   a.rloc_l = rloc_l;
+  {   // MAX_NOBS_PER_GRID anywhere?  (nctype ints back to the host; the fill phase then gets its LDS candidate cache)
+    std::vector<int32_t> mx(t->nctype);
+    HIP_TRY(hipMemcpyAsync(mx.data(), t->max_nobs, sizeof(int32_t) * t->nctype, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    a.limited = 0;
+    for (int ic = 0; ic < t->nctype; ++ic) a.limited |= mx[ic] > 0;
+  }
   HIP_TRY(letkf::launch_search(a, c->num_cu, c->stream));
   return LETKF_OK;
 }

@@ -84,6 +84,7 @@ struct SearchArgs {
   int* obs_idx;
   double* rdiag_l;
   double* rloc_l;
+  int limited;         // some max_nobs > 0 (host knowledge: sizes the LDS candidate cache)
 };
 hipError_t launch_search(const SearchArgs& a, int num_cu, hipStream_t st);
 hipError_t launch_search_columns(const letkf_search_tables& t, long nij1, int nlev, const double* rig,

@@ -531,7 +531,8 @@ hipError_t launch_search(const SearchArgs& a, int num_cu, hipStream_t st) {
   const long nwg = (a.npts + 3) / 4;
   const long g = (long)num_cu * 8;
   const int grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
-  const size_t lds = (size_t)4 * 4 * kCacheCap * sizeof(double);
+  // the candidate cache is only touched in limited mode: without a limit the kernel keeps its full occupancy
+  const size_t lds = a.limited ? (size_t)4 * 4 * kCacheCap * sizeof(double) : 0;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_search_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
