@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile of the headline bench (needs a GPU): bench line with CPU baseline, rocprofv3 kernel stats, and the two
-# PMC passes (FETCH_SIZE, WRITE_SIZE) in their own runs.  Usage: ./tools_profile.sh v6   -> gpurun_out/prof_v6/
+# PMC passes (FETCH_SIZE, WRITE_SIZE) in their own runs.  Usage: ./tools/profile.sh v6   -> gpurun_out/prof_v6/
 set -o pipefail
 TAG=${1:-vX}
 OUT=gpurun_out/prof_$TAG

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Timing probe: obs_local with MAX_NOBS_PER_GRID on the C2 grid -- two radar ctypes (REF, Vr) on the C2 lattice, each
 limited to 100 observations per point (SURVEY.md section 8(d) variant: n = 200 exactly)."""
-import sys, time, torch
-sys.path.insert(0, ".")
+import os, sys, time, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from __graft_entry__ import load_package
 import bench_workload as bw
 
