@@ -1270,17 +1270,16 @@ static hipError_t launch_wave(const PointArgs& a, int num_cu, hipStream_t st) {
 }
 
 bool wave_kernel_supports(int k, int nv, int mode) {
-  // one wave per point up to k = 62 (k + 2 augmented Gram columns in 64 lanes); two waves for 65..100, where the
-  // columns no longer fit the 256 VALU-addressable VGPRs twice and part of them lives in AGPRs (measured: 170 k
-  // solves/s at k = 100 against 79 k for the workgroup kernel; at k = 63, 64 the workgroup kernel is still ahead)
-  if (k > 100 || k == 63 || k == 64) return false;
+  // one wave per point up to k = 62 (k + 2 augmented Gram columns in 64 lanes); two waves for 63..100 (at k >= 65 the
+  // half-columns no longer fit the 256 VALU-addressable VGPRs three times over and part of them lives in AGPRs)
+  if (k > 100) return false;
   if (mode == 2) return nv == 11 && k <= 62;   // the fused search is written for one wave per point
   if (mode == 0) return nv == 11;
   return nv == 0;
 }
 
 static int wave_kr(int k) {
-  return k <= 16 ? 16 : k <= 32 ? 32 : k <= 48 ? 48 : k <= 50 ? 50 : k <= 62 ? 64 : k <= 80 ? 80 : 100;
+  return k <= 16 ? 16 : k <= 32 ? 32 : k <= 48 ? 48 : k <= 50 ? 50 : k <= 62 ? 64 : k <= 64 ? 64 : k <= 80 ? 80 : 100;
 }
 
 // Launch shape of the wave kernel: run length of the warm-started runs, grid, and the bytes of warm-start workspace
@@ -1326,6 +1325,7 @@ hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st) {
   LETKF_WAVE_CASE(48, 1)
   LETKF_WAVE_CASE(50, 1)
   LETKF_WAVE_CASE(64, 1)
+  LETKF_WAVE_CASE(64, 2)
   LETKF_WAVE_CASE(80, 2)
   LETKF_WAVE_CASE(100, 2)
 #undef LETKF_WAVE_CASE

@@ -143,7 +143,7 @@ def test_empty_batch_and_all_beta_zero():
 
 
 @pytest.mark.parametrize("name", ["rtps", "rtps_adaptive_det", "rtps_qtop", "rtpp"])
-@pytest.mark.parametrize("k,warm_run", [(50, 5), (20, 16), (33, 3), (62, 4), (100, 3), (72, 4), (65, 2)])
+@pytest.mark.parametrize("k,warm_run", [(50, 5), (20, 16), (33, 3), (62, 4), (100, 3), (72, 4), (65, 2), (63, 3), (64, 5)])
 def test_das_points_warm_started_runs(name, k, warm_run):
     """Eigensolves warm-started from the previous point of a run (letkf_das_args.warm_run): same parity bar as the cold
     start, here on UNRELATED consecutive points (the worst case for the predictor), incl. points without obs and
