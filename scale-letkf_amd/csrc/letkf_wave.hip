@@ -23,12 +23,14 @@
 
 #include "letkf_device.h"
 #include "letkf_search_dev.h"
+#include "letkf_jacobi_dev.h"
 
 namespace letkf {
 
 namespace {
 
-typedef double v4d __attribute__((ext_vector_type(4)));
+using namespace jacobi_dev;
+
 
 __device__ __forceinline__ double wshfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ double wshfl(double v, int src) { return __shfl(v, src, 64); }
@@ -91,26 +93,6 @@ __device__ __forceinline__ void pin_acc(double (&c)[NB]) {
   }
 }
 
-// LDS written by some lanes of this wave, read by others: DS instructions of one wave execute in
-// order, so only the compiler has to be kept from reordering across the hand-off.
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// A grid point is solved by NW wavefronts (NW = 1: k <= 62, 4 independent points per 256-thread workgroup;
-// NW = 2: 62 < k <= 100, one point per 128-thread workgroup).  Hand-offs through LDS between lanes of the point:
-template <int NW>
-__device__ __forceinline__ void psync() {
-  if constexpr (NW == 1) wave_lds_sync();
-  else __syncthreads();
-}
-template <int NW>
-__device__ __forceinline__ bool pany(bool v) {
-  if constexpr (NW == 1) return __any(v) != 0;
-  else return __syncthreads_or(v) != 0;
-}
 // sum / max / min over all lanes of the point.  With two waves the partials meet in a 4-double LDS scratch; `slot`
 // alternates between consecutive calls (each call has its own barrier, so slot s is free again two calls later).
 template <int NW, int OP>
@@ -134,265 +116,10 @@ __device__ __forceinline__ long xcd_remap_w(long orig, long n) {
   return base + j;
 }
 
-constexpr double kRotTol2W = 1e-30;   // rotate when cos^2 > 1e-30
-constexpr double kStopTol2W = 1e-20;  // sweep counts as converged when every visited pair had |cos| <= 1e-10 (all of them were
-                                      // still rotated away in that sweep, so what is left is second order)
 constexpr int kTnW = 8;               // obs rows per LDS tile (per wave)
 constexpr int kChunk = 8;             // columns per LDS transposition chunk
 constexpr int kVld = kChunk + 2;      // row stride of the transposition buffer (doubles, even)
 
-// 1/sqrt(x) and 1/x from the hardware seeds (v_rsq_f64 / v_rcp_f64, ~2^-23) + two Newton steps each: full
-// double precision without the IEEE division / sqrt expansions (~25 instructions each), which were 1/3 of
-// the Jacobi step's FP64 issue slots.
-__device__ __forceinline__ double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  double e = fma(-x * y, y, 1.0);
-  y = fma(y * 0.5, e, y);
-  e = fma(-x * y, y, 1.0);
-  return fma(y * 0.5, e, y);
-}
-// one Newton step (~2^-46): enough for the rotation ANGLE, whose error only leaves a second-order residual
-__device__ __forceinline__ double fast_rsqrt1(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  const double e = fma(-x * y, y, 1.0);
-  return fma(y * 0.5, e, y);
-}
-__device__ __forceinline__ double fast_rcp1(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  const double e = fma(-x, r, 1.0);
-  return fma(r, e, r);
-}
-__device__ __forceinline__ double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-x, r, 1.0);
-  return fma(r, e, r);
-}
-
-// ---------------------------------------------------------------------------------------------
-// One-sided (Hestenes) Jacobi on register-resident columns.
-//
-// Pair ordering = odd-even transposition on a line of column positions: even steps pair positions (0,1)(2,3)...,
-// odd steps (1,2)(3,4)...; after its rotation a pair SWAPS places.  After k steps every one of the k(k-1)/2 column
-// pairs has met exactly once, for any k, and the only partners a column ever has are its two neighbours.
-// The rotation itself is a "fast" scaled rotation G' = H + coef * G (one FMA per element): the cosine is not
-// multiplied into the column but accumulated in a per-column inverse scale `is`, and the squared norms alpha follow
-// the rotation identities alpha' = alpha -/+ t*gamma.  Both are refreshed once per sweep.
-// (Earlier layouts, measured and replaced -- see DESIGN.md 4.1: a workgroup per point with G in LDS; lane = column
-// with a ds_bpermute XOR tournament; lane = column with DPP even steps and LDS-chunk odd steps.)
-//
-// Row-split layout: a SLOT of two lanes (m, m + 32) owns the two columns at line positions (2m, 2m + 1),
-// lane m their even rows, lane m + 32 their odd rows:
-//   even steps pair the two columns of a slot: no column moves at all, KR/2 FMAs for the inner product (the two
-//     halves meet through v_permlane32_swap) and KR FMAs for the two half-columns;
-//   odd steps pair column 2m+1 with 2m+2 of the next slot: each lane fetches one half-column from either
-//     neighbour slot (wave_shr:1 / wave_shl:1 DPP moves, KR dword moves each way as before), but computes only ONE
-//     inner product half (the left slot of a pair passes its rotation on through four more DPP moves).
-// Per two steps: 3/2 KR FMAs + 2 KR moves less than the column-per-lane version (~390 instead of ~500
-// instructions at k = 50).  The lanes of unused slots are switched off for the whole iteration: DPP reads from a
-// disabled lane return 0 (bound_ctrl), which is exactly the "no partner" case at both ends of the line.
-// ---------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ double dpp_shift0(double v) {     // wave_shl:1 (0x130) / wave_shr:1 (0x138), 0 if no source
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-// v[l & 31] + v[32 + (l & 31)] in every lane (both lanes of a slot must be active)
-__device__ __forceinline__ double slot_sum(double v) {
-  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
-  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
-  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-
-// sum of the two lanes of a slot.  One wave: lanes (m, m + 32) through v_permlane32_swap.  Two waves (k > 62): the
-// same lane of the two waves, through LDS and a workgroup barrier; the two exchange buffers alternate, so that a buffer
-// is rewritten only after the barrier that follows everybody's read of it.
-template <int NW>
-__device__ __forceinline__ double slot_sum_nw(double v, double* xs, int& ph) {
-  if constexpr (NW == 1) {
-    return slot_sum(v);
-  } else {
-    const int t = threadIdx.x & 127;
-    xs[ph * 128 + t] = v;
-    __syncthreads();
-    const double o = xs[ph * 128 + (t ^ 64)];
-    ph ^= 1;
-    return v + o;
-  }
-}
-
-// NW = 2 (62 < k <= 100): slot m = lane m of both waves (wave 0 the even rows, wave 1 the odd rows); everything
-// else as for one wave -- the DPP shifts stay inside a wave, only the inner-product halves and the convergence vote
-// cross waves (three workgroup barriers per step pair).
-template <int KR, int NW>
-__device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const int max_sweep, double* lds) {
-  static_assert(KR % 2 == 0, "row halves");
-  constexpr int H = KR / 2;
-  constexpr int RC = 24;                       // rows per conversion chunk: 24 * 64 NW doubles of LDS
-  constexpr int NL = 64 * NW;
-  const int lane = threadIdx.x & (NL - 1);
-  const int slot = (NW == 1) ? (lane & 31) : (lane & 63), par = (NW == 1) ? (lane >> 5) : (lane >> 6);
-  int ph = 0;
-  const int ncol = (k + 1) & ~1;               // an odd k gets one zero column as an extra (inert) participant
-  const int S = ncol >> 1;                     // slots in use
-  double xa[H], xb[H], xf[H];
-  // ---- column-per-lane -> row-split: lds[r][col], r in chunks
-#pragma unroll
-  for (int r0 = 0; r0 < KR; r0 += RC) {
-    psync<NW>();
-#pragma unroll
-    for (int r = r0; r < r0 + RC && r < KR; ++r) lds[(r - r0) * NL + lane] = g[r];
-    psync<NW>();
-#pragma unroll
-    for (int rr = r0 / 2; rr < (r0 + RC) / 2 && rr < H; ++rr) {
-      const double2 v2 = *reinterpret_cast<const double2*>(&lds[(2 * rr + par - r0) * NL + 2 * slot]);
-      xa[rr] = v2.x;
-      xb[rr] = v2.y;
-    }
-  }
-  int sweep = 0;
-  if (slot < S) {
-    const bool hasL = slot > 0, hasR = slot + 1 < S;
-    double alA = 0.0, alB = 0.0, isA = 1.0, isB = 1.0, scA = 1.0, scB = 1.0;
-    // `quiet` counts consecutive step pairs in which no visited column pair exceeded the tolerance; S of them in a
-    // row are one full cycle of the ordering (every column pair seen once) whatever step it started at, so the
-    // iteration stops S step pairs after the last significant rotation, not at the next sweep boundary.
-    int quiet = 0, pairs = 0;
-    bool done = false;
-    for (; sweep < max_sweep && !done; ++sweep) {
-      // refresh: fold the scales back, recompute the squared norms
-      double a0 = 0.0, b0 = 0.0;
-#pragma unroll
-      for (int rr = 0; rr < H; ++rr) {
-        xa[rr] *= isA;
-        xb[rr] *= isB;
-        a0 = fma(xa[rr], xa[rr], a0);
-        b0 = fma(xb[rr], xb[rr], b0);
-      }
-      alA = slot_sum_nw<NW>(a0, lds, ph);
-      alB = slot_sum_nw<NW>(b0, lds, ph);
-      isA = isB = scA = scB = 1.0;
-      for (int t = 0; t < ncol && !done; t += 2) {
-        bool notconv = false;
-        // ---------------- even step: the slot's own two columns (A at the lower position)
-        {
-          double p0 = 0.0, p1 = 0.0;
-#pragma unroll
-          for (int rr = 0; rr < H; ++rr) {
-            if (rr & 1) p1 = fma(xa[rr], xb[rr], p1);
-            else p0 = fma(xa[rr], xb[rr], p0);
-          }
-          const double ga = slot_sum_nw<NW>(p0 + p1, lds, ph) * (isA * isB);
-          const double a = alA, b = alB;
-          const double g2 = ga * ga, ab = a * b;
-          notconv |= g2 > kStopTol2W * ab;
-          const bool rot = g2 > kRotTol2W * ab;
-          const double d = b - a;
-          const double x = fma(d, d, 4.0 * g2);
-          const double hh = x * fast_rsqrt1(x);
-          double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
-          tt = rot ? tt : 0.0;
-          const double w = fma(tt, tt, 1.0);
-          const double c = fast_rsqrt(w);
-          const double tg = tt * ga, wc = w * c;
-          // rotate and swap: position 2m takes c (g_B + t g_A), position 2m+1 takes c (g_A - t g_B)
-          const double cA = tt * (isA * scB), cB = -tt * (isB * scA);
-          const double nisA = isB * c, nscA = scB * wc, nisB = isA * c, nscB = scA * wc;
-          alA = b + tg;
-          alB = a - tg;
-          isA = nisA;
-          scA = nscA;
-          isB = nisB;
-          scB = nscB;
-          // the new A goes to the spare array xf, the new B is accumulated in place in xa[] (every FMA adds into the
-          // register its result stays in: no copies)
-#pragma unroll
-          for (int rr = 0; rr < H; ++rr) {
-            // three-address form with an early-clobber destination: left to itself the compiler accumulates into
-            // xb's registers (v_fmac) and then has to copy the column out of the way of the DPP fetch below.  (No
-            // "nothing to rotate" shortcut here: its copy path made the allocator shuffle 50 registers per step pair.)
-            asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(xf[rr]) : "v"(cA), "v"(xa[rr]), "v"(xb[rr]));
-            xa[rr] = fma(cB, xb[rr], xa[rr]);
-          }
-        }
-        // ---------------- odd step: own B (now in xa[]) with the right slot's A; own A (in xf[]) with the left slot's B
-        {
-          double p0 = 0.0, p1 = 0.0;
-#pragma unroll
-          for (int rr = 0; rr < H; ++rr) {
-            xb[rr] = dpp_shift0<0x130>(xf[rr]);                 // A of the right slot
-            if (rr & 1) p1 = fma(xa[rr], xb[rr], p1);
-            else p0 = fma(xa[rr], xb[rr], p0);
-          }
-          const double alAr = dpp_shift0<0x130>(alA), isAr = dpp_shift0<0x130>(isA), scAr = dpp_shift0<0x130>(scA);
-          const double ga = slot_sum_nw<NW>(p0 + p1, lds, ph) * (isB * isAr);
-          const double a = alB, b = alAr;
-          const double g2 = ga * ga, ab = a * b;
-          notconv |= hasR && g2 > kStopTol2W * ab;
-          const bool rot = hasR && g2 > kRotTol2W * ab;
-          const double d = b - a;
-          const double x = fma(d, d, 4.0 * g2);
-          const double hh = x * fast_rsqrt1(x);
-          double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
-          tt = rot ? tt : 0.0;
-          const double w = fma(tt, tt, 1.0);
-          const double c = fast_rsqrt(w);
-          const double tg = tt * ga, wc = w * c;
-          // what the right slot needs to rotate its A against this slot's (old) B
-          const double q1 = dpp_shift0<0x138>(-tt * scB), q2 = dpp_shift0<0x138>(isB * c),
-                       q3 = dpp_shift0<0x138>(scB * wc), q4 = dpp_shift0<0x138>(a - tg);
-          const double coefR = hasR ? tt * (isB * scAr) : 1.0;   // position 2m+1 takes c (g_Ar + t g_B)
-          const double coefL = hasL ? q1 * isA : 1.0;            // position 2m takes c (g_Bl - t g_A)
-          if (hasR) {
-            alB = b + tg;
-            isB = isAr * c;
-            scB = scAr * wc;
-          }
-          if (hasL) {
-            alA = q4;
-            isA = q2;
-            scA = q3;
-          }
-          // new B into xb[] (on top of the fetched column); then the old B of the LEFT slot is pulled into xa[] --
-          // every lane reads its neighbour's xa[rr] and overwrites its own in the same instruction -- and the new A
-          // accumulated on top of it: A is back in xa[], B in xb[], xf[] is spare again
-#pragma unroll
-          for (int rr = 0; rr < H; ++rr) {
-            xb[rr] = fma(coefR, xa[rr], xb[rr]);
-            xa[rr] = dpp_shift0<0x138>(xa[rr]);
-            xa[rr] = fma(coefL, xf[rr], xa[rr]);
-          }
-        }
-        ++pairs;
-        quiet = pany<NW>(notconv) ? 0 : quiet + 1;
-        done = quiet >= S;
-      }
-    }
-    sweep = (pairs + S - 1) / S;
-#pragma unroll
-    for (int rr = 0; rr < H; ++rr) {
-      xa[rr] *= isA;
-      xb[rr] *= isB;
-    }
-  }
-  sweep = __builtin_amdgcn_readfirstlane(sweep);
-  // ---- row-split -> column-per-lane
-#pragma unroll
-  for (int r0 = 0; r0 < KR; r0 += RC) {
-    psync<NW>();
-#pragma unroll
-    for (int rr = r0 / 2; rr < (r0 + RC) / 2 && rr < H; ++rr)
-      *reinterpret_cast<double2*>(&lds[(2 * rr + par - r0) * NL + 2 * slot]) = double2{xa[rr], xb[rr]};
-    psync<NW>();
-#pragma unroll
-    for (int r = r0; r < r0 + RC && r < KR; ++r) g[r] = lds[(r - r0) * NL + lane];
-  }
-  psync<NW>();
-  return sweep;
-}
 
 // Out[b] (lane m: row m of V C) += sum over the wave's columns j of V[m][j] * C[j][b], b < NB.
 // V[:, j] is lane j's register column vcol[], C[j][:] is lane j's crow[].  Done in chunks of
