@@ -108,12 +108,20 @@ int make_plan(const letkf_ctx* c, int k, int nv, long npts, Plan* p) {
   // large-k spill path: G, U, X in a per-workgroup HBM workspace, obs tile sized to what LDS is left
   p->lp.big = true;
   p->lp.rmax = 0;
-  p->lp.block = 1024;
-  const size_t budget = 64 * 1024 / 8;   // doubles of LDS we allow ourselves (keeps 2 workgroups per CU)
+  // one wave per block pair of the block Jacobi (k/32 pairs per round), 4..12 waves: 12 waves = 3 per SIMD keeps
+  // 170 VGPRs per lane for the in-register 32 x 32 eigensolver; one workgroup per CU
+  const int nblk = (k + 15) / 16, nbe = nblk + (nblk & 1);
+  int waves = nbe / 2;
+  if (waves < 4) waves = 4;
+  if (waves > 12) waves = 12;
+  p->lp.block = 64 * waves;
+  const size_t budget = 128 * 1024 / 8;  // doubles of LDS we allow ourselves
   size_t fixed = lds_doubles(true, k, nv, p->ldg, p->ldy, 0);
   long tn = fixed < budget ? (long)((budget - fixed) / (p->ldy + 3)) : 0;
   if (tn > 32) tn = 32;
   if (tn < 4) tn = 4;
+  // the obs tile region doubles as the per-wave scratch of the block Jacobi (512 doubles per wave)
+  while ((size_t)tn * p->ldy < (size_t)waves * 512) ++tn;
   p->tn = (int)tn;
   p->lp.lds_bytes = 8 * lds_doubles(true, k, nv, p->ldg, p->ldy, p->tn);
   if (p->lp.lds_bytes > c->lds_max) return fail(LETKF_E_INVALID, "ensemble size too large for the LDS vectors");
@@ -147,6 +155,7 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
   a.ws = c->ws;
   a.ws_per_block = p.ws_per_block;
   a.max_sweep = 60;
+  a.big_block = (p.lp.big && !std::getenv("LETKF_AMD_BIG_STREAM")) ? 1 : 0;   // knob: the older streaming Jacobi
   if (const char* e = std::getenv("LETKF_AMD_MAX_SWEEP")) {   // profiling knob: time the non-eigensolve phases
     int v = std::atoi(e);
     if (v >= 0 && v < 60) a.max_sweep = v;   // 0: skip the eigensolve entirely (timing only, results invalid)

@@ -55,6 +55,7 @@ struct PointArgs {
   // large-k workspace
   double* ws;
   long ws_per_block;   // doubles
+  int big_block;       // large-k path: block Jacobi on the matrix cores (0: streaming column-pair Jacobi)
   // mode 2: the search tables and the points' coordinates (rig1, rjg1, p mean, hgt1)
   letkf_search_tables stab;
   const double *pri, *prj, *prlev, *prz;

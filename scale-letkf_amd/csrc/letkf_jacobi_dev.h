@@ -121,7 +121,8 @@ __device__ __forceinline__ double slot_sum_nw(double v, double* xs, int& ph) {
 // else as for one wave -- the DPP shifts stay inside a wave, only the inner-product halves and the convergence vote
 // cross waves (three workgroup barriers per step pair).
 template <int KR, int NW, int RC = 24>
-__device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const int max_sweep, double* lds) {
+__device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const int max_sweep, double* lds,
+                                            int* pairs_out = nullptr) {
   static_assert(KR % 2 == 0, "row halves");
   constexpr int H = KR / 2;
   static_assert(RC % 2 == 0, "RC rows per conversion chunk: RC * 64 NW doubles of LDS");
@@ -146,7 +147,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
       xb[rr] = v2.y;
     }
   }
-  int sweep = 0;
+  int sweep = 0, pairs_done = 0;
   if (slot < S) {
     const bool hasL = slot > 0, hasR = slot + 1 < S;
     double alA = 0.0, alB = 0.0, isA = 1.0, isB = 1.0, scA = 1.0, scB = 1.0;
@@ -265,6 +266,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
       }
     }
     sweep = (pairs + S - 1) / S;
+    pairs_done = pairs;
 #pragma unroll
     for (int rr = 0; rr < H; ++rr) {
       xa[rr] *= isA;
@@ -272,6 +274,8 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
     }
   }
   sweep = __builtin_amdgcn_readfirstlane(sweep);
+  if (pairs_out) *pairs_out = __builtin_amdgcn_readfirstlane(pairs_done);   // step pairs executed (the column order
+                                                                             // after them is a fixed permutation)
   // ---- row-split -> column-per-lane
 #pragma unroll
   for (int r0 = 0; r0 < KR; r0 += RC) {
