@@ -267,15 +267,26 @@ __device__ __forceinline__ int jacobi_block_mfma(double* __restrict__ G, const i
         // ---- 1. Gram of the 32 columns
         v4d tII{0.0, 0.0, 0.0, 0.0}, tIJ{0.0, 0.0, 0.0, 0.0}, tJJ{0.0, 0.0, 0.0, 0.0};
         {
-          double yI = (okI && q < k) ? gI[q] : 0.0, yJ = (okJ && q < k) ? gJ[q] : 0.0;
-          for (int r0 = 0; r0 < k; r0 += 4) {
-            const int rn = r0 + 4 + q;
-            const double nI = (okI && rn < k) ? gI[rn] : 0.0, nJ = (okJ && rn < k) ? gJ[rn] : 0.0;
-            tII = __builtin_amdgcn_mfma_f64_16x16x4f64(yI, yI, tII, 0, 0, 0);
-            tIJ = __builtin_amdgcn_mfma_f64_16x16x4f64(yI, yJ, tIJ, 0, 0, 0);
-            tJJ = __builtin_amdgcn_mfma_f64_16x16x4f64(yJ, yJ, tJJ, 0, 0, 0);
-            yI = nI;
-            yJ = nJ;
+          // four 4-row steps in flight (the rows come from L2: one step of MFMAs does not cover a load)
+          constexpr int PD = 4;
+          double yI[PD], yJ[PD];
+#pragma unroll
+          for (int u = 0; u < PD; ++u) {
+            const int rn = 4 * u + q;
+            yI[u] = (okI && rn < k) ? gI[rn] : 0.0;
+            yJ[u] = (okJ && rn < k) ? gJ[rn] : 0.0;
+          }
+          for (int r0 = 0; r0 < k; r0 += 4 * PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+              const double cI = yI[u], cJ = yJ[u];
+              const int rn = r0 + 4 * (PD + u) + q;
+              yI[u] = (okI && rn < k) ? gI[rn] : 0.0;
+              yJ[u] = (okJ && rn < k) ? gJ[rn] : 0.0;
+              tII = __builtin_amdgcn_mfma_f64_16x16x4f64(cI, cI, tII, 0, 0, 0);
+              tIJ = __builtin_amdgcn_mfma_f64_16x16x4f64(cI, cJ, tIJ, 0, 0, 0);
+              tJJ = __builtin_amdgcn_mfma_f64_16x16x4f64(cJ, cJ, tJJ, 0, 0, 0);
+            }
           }
         }
         // ---- B -> "lane j owns column j" (lanes 0..31), 16 columns at a time through scr[16][32]
