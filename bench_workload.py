@@ -28,6 +28,9 @@ CONFIGS = {
     # profiling stand-in: same grid, no observation in range (isolates state I/O + transform)
     "C2-mini-noobs": dict(nx=48, ny=48, nz=12, k=50, dx=1000.0, hloc=40.0, vloc=20.0, spacing=3200.0, err=3.0,
                           ztop=18000.0, seed=20240610),
+    # BASELINE configs[2] (C3: k = 320) on a small grid: the large-k path (block Jacobi on the matrix cores)
+    "C3-mini": dict(nx=24, ny=24, nz=6, k=320, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2900.0, err=3.0,
+                    ztop=18000.0, seed=20240613),
     "C1": dict(nx=40, ny=40, nz=30, k=20, dx=15000.0, hloc=120000.0, vloc=4000.0, spacing=30000.0, err=3.0,
                ztop=18000.0, seed=20240608),
 }

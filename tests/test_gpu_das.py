@@ -243,3 +243,13 @@ def test_two_variable_localisation_classes(name, k, nv):
         g = rtps.cpu().numpy()
         live = ~np.isnan(want_rtps) & (want_rtps != 0.0)
         assert np.allclose(g[live], want_rtps[live], rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("k,name", [(144, "rtps_adaptive_det"), (160, "rtpp_qclamp")])
+def test_das_points_large_k_block_jacobi(k, name):
+    """k > 128: the workgroup kernel with G in the HBM workspace and the block Jacobi on the matrix cores"""
+    cfg = CONFIGS[name]
+    c, ref, got, infl, status, _, _ = run_both(k, 11, 7, 700, 180, seed=31 + k, cfg=cfg)
+    assert (status == 0).all()
+    compare_anal(c, ref, got, k, 11, bool(cfg.get("det_run", 0)))
+    assert np.abs(infl - ref["infl"]).max() <= 1e-12
