@@ -13,7 +13,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libletkf_amd.so")
+LIB_PATH = os.environ.get("LETKF_AMD_LIB") or os.path.join(HERE, "lib", "libletkf_amd.so")   # override: profiling twin (make PROF=1)
 
 LETKF_OK = 0
 ST_OK, ST_NOT_CONVERGED, ST_NONPOSITIVE, ST_ILLCOND = 0, 1, 2, 3

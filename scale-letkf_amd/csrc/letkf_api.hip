@@ -180,7 +180,26 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
     a.warm_ws = reinterpret_cast<double*>(c->warm_ws);
     a.warm_dbg = 0;
     if (const char* e = std::getenv("LETKF_AMD_WARM_DBG")) a.warm_dbg = std::atoi(e);
+    a.prof = nullptr;
+#ifdef LETKF_WAVE_PROF
+    static unsigned long long* prof_dev = nullptr;
+    if (!prof_dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&prof_dev), 10 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(prof_dev, 0, 10 * sizeof(unsigned long long), c->stream));
+    a.prof = prof_dev;
+#endif
     HIP_TRY(letkf::launch_wave_kernel(a, c->num_cu, c->stream));
+#ifdef LETKF_WAVE_PROF
+    {
+      unsigned long long h[10];
+      HIP_TRY(hipMemcpyAsync(h, prof_dev, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      unsigned long long tot = 0;
+      for (int i = 0; i < 10; ++i) tot += h[i];
+      std::fprintf(stderr, "[letkf prof] wave-time share by phase (s_memtime ticks, all waves):");
+      for (int i = 0; i < 10; ++i) std::fprintf(stderr, " p%d=%.1f%%", i, tot ? 100.0 * (double)h[i] / (double)tot : 0.0);
+      std::fprintf(stderr, " total=%llu\n", tot);
+    }
+#endif
   } else
     HIP_TRY(letkf::launch_point_kernel(a, p.lp, c->stream));
   if (c->timing) {

@@ -63,6 +63,7 @@ struct PointArgs {
   // wave kernel: launch shape and warm-start workspace (wave_launch_shape)
   double* warm_ws;
   int run_len, wave_grid, warm_dbg;
+  unsigned long long* prof;   // profiling build (-DLETKF_WAVE_PROF) only: per-phase s_memtime totals, else null
 };
 
 struct LaunchPlan {

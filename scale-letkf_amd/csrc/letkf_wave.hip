@@ -271,6 +271,98 @@ __device__ __forceinline__ void warm_start_product(double (&g)[KR], const double
   for (int r = 0; r < KR; ++r) g[r] = out[r];
 }
 
+// The same product on the FP64 matrix cores, for one-wave points with KR <= 50 (A fits the wave's LDS slice whole:
+// 4 x 20 KB per workgroup, two workgroups still share a CU -- tools/ubench_lds_occ.hip).  The LDS-broadcast version
+// above is latency-bound (4 ds_read_b128 in flight against 8 FMAs: 23 cycles per instruction, 15 % of the kernel's
+// wave time on C2, measured with the PROF build) and it competes with the other wave's Jacobi for the vector ALU;
+// here every lane first parks its column of A in LDS -- which frees the 2 KR registers of g for the accumulators --
+// and the product runs as KS = KR/4 steps of 16 v_mfma_f64_16x16x4 with
+//   A operand, row block I : A[4c + I][4s + q]   = 4 consecutive doubles of LDS column 4s+q (A is symmetric)
+//   B operand, col block J : Q[4s + q][4c + J]   = 4 consecutive doubles of workspace row 4s+q (coalesced 32-B loads)
+// (lane = 16 q + c; the blocks interleave rows / columns with stride 4 instead of covering 16 contiguous ones, so that
+// both operands of a step are one 32-byte read per lane).  Accumulator (I, J), register `reg` of lane (q, c) is
+// G0[16 reg + 4q + I][4c + J]; the tiles go back to "lane j owns column j" through the same LDS region.
+template <int KR>
+__device__ __forceinline__ void warm_start_product_mfma(double (&g)[KR], const double* __restrict__ qslot, double* cb) {
+  static_assert(KR % 2 == 0 && KR <= 50, "A must fit the LDS slice");
+  constexpr int KS = (KR + 3) / 4;             // contraction steps of 4
+  constexpr int PD = (KS < 6) ? KS : 6;        // workspace row-quads in flight
+  const int wlane = threadIdx.x & 63;
+  const int q = wlane >> 4, c = wlane & 15;
+  struct Quad {
+    double2 lo, hi;
+  };
+  const double* qp = qslot + q * 64 + 4 * c;
+  asm volatile("" : "+v"(qp));
+  auto ldq = [&](const int s) {
+    Quad t{double2{0.0, 0.0}, double2{0.0, 0.0}};
+    if (4 * s + 3 < KR || 4 * s + q < KR) {    // rows >= KR do not exist in the slot
+      const double* a = qp + (size_t)s * 256;
+      t.lo = *reinterpret_cast<const double2*>(a);
+      t.hi = *reinterpret_cast<const double2*>(a + 2);
+    }
+    return t;
+  };
+  auto lda = [&](const int s) {
+    Quad t{double2{0.0, 0.0}, double2{0.0, 0.0}};
+    if (4 * s + 3 < KR || 4 * s + q < KR) {
+      const double* a = cb + (4 * s + q) * KR + 4 * c;   // rows 4c+I >= KR read finite-or-not garbage: only output
+      t.lo = *reinterpret_cast<const double2*>(a);        // rows >= KR see it, and those are dropped below
+      t.hi = *reinterpret_cast<const double2*>(a + 2);
+    }
+    return t;
+  };
+  Quad qr[PD];
+#pragma unroll
+  for (int s = 0; s < PD; ++s) qr[s] = ldq(s);
+  wave_lds_sync();
+  if (wlane < KR) {
+    double* mine = cb + wlane * KR;
+#pragma unroll
+    for (int r = 0; r < KR; r += 2) *reinterpret_cast<double2*>(&mine[r]) = double2{g[r], g[r + 1]};
+  }
+  wave_lds_sync();
+  v4d acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  Quad ar[2];
+  ar[0] = lda(0);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (s + 1 < KS) ar[(s + 1) & 1] = lda(s + 1);
+    const Quad a4 = ar[s & 1], b4 = qr[s % PD];
+    const double av[4] = {a4.lo.x, a4.lo.y, a4.hi.x, a4.hi.y};
+    const double bv[4] = {b4.lo.x, b4.lo.y, b4.hi.x, b4.hi.y};
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+      for (int J = 0; J < 4; ++J) acc[4 * I + J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], bv[J], acc[4 * I + J], 0, 0, 0);
+    if (s + PD < KS) qr[s % PD] = ldq(s + PD);
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int J = 0; J < 4; ++J) {
+    const int col = 4 * c + J;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row0 = 16 * reg + 4 * q;
+      if (col < KR && row0 < KR) *reinterpret_cast<double2*>(&cb[col * KR + row0]) = double2{acc[J][reg], acc[4 + J][reg]};
+      if (col < KR && row0 + 2 < KR) *reinterpret_cast<double2*>(&cb[col * KR + row0 + 2]) = double2{acc[8 + J][reg], acc[12 + J][reg]};
+    }
+  }
+  wave_lds_sync();
+  {
+    const double* mine = cb + (wlane < KR ? wlane : 0) * KR;
+#pragma unroll
+    for (int r = 0; r < KR; r += 2) {
+      const double2 v2 = *reinterpret_cast<const double2*>(&mine[r]);
+      g[r] = wlane < KR ? v2.x : 0.0;
+      g[r + 1] = wlane < KR ? v2.y : 0.0;
+    }
+  }
+  wave_lds_sync();
+}
+
 }  // namespace
 
 // per-wave LDS slice (doubles); mirrored by wave_lds_doubles() in letkf_api.hip
@@ -286,6 +378,7 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
   if (tile + bmat < 1536 * NW) bmat = 1536 * NW - tile;   // Gram transposition buffer abuf[64 NW][18] and the Jacobi
                                                          // exchange slots (64 NW * 24 doubles) span tile + bmat
   int tot = tile + bmat + cb + small + 8;                // + 4 doubles of reduction scratch (two-wave points)
+  if (NW == 1 && KR <= 50 && tot < (KR - 1) * KR + 64) tot = (KR - 1) * KR + 64;   // A whole: warm_start_product_mfma
   return (tot + 1) & ~1;
 }
 
@@ -293,6 +386,17 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
 // production kernel carries neither the code nor the registers for it.
 // FUSED: obs_local walked inside the kernel (mode 2) -- its own instantiation as well: carried by the list-driven kernel
 // the extra code cost 15 % of its speed (registers / instruction cache), measured.
+// Profiling build (make PROF=1): per-phase wave time from s_memtime, kept in SGPRs, summed over all waves.
+#ifdef LETKF_WAVE_PROF
+#define PROF_DECL unsigned long long prof_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#define PROF_MARK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_t[i] += t_ - prof_last; prof_last = t_; }
+#define PROF_FLUSH if (A.prof && wlane == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&A.prof[i_], prof_t[i_]); }
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#define PROF_FLUSH
+#endif
+
 template <int KR, int NV, bool KKOUT, int NW, bool FUSED>
 __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wave_kernel(const PointArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -333,6 +437,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
   const long nB = (A.npts + per_wg - 1) / per_wg;
   // this wave's slot of the warm-start workspace: [KR][NL] doubles, lane-fastest
   double* uws = (WARM && run_len > 1) ? A.warm_ws + ((size_t)blockIdx.x * PPW + wv) * ((size_t)KR * NL) + lane : nullptr;
+  PROF_DECL
   for (long B = blockIdx.x; B < nB; B += gridDim.x) {
    const long run0 = xcd_remap_w(B, nB) * per_wg + (long)wv * run_len;
    bool have_u = false;
@@ -382,6 +487,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     double* infl_p = das ? ((v0 < nv) ? &A.infl[pt + A.npts * (long)v0] : nullptr) : &A.infl[pt];
     const double infl_old = infl_p ? *infl_p : 1.0;
 
+    PROF_MARK(0)
     // ------------------------------------------------------------ Gram on the FP64 matrix cores
     // A_aug = Ya^T Ya with Ya = sqrt(w) * [y_1 .. y_k | dep | dep_det]  (n x (k+2)), v_mfma_f64_16x16x4:
     // 4 obs per step.  Lane l supplies, for member block I, Ya[obs0 + (l>>4)][16 I + (l&15)] -- the SAME register
@@ -684,6 +790,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         psync<NW>();
         run_steps(nsp);
       }
+      PROF_MARK(1)
       if (n > 0) {
       solved = true;
       // accumulator tiles -> "lane j owns column j": 16 rows at a time through LDS.  C/D layout of the f64 MFMA:
@@ -750,11 +857,17 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         parm2 = preduce<NW, 0>(lane < k ? diag : 0.0, red, rslot) / km1;
       }
 
+      PROF_MARK(2)
       // ------------------------------------------------------------ eigen-decomposition in registers
       if constexpr (WARM) {
-        if (have_u && !(A.warm_dbg & 1)) warm_start_product<KR, NW>(g, uws, k, slice);
+        if (have_u && !(A.warm_dbg & 1)) {
+          if constexpr (NW == 1 && KR <= 50) warm_start_product_mfma<KR>(g, uws - lane, slice);
+          else warm_start_product<KR, NW>(g, uws, k, slice);
+        }
       }
+      PROF_MARK(3)
       sweeps = jacobi_split<KR, NW>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
+      PROF_MARK(4)
 
       double ss = 0.0;
 #pragma unroll
@@ -811,6 +924,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     const double sc1 = colvalid ? sqrt(km1 / lam) : 0.0;      // T spectrum
     const double sc2 = colvalid ? 1.0 / lam : 0.0;            // Pa spectrum
 
+    PROF_MARK(5)
     // ------------------------------------------------------------ B = [r, r_det, x'_v] as bmat[m][NBP]; U = V^T B
     psync<NW>();
     if (lane < KR) {
@@ -845,6 +959,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       }
       if ((r & 1) == 1) pin_acc<NB>(crow);
     }
+    PROF_MARK(6)
     // RTPS factor per variable (letkf_tools.f90:1982-1999), kept in SGPRs: var_a = x'^T Pa x' = sum_j U_jv^2 / lam_j
     double cf[NV > 0 ? NV : 1];
     const int mrow_l = lane < KR ? lane : KR - 1;
@@ -878,6 +993,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     double out[NB];
     rows_times_c<KR, NB, NW>(g, crow, out, k, vbuf, cbuf);   // lane m: out[0] = w-bar_m, out[1] = w-bar_det_m, out[2+v] = (T x'_v)_m
 
+    PROF_MARK(7)
     // ------------------------------------------------------------ analysis members (letkf_tools.f90:472-513)
     if (NV > 0 && das) {
       double* ap = a0 + moff;
@@ -973,6 +1089,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         }
       }
     }
+    PROF_MARK(8)
     if (lane == 0) {
       if (A.status) A.status[pt] = st;
       if (A.nsweep) A.nsweep[pt] = sweeps;
@@ -980,6 +1097,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     }
    }
   }
+  PROF_FLUSH
 }
 
 // ------------------------------------------------------------------ host launcher
