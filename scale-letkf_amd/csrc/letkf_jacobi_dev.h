@@ -31,8 +31,22 @@ __device__ __forceinline__ bool pany(bool v) {
 }
 
 constexpr double kRotTol2W = 1e-30;   // rotate when cos^2 > 1e-30
+#ifndef LETKF_EARLY_TOL2
+#define LETKF_EARLY_TOL2 1e-16
+#endif
+#ifndef LETKF_EARLY_T2
+#define LETKF_EARLY_T2 1e-12
+#endif
 constexpr double kStopTol2W = 1e-20;  // sweep counts as converged when every visited pair had |cos| <= 1e-10 (all of them were
                                       // still rotated away in that sweep, so what is left is second order)
+// Early stop: a full cycle in which every pair had |cos| <= 1e-8 AND every applied rotation a tangent |t| <= 1e-6 ends the
+// iteration as well -- each coupling was annihilated once in that cycle and re-filled by at most k products t * cos
+// <= 1e-14.  The tangent condition matters: with (near-)multiple eigenvalues a pair of almost equal columns is rotated
+// by a large angle at a tiny cosine, which shuffles the couplings of size 1e-8 of those two columns to all others
+// after they were visited -- without it the result is only first-order accurate (measured: 8e-10 on T for n < k,
+// tools/parity_margin.py).  Such points simply fall back to the 1e-10 rule.
+constexpr double kEarlyTol2W = LETKF_EARLY_TOL2;
+constexpr double kEarlyT2W = LETKF_EARLY_T2;
 
 // 1/sqrt(x) and 1/x from the hardware seeds (v_rsq_f64 / v_rcp_f64, ~2^-23) + two Newton steps each: full
 // double precision without the IEEE division / sqrt expansions (~25 instructions each), which were 1/3 of
@@ -154,7 +168,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
     // `quiet` counts consecutive step pairs in which no visited column pair exceeded the tolerance; S of them in a
     // row are one full cycle of the ordering (every column pair seen once) whatever step it started at, so the
     // iteration stops S step pairs after the last significant rotation, not at the next sweep boundary.
-    int quiet = 0, pairs = 0;
+    int quiet = 0, quiet2 = 0, pairs = 0;
     bool done = false;
     for (; sweep < max_sweep && !done; ++sweep) {
       // refresh: fold the scales back, recompute the squared norms
@@ -170,7 +184,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
       alB = slot_sum_nw<NW>(b0, lds, ph);
       isA = isB = scA = scB = 1.0;
       for (int t = 0; t < ncol && !done; t += 2) {
-        bool notconv = false;
+        bool notconv = false, notconv2 = false;
         // ---------------- even step: the slot's own two columns (A at the lower position)
         {
           double p0 = 0.0, p1 = 0.0;
@@ -189,6 +203,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           const double hh = x * fast_rsqrt1(x);
           double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
           tt = rot ? tt : 0.0;
+          notconv2 |= g2 > kEarlyTol2W * ab || tt * tt > kEarlyT2W;
           const double w = fma(tt, tt, 1.0);
           const double c = fast_rsqrt(w);
           const double tg = tt * ga, wc = w * c;
@@ -232,6 +247,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           const double hh = x * fast_rsqrt1(x);
           double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
           tt = rot ? tt : 0.0;
+          notconv2 |= hasR && (g2 > kEarlyTol2W * ab || tt * tt > kEarlyT2W);
           const double w = fma(tt, tt, 1.0);
           const double c = fast_rsqrt(w);
           const double tg = tt * ga, wc = w * c;
@@ -262,7 +278,8 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
         }
         ++pairs;
         quiet = pany<NW>(notconv) ? 0 : quiet + 1;
-        done = quiet >= S;
+        quiet2 = pany<NW>(notconv2) ? 0 : quiet2 + 1;
+        done = quiet >= S || quiet2 >= S;
       }
     }
     sweep = (pairs + S - 1) / S;
