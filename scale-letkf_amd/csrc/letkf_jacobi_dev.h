@@ -134,7 +134,9 @@ __device__ __forceinline__ double slot_sum_nw(double v, double* xs, int& ph) {
 // NW = 2 (62 < k <= 100): slot m = lane m of both waves (wave 0 the even rows, wave 1 the odd rows); everything
 // else as for one wave -- the DPP shifts stay inside a wave, only the inner-product halves and the convergence vote
 // cross waves (three workgroup barriers per step pair).
-template <int KR, int NW, int RC = 24>
+// EARLY = false: only the 1e-10 rule (the block Jacobi of letkf_kernels.hip reads "one cycle" as "this block pair
+// was already diagonal" and must not have rotations of 1e-8 pass for that).
+template <int KR, int NW, int RC = 24, bool EARLY = true>
 __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const int max_sweep, double* lds,
                                             int* pairs_out = nullptr) {
   static_assert(KR % 2 == 0, "row halves");
@@ -279,7 +281,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
         ++pairs;
         quiet = pany<NW>(notconv) ? 0 : quiet + 1;
         quiet2 = pany<NW>(notconv2) ? 0 : quiet2 + 1;
-        done = quiet >= S || quiet2 >= S;
+        done = quiet >= S || (EARLY && quiet2 >= S);
       }
     }
     sweep = (pairs + S - 1) / S;

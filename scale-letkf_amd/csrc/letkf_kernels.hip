@@ -324,7 +324,7 @@ __device__ __forceinline__ int jacobi_block_mfma(double* __restrict__ G, const i
         }
         // ---- 2. eigenvectors of B
         int inpairs = 0;
-        const int insw = jacobi_dev::jacobi_split<32, 1, 8>(g, 32, 30, scr, &inpairs);
+        const int insw = jacobi_dev::jacobi_split<32, 1, 8, false>(g, 32, 30, scr, &inpairs);
         if (insw > 1) notconv = 1;
         // The inner solver swaps the two columns of a pair after every rotation, unconditionally: after T steps the
         // column order is a fixed permutation (odd-even transposition: reversal after 32 steps, identity after 64).
