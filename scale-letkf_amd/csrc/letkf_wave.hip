@@ -76,6 +76,13 @@ __device__ __forceinline__ double uniform(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// lane `src` (wave-uniform) of v -> SGPR pair
+__device__ __forceinline__ double readlane_d(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
 // Scheduling pin: makes every accumulator an in/out operand of an empty asm with a memory clobber.  The FMAs that
 // produce the accumulators must then retire before it and the next LDS loads issue after it, which stops the
 // compiler from issuing all unrolled broadcast loads first and spilling them (measured: 5 KB of scratch per lane).
@@ -379,6 +386,8 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
                                                          // exchange slots (64 NW * 24 doubles) span tile + bmat
   int tot = tile + bmat + cb + small + 8;                // + 4 doubles of reduction scratch (two-wave points)
   if (NW == 1 && KR <= 50 && tot < (KR - 1) * KR + 64) tot = (KR - 1) * KR + 64;   // A whole: warm_start_product_mfma
+  if (NW == 1 && KR <= 50 && tot < 32 * KR + KR * ((nb + 1) & ~1) + 128)              // half of V + B + spectra: the apply phase on the matrix cores
+    tot = 32 * KR + KR * ((nb + 1) & ~1) + 128;
   return (tot + 1) & ~1;
 }
 
@@ -925,74 +934,220 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     const double sc2 = colvalid ? 1.0 / lam : 0.0;            // Pa spectrum
 
     PROF_MARK(5)
-    // ------------------------------------------------------------ B = [r, r_det, x'_v] as bmat[m][NBP]; U = V^T B
-    psync<NW>();
-    if (lane < KR) {
-      bmat[lane * NBP + 0] = (lane < k) ? racc : 0.0;
-      bmat[lane * NBP + 1] = (lane < k) ? rdacc : 0.0;
-      if (NBP > NB) bmat[lane * NBP + NB] = 0.0;
-    }
-    if (NV > 0) {
-      const double* gp = g0 + moff;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const double x = (lane < k) ? *gp : 0.0;
-        gp += A.sv;
-        if (lane < KR) bmat[lane * NBP + 2 + v] = x;
-      }
-      if (lane < NV) {
-        xmean[lane] = g0[k * A.sm + lane * A.sv];
-        xdet[lane] = A.det_run ? g0[(k + 1) * A.sm + lane * A.sv] : 0.0;
-      }
-    }
-    psync<NW>();
-    double crow[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) crow[b] = 0.0;
-#pragma unroll
-    for (int r = 0; r < KR; ++r) {
-#pragma unroll
-      for (int b = 0; b < NBP; b += 2) {
-        const double2 b2 = *reinterpret_cast<const double2*>(&bmat[r * NBP + b]);   // broadcast
-        crow[b] = fma(g[r], b2.x, crow[b]);
-        if (b + 1 < NB) crow[b + 1] = fma(g[r], b2.y, crow[b + 1]);
-      }
-      if ((r & 1) == 1) pin_acc<NB>(crow);
-    }
-    PROF_MARK(6)
-    // RTPS factor per variable (letkf_tools.f90:1982-1999), kept in SGPRs: var_a = x'^T Pa x' = sum_j U_jv^2 / lam_j
-    double cf[NV > 0 ? NV : 1];
+    // ------------------------------------------------------------ apply phase
+    // U = V^T B, C = D U, Out = V C.  One-wave points with KR <= 50 run both products on the FP64 matrix cores
+    // (MAPPLY); the others (two-wave points, the T / Pa instantiations) keep the LDS-broadcast version below.
+    constexpr bool MAPPLY = !KKOUT && NW == 1 && KR <= 50 && NV > 0 && NB <= 14;
     const int mrow_l = lane < KR ? lane : KR - 1;
-    if (NV > 0) {
+    double cf[NV > 0 ? NV : 1];
+    double out[NB];
+    double xv[NV > 0 ? NV : 1];                 // MAPPLY: x'_v of member `lane`
+    double xm_l = 0.0, xd_l = 0.0;             // MAPPLY: lane v < NV holds x-bar_v and the deterministic member of variable v
+    if constexpr (MAPPLY) {
+      // The broadcast version is LDS-latency-bound like the old warm-start product was (16 % of the wave time on C2,
+      // PROF build).  Here V is parked in LDS 32 columns at a time ([col][row], like A in warm_start_product_mfma --
+      // a whole V plus B does not fit the 20 KB slice), and per half h:
+      //   U tile il (rows j = 32h + 16 il + i): A operand V[4s+q][j] (ds_read_b64), B operand B[4s+q][c] (c = b < 14)
+      //   C = D U on the accumulators: register `reg` of lane (q, c) is U[32h + 16 il + 4 reg + q][c] -- which is
+      //     exactly the B-operand layout of contraction step s = 8h + 4 il + reg of Out = V C (j = 4s + q): no exchange
+      //   Out tile I (rows m = 4i + I): A operand V[4c + I][4s + q] = 4 consecutive doubles of LDS column 4s+q.
+      // var_a of the RTPS factor is summed from the same accumulators, var_g from the B operands.
+      constexpr int KS = (KR + 3) / 4;
+      double* vh = slice;                      // [32][KR]
+      double* bm = slice + 32 * KR;            // [KR][NBP]
+      double* scl = bm + KR * NBP;             // [64][2]: (1/lam, sqrt((k-1)/lam)) per eigen-column
+      const int q = wlane >> 4, c = wlane & 15;
+      wave_lds_sync();
+      {
+        const double* gp = g0 + moff;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
+        for (int v = 0; v < NV; ++v) {
+          xv[v] = (lane < k) ? *gp : 0.0;
+          gp += A.sv;
+        }
+        if (lane < NV) {
+          xm_l = g0[k * A.sm + lane * A.sv];
+          xd_l = A.det_run ? g0[(k + 1) * A.sm + lane * A.sv] : 0.0;
+        }
+        if (lane < KR) {
+          double* row = bm + lane * NBP;
+          *reinterpret_cast<double2*>(&row[0]) = double2{(lane < k) ? racc : 0.0, (lane < k) ? rdacc : 0.0};
+#pragma unroll
+          for (int v = 0; v < NV; v += 2)
+            *reinterpret_cast<double2*>(&row[2 + v]) = double2{xv[v], (v + 1 < NV) ? xv[v + 1] : 0.0};
+        }
+        *reinterpret_cast<double2*>(&scl[2 * lane]) = double2{sc2, sc1};
+      }
+      v4d accO[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) accO[t] = v4d{0.0, 0.0, 0.0, 0.0};
+      double va = 0.0, vg = 0.0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (32 * h < KR) {
+          wave_lds_sync();
+          if ((lane >> 5) == h && lane < KR) {
+            double* mine = vh + (lane - 32 * h) * KR;
+#pragma unroll
+            for (int r = 0; r < KR; r += 2) *reinterpret_cast<double2*>(&mine[r]) = double2{g[r], g[r + 1]};
+          }
+          wave_lds_sync();
+          v4d accU[2];
+          accU[0] = v4d{0.0, 0.0, 0.0, 0.0};
+          accU[1] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s_ = 0; s_ < KS; ++s_) {
+            const bool rok = (4 * s_ + 3 < KR) || (4 * s_ + q < KR);
+            const double bq = (rok && c < NBP) ? bm[(4 * s_ + q) * NBP + c] : 0.0;
+            if (h == 0) vg = fma(bq, bq, vg);
+#pragma unroll
+            for (int il = 0; il < 2; ++il) {
+              if (32 * h + 16 * il < KR) {
+                const int jl = 16 * il + c;
+                const double a = (rok && 32 * h + jl < KR) ? vh[jl * KR + 4 * s_ + q] : 0.0;
+                accU[il] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, accU[il], 0, 0, 0);
+              }
+            }
+          }
+#pragma unroll
+          for (int il = 0; il < 2; ++il) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const int s_ = 4 * (2 * h + il) + reg;       // contraction step of Out: eigen-columns j = 4 s_ + q
+              if (4 * s_ < KR) {
+                const int j = 4 * s_ + q;
+                const double2 sc = *reinterpret_cast<const double2*>(&scl[2 * j]);
+                const double u = accU[il][reg];
+                va = fma(u * u, sc.x, va);
+                const double cv = u * (c < 2 ? sc.x : sc.y);
+                const bool jok = (4 * s_ + 3 < KR) || (j < KR);
+                const double* a = vh + (j - 32 * h) * KR + 4 * c;
+                double2 lo{0.0, 0.0}, hi{0.0, 0.0};
+                if (jok) {
+                  lo = *reinterpret_cast<const double2*>(a);
+                  hi = *reinterpret_cast<const double2*>(a + 2);
+                }
+                accO[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(lo.x, cv, accO[0], 0, 0, 0);
+                accO[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(lo.y, cv, accO[1], 0, 0, 0);
+                accO[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(hi.x, cv, accO[2], 0, 0, 0);
+                accO[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(hi.y, cv, accO[3], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      PROF_MARK(6)
+      // RTPS factor per variable (letkf_tools.f90:1982-1999) in the lanes of column c = 2 + v:
+      // var_a = x'^T Pa x' = sum_j U_jv^2 / lam_j, var_g = sum_m x'_v[m]^2 (both still split over the 4 q groups)
+      va += wshfl_xor(va, 16);
+      va += wshfl_xor(va, 32);
+      vg += wshfl_xor(vg, 16);
+      vg += wshfl_xor(vg, 32);
+      {
+        const int v = c - 2;
+        const bool isv = c >= 2 && c < NB;
         double cfv = 1.0;
         if (A.relax_alpha != 0.0) {
           cfv = 1.0 - A.relax_alpha;
         } else if (A.relax_alpha_spread != 0.0) {
-          const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391
-          const double x = (lane < k) ? bmat[mrow_l * NBP + 2 + v] : 0.0;
-          const double var_g = preduce<NW, 0>(x * x, red, rslot);
-          const double var_a = preduce<NW, 0>(crow[2 + v] * crow[2 + v] * sc2, red, rslot);
-          if (var_g > 0.0 && var_a > 0.0)
-            cfv = A.relax_alpha_spread * sqrt(var_g * parm / (var_a * km1)) - A.relax_alpha_spread + 1.0;
+          const double parm = (A.relax_to_inflated_prior && isv) ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391
+          if (vg > 0.0 && va > 0.0) cfv = A.relax_alpha_spread * sqrt(vg * parm / (va * km1)) - A.relax_alpha_spread + 1.0;
         }
-        cf[v] = uniform(cfv);
-        if (A.rtps_out && lane == 0 && ((A.var_mask >> v) & 1u)) {   // work3da (letkf_tools.f90:460-462); skipped variables keep 1
+        if (A.rtps_out && q == 0 && isv && ((A.var_mask >> v) & 1u)) {   // work3da (letkf_tools.f90:460-462); skipped variables keep 1
           const bool skipv = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
           A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cfv : 1.0;
         }
-      }
-    }
-    // C = D U : w-bar spectrum 1/lam, T spectrum sqrt((k-1)/lam)
-    crow[0] *= sc2;
-    crow[1] *= sc2;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) crow[2 + v] *= sc1;
+        for (int vv = 0; vv < NV; ++vv) cf[vv] = readlane_d(cfv, 2 + vv);
+      }
+      // Out tiles -> lane m holds row m: register `reg` of tile I, lane (q, c) is Out[16 reg + 4 q + I][c]
+      wave_lds_sync();
+      double* ob = slice;                      // [KR][NBP], on top of the V half
+#pragma unroll
+      for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int m = 16 * reg + 4 * q + I;
+          if (m < KR && c < NBP) ob[m * NBP + c] = accO[I][reg];
+        }
+      wave_lds_sync();
+      {
+        const double* row = ob + (lane < KR ? lane : 0) * NBP;
+#pragma unroll
+        for (int b = 0; b < NB; b += 2) {
+          const double2 o2 = *reinterpret_cast<const double2*>(&row[b]);
+          out[b] = o2.x;
+          if (b + 1 < NB) out[b + 1] = o2.y;
+        }
+      }
+      wave_lds_sync();
+    } else {
+      // ------------------------------------------------------------ B = [r, r_det, x'_v] as bmat[m][NBP]; U = V^T B
+      psync<NW>();
+      if (lane < KR) {
+        bmat[lane * NBP + 0] = (lane < k) ? racc : 0.0;
+        bmat[lane * NBP + 1] = (lane < k) ? rdacc : 0.0;
+        if (NBP > NB) bmat[lane * NBP + NB] = 0.0;
+      }
+      if (NV > 0) {
+        const double* gp = g0 + moff;
+  #pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const double x = (lane < k) ? *gp : 0.0;
+          gp += A.sv;
+          if (lane < KR) bmat[lane * NBP + 2 + v] = x;
+        }
+        if (lane < NV) {
+          xmean[lane] = g0[k * A.sm + lane * A.sv];
+          xdet[lane] = A.det_run ? g0[(k + 1) * A.sm + lane * A.sv] : 0.0;
+        }
+      }
+      psync<NW>();
+      double crow[NB];
+  #pragma unroll
+      for (int b = 0; b < NB; ++b) crow[b] = 0.0;
+  #pragma unroll
+      for (int r = 0; r < KR; ++r) {
+  #pragma unroll
+        for (int b = 0; b < NBP; b += 2) {
+          const double2 b2 = *reinterpret_cast<const double2*>(&bmat[r * NBP + b]);   // broadcast
+          crow[b] = fma(g[r], b2.x, crow[b]);
+          if (b + 1 < NB) crow[b + 1] = fma(g[r], b2.y, crow[b + 1]);
+        }
+        if ((r & 1) == 1) pin_acc<NB>(crow);
+      }
+      PROF_MARK(6)
+      // RTPS factor per variable (letkf_tools.f90:1982-1999), kept in SGPRs: var_a = x'^T Pa x' = sum_j U_jv^2 / lam_j
+      if (NV > 0) {
+  #pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          double cfv = 1.0;
+          if (A.relax_alpha != 0.0) {
+            cfv = 1.0 - A.relax_alpha;
+          } else if (A.relax_alpha_spread != 0.0) {
+            const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391
+            const double x = (lane < k) ? bmat[mrow_l * NBP + 2 + v] : 0.0;
+            const double var_g = preduce<NW, 0>(x * x, red, rslot);
+            const double var_a = preduce<NW, 0>(crow[2 + v] * crow[2 + v] * sc2, red, rslot);
+            if (var_g > 0.0 && var_a > 0.0)
+              cfv = A.relax_alpha_spread * sqrt(var_g * parm / (var_a * km1)) - A.relax_alpha_spread + 1.0;
+          }
+          cf[v] = uniform(cfv);
+          if (A.rtps_out && lane == 0 && ((A.var_mask >> v) & 1u)) {   // work3da (letkf_tools.f90:460-462); skipped variables keep 1
+            const bool skipv = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
+            A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cfv : 1.0;
+          }
+        }
+      }
+      // C = D U : w-bar spectrum 1/lam, T spectrum sqrt((k-1)/lam)
+      crow[0] *= sc2;
+      crow[1] *= sc2;
+  #pragma unroll
+      for (int v = 0; v < NV; ++v) crow[2 + v] *= sc1;
 
-    double out[NB];
-    rows_times_c<KR, NB, NW>(g, crow, out, k, vbuf, cbuf);   // lane m: out[0] = w-bar_m, out[1] = w-bar_det_m, out[2+v] = (T x'_v)_m
+      rows_times_c<KR, NB, NW>(g, crow, out, k, vbuf, cbuf);   // lane m: out[0] = w-bar_m, out[1] = w-bar_det_m, out[2+v] = (T x'_v)_m
 
+    }
     PROF_MARK(7)
     // ------------------------------------------------------------ analysis members (letkf_tools.f90:472-513)
     if (NV > 0 && das) {
@@ -1000,10 +1155,18 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
-        const double x = (lane < k) ? bmat[mrow_l * NBP + 2 + v] : 0.0;
+        double x, xm, xdt;
+        if constexpr (MAPPLY) {
+          x = xv[v];
+          xm = readlane_d(xm_l, v);
+          xdt = readlane_d(xd_l, v);
+        } else {
+          x = (lane < k) ? bmat[mrow_l * NBP + 2 + v] : 0.0;
+          xm = xmean[v];
+          xdt = xdet[v];
+        }
         const double sdot = preduce<NW, 0>(x * out[0], red, rslot);
         const double sdotd = A.det_run ? preduce<NW, 0>(x * out[1], red, rslot) : 0.0;
-        const double xm = xmean[v];
         double val;
         if (skip) {
           val = xm + x;
@@ -1026,7 +1189,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         if (lane < k && inclass) *ap = val;
         ap += A.sv;
         if (A.det_run && lane == 0 && inclass)
-          a0[(k + 1) * A.sm + v * A.sv] = skip ? xdet[v] : xdet[v] + sdotd * beta;     // :489-497
+          a0[(k + 1) * A.sm + v * A.sv] = skip ? xdt : xdt + sdotd * beta;     // :489-497
       }
       if (A.infl_adaptive) {                       // :396-398 (also without obs: the class copies its first slot), after every parm read above
 #pragma unroll
