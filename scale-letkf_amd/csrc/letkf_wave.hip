@@ -372,6 +372,12 @@ __device__ __forceinline__ void warm_start_product_mfma(double (&g)[KR], const d
 
 }  // namespace
 
+// smallest k the instantiation <KR, NW> is dispatched for (launch_wave_kernel walks the instances in this order)
+__host__ __device__ constexpr int wave_kmin(int KR, int NW) {
+  return NW == 1 ? (KR == 16 ? 1 : KR == 32 ? 17 : KR == 48 ? 33 : KR == 50 ? 49 : KR == 64 ? 51 : 1)
+                 : (KR == 64 ? 63 : KR == 80 ? 65 : KR == 100 ? 81 : 1);
+}
+
 // per-wave LDS slice (doubles); mirrored by wave_lds_doubles() in letkf_api.hip
 __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
   const int nb = nv + 2;
@@ -513,6 +519,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     bool solved = false;
     if (n != 0) {
       constexpr int NBLK = (KR + 2 + 15) / 16;                 // member blocks incl. the 2 augmented columns
+      constexpr int KMIN = wave_kmin(KR, NW);                  // launch_wave_kernel: this instantiation serves KMIN <= k <= KR
       constexpr int NTILE = NBLK * (NBLK + 1) / 2;
       v4d acc[NTILE];
 #pragma unroll
@@ -565,7 +572,9 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
 #pragma unroll
           for (int I = 0; I < NBLK; ++I) {
             double v = t.f[I] * t.sw;
-            if (16 * (I + 1) > k) {                            // wave-uniform: block reaches past the members
+            // (blocks that lie below the smallest k this instantiation is dispatched for are all members at compile
+            // time: hipcc turns the wave-uniform test into 9 v_cndmask per block and step otherwise)
+            if (16 * (I + 1) > KMIN && 16 * (I + 1) > k) {     // wave-uniform: block reaches past the members
               v = rowok[I] ? v : 0.0;
               if (I == blk_d && is_d) v = t.dsw;
               if (I == blk_dd && is_dd) v = t.ddsw;
@@ -1267,6 +1276,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
 template <int KR, int NV, bool KKOUT, int NW, bool FUSED = false>
 static hipError_t launch_wave(const PointArgs& a, int num_cu, hipStream_t st) {
   const size_t lds = (size_t)(NW == 1 ? 4 : 1) * wave_slice_doubles(KR, NV, NW) * sizeof(double);
+  if (a.k < wave_kmin(KR, NW) || a.k > KR) return hipErrorInvalidValue;   // the Gram assumes its full member blocks
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_wave_kernel<KR, NV, KKOUT, NW, FUSED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
