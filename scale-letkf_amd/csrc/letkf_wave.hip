@@ -592,19 +592,32 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         };
         Step t0, t1, t2;
         fetch(wvp, t0);
+        asm volatile("" ::: "memory");         // (same order as in the loop: the waits are counted statically)
         fetch(wvp + NW, t1);
+        asm volatile("" ::: "memory");
         fetch(wvp + 2 * NW, t2);
+        asm volatile("" ::: "memory");
+        // (no conditions inside the body: a step past the end has sw = dsw = ddsw = 0 and adds nothing, and with
+        // branches around the fetches hipcc can no longer count the loads in flight and waits for ALL of them --
+        // s_waitcnt vmcnt(0) -- at the top of every iteration, exposing one L2 latency per three steps)
+        // The empty asm statements keep each fetch where it is written: left alone, hipcc rotates the loop so that all
+        // twelve loads sit at the top of the iteration that consumes them.
+        // (and the loaded rows are routed through them just before their use: otherwise the multiplies of the LATER steps
+        // are hoisted to the top of the iteration and wait for the youngest loads there)
+        auto pin = [&](Step& t) {
+#pragma unroll
+          for (int I = 0; I < NBLK; ++I) asm volatile("" : "+v"(t.f[I])::"memory");
+        };
         for (int c = wvp; c < nch; c += 3 * NW) {
+          pin(t0);
           mma(t0);
           fetch(c + 3 * NW, t0);
-          if (c + NW < nch) {
-            mma(t1);
-            fetch(c + 4 * NW, t1);
-          }
-          if (c + 2 * NW < nch) {
-            mma(t2);
-            fetch(c + 5 * NW, t2);
-          }
+          pin(t1);
+          mma(t1);
+          fetch(c + 4 * NW, t1);
+          pin(t2);
+          mma(t2);
+          fetch(c + 5 * NW, t2);
         }
       };
 
