@@ -192,6 +192,10 @@ __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const dou
 // (tools/ubench_readlane.hip: 5.6 ns per triple against 2.35 ns per bare v_fma_f64) cost one sweep; with the
 // row-split Jacobi (no LDS in its steps) the LDS broadcast is the cheapest again.
 // ---------------------------------------------------------------------------------------------
+#ifndef LETKF_GRAM_DEPTH
+#define LETKF_GRAM_DEPTH 3
+#endif
+constexpr int kGramDepth = LETKF_GRAM_DEPTH;   // 4-obs Gram steps in flight (measured on C2: 3 -> 477 ms, 4 -> 487, 5 -> 492)
 constexpr int kWC = 4;   // columns of A per LDS chunk (small: the unrolled chunk body is ~100 instructions per column)
 // pins out[R0 .. R0+7] (those below KR): see pin_acc
 template <int KR, int R0>
@@ -590,34 +594,32 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
               ++tt;
             }
         };
-        Step t0, t1, t2;
-        fetch(wvp, t0);
-        asm volatile("" ::: "memory");         // (same order as in the loop: the waits are counted statically)
-        fetch(wvp + NW, t1);
-        asm volatile("" ::: "memory");
-        fetch(wvp + 2 * NW, t2);
-        asm volatile("" ::: "memory");
-        // (no conditions inside the body: a step past the end has sw = dsw = ddsw = 0 and adds nothing, and with
-        // branches around the fetches hipcc can no longer count the loads in flight and waits for ALL of them --
-        // s_waitcnt vmcnt(0) -- at the top of every iteration, exposing one L2 latency per three steps)
-        // The empty asm statements keep each fetch where it is written: left alone, hipcc rotates the loop so that all
-        // twelve loads sit at the top of the iteration that consumes them.
-        // (and the loaded rows are routed through them just before their use: otherwise the multiplies of the LATER steps
-        // are hoisted to the top of the iteration and wait for the youngest loads there)
+        // PD steps in flight.  Three things keep the pipeline the way it is written (each found in the ISA):
+        //  * no conditions around the fetches (a step past the end has sw = dsw = ddsw = 0 and adds nothing): with
+        //    branches hipcc can no longer count the loads in flight and waits for ALL of them -- s_waitcnt vmcnt(0) --
+        //    at the top of every iteration, one exposed L2 latency per iteration;
+        //  * the empty asm statements keep each fetch where it is written: left alone, hipcc rotates the loop so that
+        //    all loads sit at the top of the iteration that consumes them;
+        //  * the loaded rows are routed through one just before their use: otherwise the multiplies of the LATER steps
+        //    are hoisted to the top of the iteration and wait for the youngest loads there.
+        constexpr int PD = kGramDepth;
+        Step ts[PD];
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+          fetch(wvp + u * NW, ts[u]);
+          asm volatile("" ::: "memory");         // (same order as in the loop: the waits are counted statically)
+        }
         auto pin = [&](Step& t) {
 #pragma unroll
           for (int I = 0; I < NBLK; ++I) asm volatile("" : "+v"(t.f[I])::"memory");
         };
-        for (int c = wvp; c < nch; c += 3 * NW) {
-          pin(t0);
-          mma(t0);
-          fetch(c + 3 * NW, t0);
-          pin(t1);
-          mma(t1);
-          fetch(c + 4 * NW, t1);
-          pin(t2);
-          mma(t2);
-          fetch(c + 5 * NW, t2);
+        for (int c = wvp; c < nch; c += PD * NW) {
+#pragma unroll
+          for (int u = 0; u < PD; ++u) {
+            pin(ts[u]);
+            if (u == 0 || c + u * NW < nch) mma(ts[u]);   // (wave-uniform; only the matrix instructions are skipped)
+            fetch(c + (PD + u) * NW, ts[u]);
+          }
         }
       };
 
