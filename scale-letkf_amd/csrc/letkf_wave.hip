@@ -396,8 +396,8 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
                                                          // exchange slots (64 NW * 24 doubles) span tile + bmat
   int tot = tile + bmat + cb + small + 8;                // + 4 doubles of reduction scratch (two-wave points)
   if (NW == 1 && KR <= 50 && tot < (KR - 1) * KR + 64) tot = (KR - 1) * KR + 64;   // A whole: warm_start_product_mfma
-  if (NW == 1 && KR <= 50 && tot < 32 * KR + KR * ((nb + 1) & ~1) + 128)              // half of V + B + spectra: the apply phase on the matrix cores
-    tot = 32 * KR + KR * ((nb + 1) & ~1) + 128;
+  if (NW == 1 && KR <= 50 && tot < 32 * KR + 64 * ((KR + 3) / 4) + 128)               // half of V + padded B + spectra: the apply phase on the matrix cores
+    tot = 32 * KR + 64 * ((KR + 3) / 4) + 128;
   return (tot + 1) & ~1;
 }
 
@@ -922,16 +922,38 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       }
       }
     }
-    if (!solved) {
+    // apply phase on the matrix cores (see below); these instantiations also give points without observations a
+    // closed-form path that never touches g
+    constexpr bool MAPPLY = !KKOUT && NW == 1 && KR <= 50 && NV > 0 && NB <= 14;
+    if constexpr (!MAPPLY) {
+      if (!solved) {
 #pragma unroll
-      for (int r = 0; r < KR; ++r) g[r] = (r == lane && lane < k) ? 1.0 : 0.0;
+        for (int r = 0; r < KR; ++r) g[r] = (r == lane && lane < k) ? 1.0 : 0.0;
+      }
     }
     const double infl_new = (A.infl_adaptive && n > 0) ? p1 : infl_old;
+    double xv[NV > 0 ? NV : 1];                 // MAPPLY: x'_v of member `lane`
+    double xm_l = 0.0, xd_l = 0.0;             // MAPPLY: lane v < NV holds x-bar_v and the deterministic member of variable v
+    if constexpr (MAPPLY) {
+      // the state loads of the apply phase, issued here so that their latency (8-byte accesses npts*8 B apart) runs
+      // under the normalisation, the workspace store and the status reductions
+      const double* gp = g0 + moff;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        xv[v] = (lane < k) ? *gp : 0.0;
+        gp += A.sv;
+      }
+      if (lane < NV) {
+        xm_l = g0[k * A.sm + lane * A.sv];
+        xd_l = A.det_run ? g0[(k + 1) * A.sm + lane * A.sv] : 0.0;
+      }
+      asm volatile("" ::: "memory");
+    }
     if constexpr (WARM) {
       // leave the eigenvectors behind for the next point of the run.  Here, while g is still entirely in registers:
       // further down part of it is spilled, and a store loop that alternates scratch reloads with global stores
       // pays one store-acknowledge latency per element (s_waitcnt vmcnt counts both) -- measured 41 us per point.
-      if (uws && !(A.warm_dbg & 2)) {
+      if (uws && (solved || !MAPPLY) && !(A.warm_dbg & 2)) {
         // (the pointer is laundered every 8 rows: otherwise all KR row addresses are hoisted out of the point loop
         // as 64-bit values, spilled, and reloaded one by one in front of each store -- same serialisation)
         double* p = uws;
@@ -953,7 +975,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       else if (!(lmx > 0.0)) st = 2;
       else if (lmn < lmx * 1.4901161193847656e-08) st = 3;
     }
-    if constexpr (WARM) have_u = uws != nullptr && st == 0;
+    if constexpr (WARM) have_u = uws != nullptr && st == 0 && (solved || !MAPPLY);
     const double sc1 = colvalid ? sqrt(km1 / lam) : 0.0;      // T spectrum
     const double sc2 = colvalid ? 1.0 / lam : 0.0;            // Pa spectrum
 
@@ -961,12 +983,9 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     // ------------------------------------------------------------ apply phase
     // U = V^T B, C = D U, Out = V C.  One-wave points with KR <= 50 run both products on the FP64 matrix cores
     // (MAPPLY); the others (two-wave points, the T / Pa instantiations) keep the LDS-broadcast version below.
-    constexpr bool MAPPLY = !KKOUT && NW == 1 && KR <= 50 && NV > 0 && NB <= 14;
     const int mrow_l = lane < KR ? lane : KR - 1;
     double cf[NV > 0 ? NV : 1];
     double out[NB];
-    double xv[NV > 0 ? NV : 1];                 // MAPPLY: x'_v of member `lane`
-    double xm_l = 0.0, xd_l = 0.0;             // MAPPLY: lane v < NV holds x-bar_v and the deterministic member of variable v
     if constexpr (MAPPLY) {
       // The broadcast version is LDS-latency-bound like the old warm-start product was (16 % of the wave time on C2,
       // PROF build).  Here V is parked in LDS 32 columns at a time ([col][row], like A in warm_start_product_mfma --
@@ -976,29 +995,55 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       //     exactly the B-operand layout of contraction step s = 8h + 4 il + reg of Out = V C (j = 4s + q): no exchange
       //   Out tile I (rows m = 4i + I): A operand V[4c + I][4s + q] = 4 consecutive doubles of LDS column 4s+q.
       // var_a of the RTPS factor is summed from the same accumulators, var_g from the B operands.
+      if (!solved) {
+        // No observations: V = I and every eigenvalue is (k-1)/rho (common_letkf.f90:89-107), so U = B, w-bar = 0 and
+        // T x' = sqrt(rho) x' in closed form.  (Besides saving these points the matrix work, this keeps g out of the
+        // merge of the two paths: as a 50-register phi it cost every SOLVED point ~15 serialised scratch-to-scratch
+        // copies, found in the ISA.)
+        out[0] = 0.0;
+        out[1] = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          out[2 + v] = sc1 * xv[v];
+          double cfv = 1.0;
+          if (A.relax_alpha != 0.0) {
+            cfv = 1.0 - A.relax_alpha;
+          } else if (A.relax_alpha_spread != 0.0) {
+            const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391
+            const double var_g = wave_sum(xv[v] * xv[v]);
+            const double var_a = var_g * uniform(sc2);
+            if (var_g > 0.0 && var_a > 0.0)
+              cfv = A.relax_alpha_spread * sqrt(var_g * parm / (var_a * km1)) - A.relax_alpha_spread + 1.0;
+          }
+          cf[v] = uniform(cfv);
+          if (A.rtps_out && lane == 0 && ((A.var_mask >> v) & 1u)) {
+            const bool skipv = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
+            A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cfv : 1.0;
+          }
+        }
+      } else {
+      // No predicates anywhere in the two products (hipcc wraps every predicated LDS read in its own exec-mask
+      // branch: 29 branches, ~100 v_readlane of spilled masks in the first version): B is stored 16 columns wide and
+      // 4 KS rows deep with zeros in the padding, so a contraction row >= KR or a column >= NB multiplies zero;
+      // eigen-columns j >= k have spectra (sc1, sc2) = 0, so whatever finite numbers U holds in their rows never
+      // reach C; rows m >= KR of Out are computed from stale LDS contents and dropped.
       constexpr int KS = (KR + 3) / 4;
+      constexpr int BR = 4 * KS;               // rows of the padded B
       double* vh = slice;                      // [32][KR]
-      double* bm = slice + 32 * KR;            // [KR][NBP]
-      double* scl = bm + KR * NBP;             // [64][2]: (1/lam, sqrt((k-1)/lam)) per eigen-column
+      double* bm = slice + 32 * KR;            // [BR][16]
+      double* scl = bm + BR * 16;              // [64][2]: (1/lam, sqrt((k-1)/lam)) per eigen-column
       const int q = wlane >> 4, c = wlane & 15;
       wave_lds_sync();
       {
-        const double* gp = g0 + moff;
+        if (lane < BR) {
+          double brow[16];
+          brow[0] = (lane < k) ? racc : 0.0;
+          brow[1] = (lane < k) ? rdacc : 0.0;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          xv[v] = (lane < k) ? *gp : 0.0;
-          gp += A.sv;
-        }
-        if (lane < NV) {
-          xm_l = g0[k * A.sm + lane * A.sv];
-          xd_l = A.det_run ? g0[(k + 1) * A.sm + lane * A.sv] : 0.0;
-        }
-        if (lane < KR) {
-          double* row = bm + lane * NBP;
-          *reinterpret_cast<double2*>(&row[0]) = double2{(lane < k) ? racc : 0.0, (lane < k) ? rdacc : 0.0};
+          for (int b = 2; b < 16; ++b) brow[b] = (b - 2 < NV) ? xv[b - 2 < NV ? b - 2 : 0] : 0.0;
+          double* row = bm + lane * 16;
 #pragma unroll
-          for (int v = 0; v < NV; v += 2)
-            *reinterpret_cast<double2*>(&row[2 + v]) = double2{xv[v], (v + 1 < NV) ? xv[v + 1] : 0.0};
+          for (int b = 0; b < 16; b += 2) *reinterpret_cast<double2*>(&row[b]) = double2{brow[b], brow[b + 1]};
         }
         *reinterpret_cast<double2*>(&scl[2 * lane]) = double2{sc2, sc1};
       }
@@ -1021,14 +1066,12 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
           accU[1] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int s_ = 0; s_ < KS; ++s_) {
-            const bool rok = (4 * s_ + 3 < KR) || (4 * s_ + q < KR);
-            const double bq = (rok && c < NBP) ? bm[(4 * s_ + q) * NBP + c] : 0.0;
+            const double bq = bm[(4 * s_ + q) * 16 + c];
             if (h == 0) vg = fma(bq, bq, vg);
 #pragma unroll
             for (int il = 0; il < 2; ++il) {
               if (32 * h + 16 * il < KR) {
-                const int jl = 16 * il + c;
-                const double a = (rok && 32 * h + jl < KR) ? vh[jl * KR + 4 * s_ + q] : 0.0;
+                const double a = vh[(16 * il + c) * KR + 4 * s_ + q];
                 accU[il] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, accU[il], 0, 0, 0);
               }
             }
@@ -1044,13 +1087,9 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
                 const double u = accU[il][reg];
                 va = fma(u * u, sc.x, va);
                 const double cv = u * (c < 2 ? sc.x : sc.y);
-                const bool jok = (4 * s_ + 3 < KR) || (j < KR);
                 const double* a = vh + (j - 32 * h) * KR + 4 * c;
-                double2 lo{0.0, 0.0}, hi{0.0, 0.0};
-                if (jok) {
-                  lo = *reinterpret_cast<const double2*>(a);
-                  hi = *reinterpret_cast<const double2*>(a + 2);
-                }
+                const double2 lo = *reinterpret_cast<const double2*>(a);
+                const double2 hi = *reinterpret_cast<const double2*>(a + 2);
                 accO[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(lo.x, cv, accO[0], 0, 0, 0);
                 accO[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(lo.y, cv, accO[1], 0, 0, 0);
                 accO[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(hi.x, cv, accO[2], 0, 0, 0);
@@ -1086,17 +1125,14 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       }
       // Out tiles -> lane m holds row m: register `reg` of tile I, lane (q, c) is Out[16 reg + 4 q + I][c]
       wave_lds_sync();
-      double* ob = slice;                      // [KR][NBP], on top of the V half
+      double* ob = slice;                      // [64][16], on top of the V half
 #pragma unroll
       for (int I = 0; I < 4; ++I)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int m = 16 * reg + 4 * q + I;
-          if (m < KR && c < NBP) ob[m * NBP + c] = accO[I][reg];
-        }
+        for (int reg = 0; reg < 4; ++reg) ob[(16 * reg + 4 * q + I) * 16 + c] = accO[I][reg];
       wave_lds_sync();
       {
-        const double* row = ob + (lane < KR ? lane : 0) * NBP;
+        const double* row = ob + lane * 16;
 #pragma unroll
         for (int b = 0; b < NB; b += 2) {
           const double2 o2 = *reinterpret_cast<const double2*>(&row[b]);
@@ -1105,6 +1141,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         }
       }
       wave_lds_sync();
+      }
     } else {
       // ------------------------------------------------------------ B = [r, r_det, x'_v] as bmat[m][NBP]; U = V^T B
       psync<NW>();
