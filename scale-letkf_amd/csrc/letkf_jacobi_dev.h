@@ -280,7 +280,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
         }
         ++pairs;
         quiet = pany<NW>(notconv) ? 0 : quiet + 1;
-        quiet2 = pany<NW>(notconv2) ? 0 : quiet2 + 1;
+        if constexpr (EARLY) quiet2 = pany<NW>(notconv2) ? 0 : quiet2 + 1;
         done = quiet >= S || (EARLY && quiet2 >= S);
       }
     }

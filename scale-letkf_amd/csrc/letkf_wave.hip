@@ -192,6 +192,11 @@ __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const dou
 // (tools/ubench_readlane.hip: 5.6 ns per triple against 2.35 ns per bare v_fma_f64) cost one sweep; with the
 // row-split Jacobi (no LDS in its steps) the LDS broadcast is the cheapest again.
 // ---------------------------------------------------------------------------------------------
+// early stop of the eigensolver (letkf_jacobi_dev.h) for one-wave points only: with two waves the second vote is a
+// workgroup barrier per step pair and costs more than the 0.5 sweep it saves (k = 64: 852 k against 948 k solves/s)
+#ifndef LETKF_EARLY_NW
+#define LETKF_EARLY_NW(nw) ((nw) == 1)
+#endif
 #ifndef LETKF_GRAM_DEPTH
 #define LETKF_GRAM_DEPTH 3
 #endif
@@ -523,7 +528,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     bool solved = false;
     if (n != 0) {
       constexpr int NBLK = (KR + 2 + 15) / 16;                 // member blocks incl. the 2 augmented columns
-      constexpr int KMIN = wave_kmin(KR, NW);                  // launch_wave_kernel: this instantiation serves KMIN <= k <= KR
+      constexpr int KMIN = (NW == 1) ? wave_kmin(KR, NW) : 1;  // launch_wave_kernel: this instantiation serves wave_kmin <= k <= KR
       constexpr int NTILE = NBLK * (NBLK + 1) / 2;
       v4d acc[NTILE];
 #pragma unroll
@@ -602,23 +607,45 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         //    all loads sit at the top of the iteration that consumes them;
         //  * the loaded rows are routed through one just before their use: otherwise the multiplies of the LATER steps
         //    are hoisted to the top of the iteration and wait for the youngest loads there.
-        constexpr int PD = kGramDepth;
-        Step ts[PD];
-#pragma unroll
-        for (int u = 0; u < PD; ++u) {
-          fetch(wvp + u * NW, ts[u]);
-          asm volatile("" ::: "memory");         // (same order as in the loop: the waits are counted statically)
-        }
-        auto pin = [&](Step& t) {
-#pragma unroll
-          for (int I = 0; I < NBLK; ++I) asm volatile("" : "+v"(t.f[I])::"memory");
-        };
-        for (int c = wvp; c < nch; c += PD * NW) {
+        if constexpr (NW == 1) {
+          constexpr int PD = kGramDepth;
+          Step ts[PD];
 #pragma unroll
           for (int u = 0; u < PD; ++u) {
-            pin(ts[u]);
-            if (u == 0 || c + u * NW < nch) mma(ts[u]);   // (wave-uniform; only the matrix instructions are skipped)
-            fetch(c + (PD + u) * NW, ts[u]);
+            fetch(wvp + u * NW, ts[u]);
+            asm volatile("" ::: "memory");       // (same order as in the loop: the waits are counted statically)
+          }
+          auto pin = [&](Step& t) {
+#pragma unroll
+            for (int I = 0; I < NBLK; ++I) asm volatile("" : "+v"(t.f[I])::"memory");
+          };
+          for (int c = wvp; c < nch; c += PD * NW) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+              pin(ts[u]);
+              if (u == 0 || c + u * NW < nch) mma(ts[u]);   // (wave-uniform; only the matrix instructions are skipped)
+              fetch(c + (PD + u) * NW, ts[u]);
+            }
+          }
+        } else {
+          // two-wave points (up to 7 member blocks, part of the register file in AGPRs) keep the plain loop; their
+          // register allocation is fragile -- the compile-time full blocks (KMIN) alone cost k = 100 a quarter of its
+          // speed (162 k -> 116 k solves/s, A/B on one box), so none of the one-wave changes is applied to them
+          Step t0, t1, t2;
+          fetch(wvp, t0);
+          fetch(wvp + NW, t1);
+          fetch(wvp + 2 * NW, t2);
+          for (int c = wvp; c < nch; c += 3 * NW) {
+            mma(t0);
+            fetch(c + 3 * NW, t0);
+            if (c + NW < nch) {
+              mma(t1);
+              fetch(c + 4 * NW, t1);
+            }
+            if (c + 2 * NW < nch) {
+              mma(t2);
+              fetch(c + 5 * NW, t2);
+            }
           }
         }
       };
@@ -899,7 +926,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         }
       }
       PROF_MARK(3)
-      sweeps = jacobi_split<KR, NW>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
+      sweeps = jacobi_split<KR, NW, 24, LETKF_EARLY_NW(NW)>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
       PROF_MARK(4)
 
       double ss = 0.0;
