@@ -268,21 +268,30 @@ __device__ __forceinline__ int jacobi_block_mfma(double* __restrict__ G, const i
         v4d tII{0.0, 0.0, 0.0, 0.0}, tIJ{0.0, 0.0, 0.0, 0.0}, tJJ{0.0, 0.0, 0.0, 0.0};
         {
           // four 4-row steps in flight (the rows come from L2: one step of MFMAs does not cover a load)
+          // (every load is unconditional, from a clamped address, and zeroed afterwards by a select: written as
+          // `cond ? g[rn] : 0.0` hipcc wraps each load in its own exec-mask branch and, unable to count the loads in
+          // flight across the branches, waits s_waitcnt vmcnt(0) in front of every step -- found in the ISA)
           constexpr int PD = 4;
           double yI[PD], yJ[PD];
+          const int kl = k - 1;
 #pragma unroll
           for (int u = 0; u < PD; ++u) {
             const int rn = 4 * u + q;
-            yI[u] = (okI && rn < k) ? gI[rn] : 0.0;
-            yJ[u] = (okJ && rn < k) ? gJ[rn] : 0.0;
+            yI[u] = gI[min(rn, kl)];
+            yJ[u] = gJ[min(rn, kl)];
+            asm volatile("" ::: "memory");
           }
           for (int r0 = 0; r0 < k; r0 += 4 * PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
-              const double cI = yI[u], cJ = yJ[u];
-              const int rn = r0 + 4 * (PD + u) + q;
-              yI[u] = (okI && rn < k) ? gI[rn] : 0.0;
-              yJ[u] = (okJ && rn < k) ? gJ[rn] : 0.0;
+              // (the raw rows are routed through an empty asm right here: placed next to the load, the select makes the
+              // wave wait for each load pair in turn -- four L2 latencies per four steps)
+              asm volatile("" : "+v"(yI[u]), "+v"(yJ[u])::"memory");
+              const int rc = r0 + 4 * u + q;
+              const double cI = (okI && rc < k) ? yI[u] : 0.0, cJ = (okJ && rc < k) ? yJ[u] : 0.0;
+              const int rn = rc + 4 * PD;
+              yI[u] = gI[min(rn, kl)];
+              yJ[u] = gJ[min(rn, kl)];
               tII = __builtin_amdgcn_mfma_f64_16x16x4f64(cI, cI, tII, 0, 0, 0);
               tIJ = __builtin_amdgcn_mfma_f64_16x16x4f64(cI, cJ, tIJ, 0, 0, 0);
               tJJ = __builtin_amdgcn_mfma_f64_16x16x4f64(cJ, cJ, tJJ, 0, 0, 0);
@@ -369,7 +378,9 @@ __device__ __forceinline__ int jacobi_block_mfma(double* __restrict__ G, const i
 #pragma unroll
           for (int s_ = 0; s_ < 8; ++s_) {
             const int col = (s_ < 4) ? 16 * I + 4 * s_ + q : 16 * J + 4 * (s_ - 4) + q;
-            a[s_] = (row < k && col < k) ? G[(size_t)col * ldg + row] : 0.0;
+            // unconditional, from a clamped address, and NOT zeroed: rows >= k are never stored, and a phantom column
+            // (>= k) only meets the exact zeros of V's phantom rows (those columns are never rotated)
+            a[s_] = G[(size_t)min(col, k - 1) * ldg + min(row, k - 1)];
           }
         };
         double a0[8], a1[8];
