@@ -298,6 +298,10 @@ __device__ __forceinline__ void warm_start_product(double (&g)[KR], const double
 // (lane = 16 q + c; the blocks interleave rows / columns with stride 4 instead of covering 16 contiguous ones, so that
 // both operands of a step are one 32-byte read per lane).  Accumulator (I, J), register `reg` of lane (q, c) is
 // G0[16 reg + 4q + I][4c + J]; the tiles go back to "lane j owns column j" through the same LDS region.
+typedef __attribute__((address_space(1))) double gdouble;
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) v2d_t gdouble2;
+
 template <int KR>
 __device__ __forceinline__ void warm_start_product_mfma(double (&g)[KR], const double* __restrict__ qslot, double* cb) {
   static_assert(KR % 2 == 0 && KR <= 50, "A must fit the LDS slice");
@@ -308,14 +312,19 @@ __device__ __forceinline__ void warm_start_product_mfma(double (&g)[KR], const d
   struct Quad {
     double2 lo, hi;
   };
-  const double* qp = qslot + q * 64 + 4 * c;
-  asm volatile("" : "+v"(qp));
+  unsigned long long qaddr = reinterpret_cast<unsigned long long>(qslot + q * 64 + 4 * c);
+  asm volatile("" : "+v"(qaddr));
+  const gdouble2* qp = (const gdouble2*)qaddr;   // integer -> global pointer: no generic pointer in between
   auto ldq = [&](const int s) {
     Quad t{double2{0.0, 0.0}, double2{0.0, 0.0}};
     if (4 * s + 3 < KR || 4 * s + q < KR) {    // rows >= KR do not exist in the slot
-      const double* a = qp + (size_t)s * 256;
-      t.lo = *reinterpret_cast<const double2*>(a);
-      t.hi = *reinterpret_cast<const double2*>(a + 2);
+      // (global address space spelled out: behind the laundering asm the pointer is generic, hipcc emits flat_load,
+      // flat operations count in lgkmcnt as well and return out of order, so every LDS wait in this loop became
+      // lgkmcnt(0) and drained the workspace loads in flight)
+      const gdouble2* a = qp + (size_t)s * 128;
+      const v2d_t lo = a[0], hi = a[1];
+      t.lo = double2{lo.x, lo.y};
+      t.hi = double2{hi.x, hi.y};
     }
     return t;
   };
@@ -927,6 +936,9 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       }
       PROF_MARK(3)
       sweeps = jacobi_split<KR, NW, 24, LETKF_EARLY_NW(NW)>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
+      // per-lane values that were spilled around the eigensolve come back HERE, in one batch: reloaded lazily, each
+      // scratch load sits behind the 50 workspace stores below and its s_waitcnt vmcnt(0) waits for all of them
+      asm volatile("" : "+v"(racc), "+v"(rdacc), "+v"(moff));
       PROF_MARK(4)
 
       double ss = 0.0;
@@ -983,12 +995,12 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       if (uws && (solved || !MAPPLY) && !(A.warm_dbg & 2)) {
         // (the pointer is laundered every 8 rows: otherwise all KR row addresses are hoisted out of the point loop
         // as 64-bit values, spilled, and reloaded one by one in front of each store -- same serialisation)
-        double* p = uws;
+        unsigned long long pa = reinterpret_cast<unsigned long long>(uws);
 #pragma unroll
         for (int r = 0; r < KR; ++r) {
-          if ((r & 7) == 0) asm volatile("" : "+v"(p));
-          p[(size_t)(r & 7) * NL] = g[r];
-          if ((r & 7) == 7) p += 8 * NL;
+          if ((r & 7) == 0) asm volatile("" : "+v"(pa));
+          ((gdouble*)pa)[(size_t)(r & 7) * NL] = g[r];   // global_store, not flat_store: see warm_start_product_mfma
+          if ((r & 7) == 7) pa += 8 * NL * sizeof(double);
         }
       }
     }
