@@ -31,6 +31,9 @@ CONFIGS = {
     # BASELINE configs[2] (C3: k = 320) on a small grid: the large-k path (block Jacobi on the matrix cores)
     "C3-mini": dict(nx=24, ny=24, nz=6, k=320, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2900.0, err=3.0,
                     ztop=18000.0, seed=20240613),
+    # BASELINE configs[3] (C4: k = 50, radar-like dense obs, ~5000 local obs/point) on a small grid: the Gram dominates
+    "C4-mini": dict(nx=32, ny=32, nz=8, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=600.0, err=3.0,
+                    ztop=18000.0, seed=20240614),
     "C1": dict(nx=40, ny=40, nz=30, k=20, dx=15000.0, hloc=120000.0, vloc=4000.0, spacing=30000.0, err=3.0,
                ztop=18000.0, seed=20240608),
 }
