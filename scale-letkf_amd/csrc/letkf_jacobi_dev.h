@@ -170,7 +170,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
     // `quiet` counts consecutive step pairs in which no visited column pair exceeded the tolerance; S of them in a
     // row are one full cycle of the ordering (every column pair seen once) whatever step it started at, so the
     // iteration stops S step pairs after the last significant rotation, not at the next sweep boundary.
-    int quiet = 0, quiet2 = 0, pairs = 0;
+    int quiet = 0, quiet2 = 0, pairs = 0, vph = 0;
     bool done = false;
     for (; sweep < max_sweep && !done; ++sweep) {
       // refresh: fold the scales back, recompute the squared norms
@@ -279,8 +279,21 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           }
         }
         ++pairs;
-        quiet = pany<NW>(notconv) ? 0 : quiet + 1;
-        if constexpr (EARLY) quiet2 = pany<NW>(notconv2) ? 0 : quiet2 + 1;
+        if constexpr (NW == 1 || !EARLY) {
+          quiet = pany<NW>(notconv) ? 0 : quiet + 1;
+          if constexpr (EARLY) quiet2 = pany<NW>(notconv2) ? 0 : quiet2 + 1;
+        } else {
+          // two waves, two votes, ONE barrier: each wave leaves its two ballots in LDS (behind the 2 x 128 doubles of
+          // the inner-product exchange; double-buffered like it)
+          int* fl = reinterpret_cast<int*>(lds + 256);
+          const int mine = (__any(notconv) ? 1 : 0) | (__any(notconv2) ? 2 : 0);
+          if ((threadIdx.x & 63) == 0) fl[2 * vph + ((threadIdx.x >> 6) & 1)] = mine;
+          __syncthreads();
+          const int both = fl[2 * vph] | fl[2 * vph + 1];
+          vph ^= 1;
+          quiet = (both & 1) ? 0 : quiet + 1;
+          quiet2 = (both & 2) ? 0 : quiet2 + 1;
+        }
         done = quiet >= S || (EARLY && quiet2 >= S);
       }
     }

@@ -192,10 +192,11 @@ __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const dou
 // (tools/ubench_readlane.hip: 5.6 ns per triple against 2.35 ns per bare v_fma_f64) cost one sweep; with the
 // row-split Jacobi (no LDS in its steps) the LDS broadcast is the cheapest again.
 // ---------------------------------------------------------------------------------------------
-// early stop of the eigensolver (letkf_jacobi_dev.h) for one-wave points only: with two waves the second vote is a
-// workgroup barrier per step pair and costs more than the 0.5 sweep it saves (k = 64: 852 k against 948 k solves/s)
+// early stop of the eigensolver (letkf_jacobi_dev.h): one-wave points, and two-wave points of the 64-column
+// instantiation (both ballots ride one barrier: k = 64 1.00 M against 0.93 M solves/s).  Not the 80- and 100-column
+// ones: at k = 100 the same change costs 8 % (A/B on one box) -- their register allocation is fragile, see the Gram.
 #ifndef LETKF_EARLY_NW
-#define LETKF_EARLY_NW(nw) ((nw) == 1)
+#define LETKF_EARLY_NW(kr, nw) ((nw) == 1 || (kr) <= 64)
 #endif
 #ifndef LETKF_GRAM_DEPTH
 #define LETKF_GRAM_DEPTH 3
@@ -935,7 +936,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         }
       }
       PROF_MARK(3)
-      sweeps = jacobi_split<KR, NW, 24, LETKF_EARLY_NW(NW)>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
+      sweeps = jacobi_split<KR, NW, 24, LETKF_EARLY_NW(KR, NW)>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
       // per-lane values that were spilled around the eigensolve come back HERE, in one batch: reloaded lazily, each
       // scratch load sits behind the 50 workspace stores below and its s_waitcnt vmcnt(0) waits for all of them
       asm volatile("" : "+v"(racc), "+v"(rdacc), "+v"(moff));
