@@ -411,6 +411,7 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
                                                          // exchange slots (64 NW * 24 doubles) span tile + bmat
   int tot = tile + bmat + cb + small + 8;                // + 4 doubles of reduction scratch (two-wave points)
   if (NW == 1 && KR <= 50 && tot < (KR - 1) * KR + 64) tot = (KR - 1) * KR + 64;   // A whole: warm_start_product_mfma
+  if (NW == 1 && KR < 32 && tot < 32 * KR + 64 * ((KR + 3) / 4) + 128 + 1024) tot = 32 * KR + 64 * ((KR + 3) / 4) + 128 + 1024;   // + [64][16] output buffer
   if (NW == 1 && KR <= 50 && tot < 32 * KR + 64 * ((KR + 3) / 4) + 128)               // half of V + padded B + spectra: the apply phase on the matrix cores
     tot = 32 * KR + 64 * ((KR + 3) / 4) + 128;
   return (tot + 1) & ~1;
@@ -965,6 +966,8 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     // apply phase on the matrix cores (see below); these instantiations also give points without observations a
     // closed-form path that never touches g
     constexpr bool MAPPLY = !KKOUT && NW == 1 && KR <= 50 && NV > 0 && NB <= 14;
+    constexpr int kBmRows = 4 * ((KR + 3) / 4), kBmOff = 32 * KR;   // MAPPLY: padded B [kBmRows][16] in the wave's LDS slice
+    constexpr int kObOff = (32 * KR >= 1024) ? 0 : kBmOff + 16 * kBmRows + 128;   // MAPPLY: output transposition buffer [64][16], clear of B
     if constexpr (!MAPPLY) {
       if (!solved) {
 #pragma unroll
@@ -1042,6 +1045,12 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         // copies, found in the ISA.)
         out[0] = 0.0;
         out[1] = 0.0;
+        wave_lds_sync();
+        if (lane < kBmRows) {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) slice[kBmOff + lane * 16 + 2 + v] = xv[v];
+        }
+        wave_lds_sync();
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           out[2 + v] = sc1 * xv[v];
@@ -1165,7 +1174,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       }
       // Out tiles -> lane m holds row m: register `reg` of tile I, lane (q, c) is Out[16 reg + 4 q + I][c]
       wave_lds_sync();
-      double* ob = slice;                      // [64][16], on top of the V half
+      double* ob = slice + kObOff;             // [64][16], on top of the V half (behind B and the spectra when the half is smaller)
 #pragma unroll
       for (int I = 0; I < 4; ++I)
 #pragma unroll
@@ -1258,7 +1267,11 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
         double x, xm, xdt;
         if constexpr (MAPPLY) {
-          x = xv[v];
+          // x' comes back from the LDS copy of B (it survives the output transposition): keeping the 22 registers of xv
+          // alive through the matrix phase made hipcc spill LDS addresses there -- a scratch round trip in front of
+          // every MFMA step of the U product (PROF build ISA)
+          const double xl = slice[kBmOff + (lane < kBmRows ? lane : kBmRows - 1) * 16 + 2 + v];
+          x = (lane < k) ? xl : 0.0;
           xm = readlane_d(xm_l, v);
           xdt = readlane_d(xd_l, v);
         } else {
