@@ -1081,7 +1081,11 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       double* vh = slice;                      // [32][KR]
       double* bm = slice + 32 * KR;            // [BR][16]
       double* scl = bm + BR * 16;              // [64][2]: (1/lam, sqrt((k-1)/lam)) per eigen-column
-      const int q = wlane >> 4, c = wlane & 15;
+      // (q and c are laundered: they are the same for every point of the wave's run, so hipcc hoists the ~40 LDS
+      // addresses built from them out of the point loop, keeps them in scratch, and reloads one -- a scratch round
+      // trip -- in front of every MFMA step; found in the ISA)
+      int q = wlane >> 4, c = wlane & 15;
+      asm volatile("" : "+v"(q), "+v"(c));
       wave_lds_sync();
       {
         if (lane < BR) {
