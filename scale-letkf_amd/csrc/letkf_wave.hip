@@ -544,7 +544,8 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
       v4d acc[NTILE];
 #pragma unroll
       for (int t = 0; t < NTILE; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
-      const int q = wlane >> 4, c16 = wlane & 15;
+      int q = wlane >> 4, c16 = wlane & 15;
+      asm volatile("" : "+v"(q), "+v"(c16));   // (not loop-invariant for hipcc: see the apply phase)
 
       // Two phases per batch of kSC observations, so that the per-observation scalars are computed ONCE (lane = obs,
       // coalesced reads of the CSR slice, all gathers of a batch in flight together) instead of 16 times over in
