@@ -143,7 +143,8 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
   constexpr int H = KR / 2;
   static_assert(RC % 2 == 0, "RC rows per conversion chunk: RC * 64 NW doubles of LDS");
   constexpr int NL = 64 * NW;
-  const int lane = threadIdx.x & (NL - 1);
+  int lane = threadIdx.x & (NL - 1);
+  if constexpr (NW == 2) asm volatile("" : "+v"(lane));   // (two-wave points, see letkf_wave_kernel: nothing built from the lane number may be hoisted out of the caller's loop)
   const int slot = (NW == 1) ? (lane & 31) : (lane & 63), par = (NW == 1) ? (lane >> 5) : (lane >> 6);
   int ph = 0;
   const int ncol = (k + 1) & ~1;               // an odd k gets one zero column as an extra (inert) participant

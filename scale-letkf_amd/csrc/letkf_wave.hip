@@ -135,7 +135,8 @@ template <int KR, int NB, int NW>
 __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const double (&crow)[NB], double (&out)[NB],
                                              const int k, double* vbuf, double* cbuf) {
   constexpr int NBP = (NB + 1) & ~1;
-  const int lane = threadIdx.x & (64 * NW - 1);
+  int lane = threadIdx.x & (64 * NW - 1);
+  if constexpr (NW == 2) asm volatile("" : "+v"(lane));   // (two-wave points: see the point loop of letkf_wave_kernel)
 #pragma unroll
   for (int b = 0; b < NB; ++b) out[b] = 0.0;
   const int ncol = (k + 1) & ~1;                 // columns live in lanes [0, ncol) (see jacobi_split)
@@ -221,7 +222,8 @@ __device__ __forceinline__ void warm_start_product(double (&g)[KR], const double
   constexpr int NL = 64 * NW;
   constexpr int NG = (KR + 7) / 8;
   static_assert(NG <= 13, "pin_rows8 dispatch below");
-  const int lane = threadIdx.x & (NL - 1);
+  int lane = threadIdx.x & (NL - 1);
+  if constexpr (NW == 2) asm volatile("" : "+v"(lane));   // (two-wave points: see the point loop of letkf_wave_kernel)
   const int ncol = (k + 1) & ~1;
   double out[KR];
 #pragma unroll
@@ -438,8 +440,8 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
   constexpr int NB = NV + 2;
   constexpr int NBP = (NB + 1) & ~1;
   constexpr int NL = 64 * NW;                 // lanes per point
-  const int lane = threadIdx.x & (NL - 1);    // lane of the point: column index in the eigen phase, member index after
-  const int wlane = threadIdx.x & 63;         // lane inside the wavefront (MFMA operand layout)
+  int lane = threadIdx.x & (NL - 1);          // lane of the point: column index in the eigen phase, member index after
+  int wlane = threadIdx.x & 63;               // lane inside the wavefront (MFMA operand layout)
   const int wvp = (NW == 1) ? 0 : (threadIdx.x >> 6);   // wave inside the point
   const int wv = (NW == 1) ? (threadIdx.x >> 6) : 0;    // point slot inside the workgroup
   const int k = A.k;
@@ -479,6 +481,13 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
    for (int ir = 0; ir < run_len; ++ir) {
     const long pt = run0 + ir;
     if (pt >= A.npts) break;
+    // Everything built from the lane number is the same for every point of the run, so hipcc hoists it out of this
+    // loop -- dozens of LDS addresses -- cannot keep it in registers across the eigensolve, and reloads it from scratch
+    // one dword at a time, each reload a round trip in front of its use.  Laundering the lane numbers keeps the address
+    // arithmetic (one or two integer instructions) where it is used.  Measured (A/B on one box): in the apply phase
+    // -0.8 % of the C2 time, in the Gram / tile transposition -2.2 % and k = 100 197 k -> 280 k solves/s; everywhere, as
+    // here, another +13 % at k = 100 (316 k) but -1 % on C2 -- so the blanket version is for two-wave points only.
+    if constexpr (NW == 2) asm volatile("" : "+v"(lane), "+v"(wlane));
     long o0 = 0;
     int n = 0;
     double beta = 1.0;
