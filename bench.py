@@ -37,6 +37,23 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(affinity, cgroup quota, 16 = the box's CPU share)")
     args = ap.parse_args()
 
+    # --gpus N is the contract; WORLD_SIZE is how the ranks learn it.  Started bare with N > 1 (no torchrun), launch
+    # the N ranks as a CHILD process -- before torch or HIP is touched in this one -- and hand back its exit code.
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and env_world == 1 and "RANK" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+    if env_world != max(args.gpus, 1):
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with "
+                 f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -57,7 +74,10 @@ def main():
     n_gpus = world
 
     pkg = load_package()
-    pkg.build()
+    if rank == 0:
+        pkg.build()                 # one rank runs make; the others wait (no race on a stale .so)
+    if world > 1:
+        dist.barrier()
     stream = torch.cuda.current_stream()
     ctx = pkg.Context(local_rank, stream.cuda_stream)
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LETKF_AMD_ABI_VERSION 3
+#define LETKF_AMD_ABI_VERSION 4
 
 /* host-side errors (function return values) */
 #define LETKF_OK 0
@@ -392,6 +392,53 @@ int letkf_additive_inflation_dev(letkf_ctx *ctx, int32_t k, int32_t nv, int64_t 
 int letkf_addinfl_weight_dev(letkf_ctx *ctx, int64_t nij1, const double *rig, const double *rjg, int64_t nob,
                              const double *ob_ri, const double *ob_rj, double dx, double dy, double hori_loc,
                              double *weight);
+
+/*---------------------------------------------------------------------------
+ * (7) The set-up das_letkf does before its loop,
+ *     scale/letkf/letkf_tools.f90:130-267 and relax_beta :1911-1948.
+ *     The three table derivations are HOST functions (tens of integers, once per analysis; they need no device and
+ *     return LETKF_OK / LETKF_E_INVALID); relax_beta and the inflation field are device passes over the points.
+ *-------------------------------------------------------------------------*/
+/* Variable-localisation classes, :130-157.  var_local: column-major var_local(nvar, nlt) as the reference fills it
+ * from VAR_LOCAL_UV .. VAR_LOCAL_H08 (:130-138; nlt = 9).  Variables whose rows agree within tiny() share a class:
+ * n2nc[n] = 0-based class of variable n (var_local_n2nc - 1), n2n[n] = 0-based first variable of that class
+ * (var_local_n2n - 1), *nclass = var_local_n2nc_max.  One letkf_das_points_dev call per class with var_mask = the
+ * class's variables and letkf_search_tables.varloc[ic] = var_local(n2n, uid_obs_varlocal(elm of ctype ic)). */
+int letkf_var_local_classes(int32_t nvar, int32_t nlt, const double *var_local, int32_t *n2nc, int32_t *n2n,
+                            int32_t *nclass);
+
+/* Merge groups of the obs-number limit, :167-192.  elm_u_ctype / typ_ctype [nctype]: 1-based uid_obs and report type
+ * of every combined type (letkf_obs.f90:35-41); ctype_merge: column-major ctype_merge(nid_obs, nobtype), > 0 = merge
+ * class (the reference sets (uid_obs(id_radar_ref_obs), 22) = (uid_obs(id_radar_ref_zero_obs), 22) = 1).  Output in the
+ * form letkf_search_tables takes: group g owns group_member[group_start[g] .. group_start[g+1]), 0-based ctypes, the
+ * master (whose MAX_NOBS_PER_GRID and search radius apply, :1434-1436) first; groups in the order of their masters. */
+int letkf_ctype_merge_groups(int32_t nctype, const int32_t *elm_u_ctype, const int32_t *typ_ctype, int32_t nid_obs,
+                             int32_t nobtype, const int32_t *ctype_merge, int32_t *group_start, int32_t *group_member,
+                             int32_t *ngroup);
+
+/* radar_only, :197-203: 1 when every combined type is of report type typ_radar (22 = 'PHARAD',
+ * common_obs_scale.f90:87-92), else 0 (also for nctype = 0 the reference leaves .true.: returned as 1). */
+int letkf_radar_only(int32_t nctype, const int32_t *typ_ctype, int32_t typ_radar);
+
+typedef struct {
+  int32_t radar_only;            /* letkf_radar_only() */
+  int32_t ihalo, jhalo;          /* IHALO, JHALO */
+  int32_t nlong, nlatg;          /* global interior size (common_scale.f90:117-121) */
+  int32_t reserved0;
+  double radar_zmax;             /* RADAR_ZMAX */
+  double vert_local_radar;       /* max(VERT_LOCAL(22), VERT_LOCAL_RADAR_VR) */
+  double boundary_buffer_width;  /* BOUNDARY_BUFFER_WIDTH, <= 0 = off */
+  double dx, dy;                 /* DX, DY */
+} letkf_beta_params;
+
+/* relax_beta, :1911-1948, for the points p = ij + nij1*lev: beta[p] from rig[ij], rjg[ij] (rig1, rjg1) and
+ * hgt[p] (hgt1(ij, ilev)); the argument `beta` of letkf_das_points_dev.  All device pointers. */
+int letkf_relax_beta_dev(letkf_ctx *ctx, const letkf_beta_params *p, int64_t nij1, int32_t nlev, const double *rig,
+                         const double *rjg, const double *hgt, double *beta);
+
+/* Multiplicative-inflation field, :237-267: infl_mul > 0 -> work3d = INFL_MUL, else work3d keeps the field the caller
+ * read in (INFL_MUL_IN_BASENAME); then work3d = max(work3d, INFL_MUL_MIN) when infl_mul_min > 0.  n = nij1*nlev*nv3d. */
+int letkf_infl_init_dev(letkf_ctx *ctx, int64_t n, double *work3d, double infl_mul, double infl_mul_min);
 
 /* Kernel timing helper for bench.py: average duration (ms) of the last
  * letkf_das_points_dev / letkf_core_batch_dev launches measured with HIP events on the

@@ -429,6 +429,88 @@ double orc_relax_beta(const orc_beta_params *bp, double ri, double rj, double rz
   return beta;
 }
 
+/* scale/letkf/letkf_tools.f90:139-157.  The reference indexes var_local with the CLASS number var_local_n2nc(i)
+ * (:145) and var_local_n2n with var_local_n2nc(n) (:147); restated as written. */
+void orc_var_local_classes(int nvar, int nlt, const double *var_local, int32_t *n2nc, int32_t *n2n, int32_t *nclass) {
+  /* 1-based work arrays, exactly the reference's */
+  int *c1 = (int *)calloc((size_t)nvar + 1, sizeof(int));
+  int *r1 = (int *)calloc((size_t)nvar + 1, sizeof(int));
+  int ncmax = 1;
+  c1[1] = 1;
+  r1[1] = 1;
+  for (int n = 2; n <= nvar; ++n) {
+    int found = 0;
+    for (int i = 1; i <= ncmax; ++i) {
+      double mx = 0.0;
+      for (int t = 0; t < nlt; ++t) {
+        double d = fabs(var_local[(c1[i] - 1) + (size_t)nvar * t] - var_local[(n - 1) + (size_t)nvar * t]);
+        if (d > mx) mx = d;
+      }
+      if (mx < DBL_MIN) { /* tiny(var_local) */
+        c1[n] = c1[i];
+        r1[n] = r1[c1[n]];
+        found = 1;
+        break;
+      }
+    }
+    if (!found) {
+      ncmax = ncmax + 1;
+      c1[n] = ncmax;
+      r1[n] = n;
+    }
+  }
+  for (int n = 1; n <= nvar; ++n) {
+    n2nc[n - 1] = c1[n] - 1;
+    n2n[n - 1] = r1[n] - 1;
+  }
+  *nclass = ncmax;
+  free(c1);
+  free(r1);
+}
+
+/* scale/letkf/letkf_tools.f90:167-192 */
+void orc_ctype_merge(int nctype, const int32_t *elm_u_ctype, const int32_t *typ_ctype, int nid_obs, int nobtype,
+                     const int32_t *ctype_merge, int32_t *n_merge, int32_t *ic_merge) {
+  (void)nobtype;
+#define CMRG(ic) ctype_merge[(elm_u_ctype[ic] - 1) + (size_t)nid_obs * (typ_ctype[ic] - 1)]
+  for (int ic = 0; ic < nctype; ++ic) n_merge[ic] = 1;
+  for (int ic = 0; ic < nctype; ++ic) {
+    if (n_merge[ic] > 0) {
+      ic_merge[(size_t)ic * nctype + 0] = ic;
+      if (CMRG(ic) > 0) {
+        for (int ic2 = ic + 1; ic2 < nctype; ++ic2) {
+          if (CMRG(ic2) == CMRG(ic)) {
+            n_merge[ic] = n_merge[ic] + 1;
+            ic_merge[(size_t)ic * nctype + n_merge[ic] - 1] = ic2;
+            n_merge[ic2] = 0;
+          }
+        }
+      }
+    }
+  }
+#undef CMRG
+}
+
+/* scale/letkf/letkf_tools.f90:197-203 */
+int orc_radar_only(int nctype, const int32_t *typ_ctype, int typ_radar) {
+  int radar_only = 1;
+  for (int ic = 0; ic < nctype; ++ic) {
+    if (typ_ctype[ic] != typ_radar) {
+      radar_only = 0;
+      break;
+    }
+  }
+  return radar_only;
+}
+
+/* scale/letkf/letkf_tools.f90:237-267 (the read-in branch leaves the caller's field in place) */
+void orc_infl_init(int64_t n, double *work3d, double infl_mul, double infl_mul_min) {
+  if (infl_mul > 0.0)
+    for (int64_t i = 0; i < n; ++i) work3d[i] = infl_mul;
+  if (infl_mul_min > 0.0)
+    for (int64_t i = 0; i < n; ++i) work3d[i] = work3d[i] > infl_mul_min ? work3d[i] : infl_mul_min;
+}
+
 /* scale/letkf/letkf_tools.f90:1953-1966 */
 void orc_weight_rtpp(int k, double relax_alpha, const double *w, double infl, double *wrlx) {
   for (size_t i = 0; i < (size_t)k * (size_t)k; ++i) wrlx[i] = (1.0 - relax_alpha) * w[i];

@@ -119,6 +119,14 @@ def scale_rm_consts(clamp=True):
     return c
 
 
+class BetaParams(C.Structure):
+    """letkf_beta_params (include/letkf_amd.h section 7)"""
+    _fields_ = [("radar_only", C.c_int32), ("ihalo", C.c_int32), ("jhalo", C.c_int32), ("nlong", C.c_int32),
+                ("nlatg", C.c_int32), ("reserved0", C.c_int32), ("radar_zmax", C.c_double),
+                ("vert_local_radar", C.c_double), ("boundary_buffer_width", C.c_double), ("dx", C.c_double),
+                ("dy", C.c_double)]
+
+
 EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", "letkf_ctx_destroy",
            "letkf_ctx_set_stream", "letkf_ctx_synchronize", "letkf_core_c", "letkf_core_batch_dev",
            "letkf_das_points_dev", "letkf_das_points_fused_dev", "letkf_obs_search_dev", "letkf_obs_search_columns_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
@@ -126,6 +134,8 @@ EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", 
            "letkf_obs_departure_dev", "letkf_obs_mesh_sort_dev", "letkf_obs_halo_plan_dev",
            "letkf_obs_gather_rows_dev", "letkf_obs_gather_i32_dev", "letkf_monit_dep_dev",
            "letkf_additive_inflation_dev", "letkf_addinfl_weight_dev",
+           "letkf_var_local_classes", "letkf_ctype_merge_groups", "letkf_radar_only", "letkf_relax_beta_dev",
+           "letkf_infl_init_dev",
            "letkf_ctx_timing_enable", "letkf_ctx_timing_read"]
 
 _lib = None
@@ -341,6 +351,15 @@ class Context:
                                                      C.c_double(dx), C.c_double(dy), C.c_double(hori_loc), _ptr(w)))
         return w
 
+    # ---- (7) das_letkf set-up
+    def relax_beta(self, params, nij1, nlev, rig, rjg, hgt, beta):
+        self._check(self._l.letkf_relax_beta_dev(self._c, C.byref(params), C.c_int64(nij1), C.c_int32(nlev), _ptr(rig),
+                                                 _ptr(rjg), _ptr(hgt), _ptr(beta)))
+
+    def infl_init(self, work3d, infl_mul, infl_mul_min):
+        self._check(self._l.letkf_infl_init_dev(self._c, C.c_int64(work3d.numel()), _ptr(work3d),
+                                                C.c_double(infl_mul), C.c_double(infl_mul_min)))
+
     # ---- (4) the steps either side of the loop
     def state_trans(self, consts, nlev, nlon, nlat, nv3d, v3dg, inverse=False):
         self._check(self._l.letkf_state_trans_dev(self._c, C.byref(consts), C.c_int32(nlev), C.c_int32(nlon),
@@ -387,3 +406,43 @@ def letkf_core_host(ne, nobs, nobsl, hdxb, rdiag, rloc, dep, parm_infl, want_tra
                    C.byref(iu) if infl_update is not None else None, f(depd), f(transmd), C.byref(st))
     return dict(trans=trans, transm=transm, pao=pao, transmd=transmd if depd is not None else None,
                 parm_infl=infl.value, status=st.value)
+
+
+# ---- (7) host-side table derivations of das_letkf's set-up (no device needed)
+def var_local_classes(var_local):
+    """var_local: numpy (nvar, nlt).  Returns (n2nc, n2n, nclass), 0-based (letkf_tools.f90:130-157)."""
+    import numpy as np
+    v = np.asfortranarray(var_local, dtype=np.float64)
+    nvar, nlt = v.shape
+    n2nc = np.zeros(nvar, dtype=np.int32)
+    n2n = np.zeros(nvar, dtype=np.int32)
+    nc = C.c_int32(0)
+    rc = lib().letkf_var_local_classes(C.c_int32(nvar), C.c_int32(nlt), v.ctypes.data_as(C.c_void_p),
+                                       n2nc.ctypes.data_as(C.c_void_p), n2n.ctypes.data_as(C.c_void_p), C.byref(nc))
+    if rc != LETKF_OK:
+        raise LetkfError(f"letkf_var_local_classes: {rc}")
+    return n2nc, n2n, nc.value
+
+
+def ctype_merge_groups(elm_u_ctype, typ_ctype, ctype_merge):
+    """ctype_merge: numpy (nid_obs, nobtype) int32.  Returns (group_start [ngroup+1], group_member [nctype])."""
+    import numpy as np
+    eu = np.ascontiguousarray(elm_u_ctype, dtype=np.int32)
+    ty = np.ascontiguousarray(typ_ctype, dtype=np.int32)
+    cm = np.asfortranarray(ctype_merge, dtype=np.int32)
+    nct = len(eu)
+    gs = np.zeros(nct + 1, dtype=np.int32)
+    gm = np.zeros(max(nct, 1), dtype=np.int32)
+    ng = C.c_int32(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib().letkf_ctype_merge_groups(C.c_int32(nct), p(eu), p(ty), C.c_int32(cm.shape[0]), C.c_int32(cm.shape[1]),
+                                        p(cm), p(gs), p(gm), C.byref(ng))
+    if rc != LETKF_OK:
+        raise LetkfError(f"letkf_ctype_merge_groups: {rc}")
+    return gs[:ng.value + 1].copy(), gm[:nct].copy()
+
+
+def radar_only(typ_ctype, typ_radar=22):
+    import numpy as np
+    ty = np.ascontiguousarray(typ_ctype, dtype=np.int32)
+    return int(lib().letkf_radar_only(C.c_int32(len(ty)), ty.ctypes.data_as(C.c_void_p), C.c_int32(typ_radar)))

@@ -148,6 +148,22 @@ int ensure_ws(letkf_ctx* c, const Plan& p) {
   return LETKF_OK;
 }
 
+// Measurement-only knobs exist in the PROF twin of the library (make PROF=1) and nowhere else: the production build
+// reads no environment variable that could change a result.
+#ifdef LETKF_WAVE_PROF
+#define LETKF_KNOB(name) std::getenv(name)
+#else
+#define LETKF_KNOB(name) static_cast<const char*>(nullptr)
+#endif
+
+struct EventPair {   // timing events that do not outlive a failed launch
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EventPair() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+};
+
 int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
   a.ldg = p.ldg;
   a.ldy = p.ldy;
@@ -155,32 +171,36 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
   a.ws = c->ws;
   a.ws_per_block = p.ws_per_block;
   a.max_sweep = 60;
-  a.big_block = (p.lp.big && !std::getenv("LETKF_AMD_BIG_STREAM")) ? 1 : 0;   // knob: the older streaming Jacobi
-  if (const char* e = std::getenv("LETKF_AMD_MAX_SWEEP")) {   // profiling knob: time the non-eigensolve phases
+  a.big_block = (p.lp.big && !LETKF_KNOB("LETKF_AMD_BIG_STREAM")) ? 1 : 0;   // PROF knob: the older streaming Jacobi
+  if (const char* e = LETKF_KNOB("LETKF_AMD_MAX_SWEEP")) {   // PROF knob: time the non-eigensolve phases
     int v = std::atoi(e);
     if (v >= 0 && v < 60) a.max_sweep = v;   // 0: skip the eigensolve entirely (timing only, results invalid)
   }
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (c->timing) {
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, c->stream));
-  }
   // k <= 64: one wavefront per grid point, matrix in registers (letkf_wave.hip); otherwise one workgroup per
   // point with the matrix in LDS, or in the HBM workspace for large k (letkf_kernels.hip)
-  static const bool force_block = std::getenv("LETKF_AMD_FORCE_BLOCK") != nullptr;
+  const bool force_block = LETKF_KNOB("LETKF_AMD_FORCE_BLOCK") != nullptr;
   if (a.mode == 2 && force_block) return fail(LETKF_E_INVALID, "LETKF_AMD_FORCE_BLOCK: the workgroup kernel has no fused search");
-  if (!force_block && letkf::wave_kernel_supports(a.k, a.nv, a.mode)) {
+  const bool wave = !force_block && letkf::wave_kernel_supports(a.k, a.nv, a.mode);
+  if (wave) {
     int run_req = warm_run;
-    if (const char* e = std::getenv("LETKF_AMD_RUN_LEN")) run_req = std::atoi(e);   // experiments: 1 = all cold
+    if (const char* e = LETKF_KNOB("LETKF_AMD_RUN_LEN")) run_req = std::atoi(e);   // PROF knob: 1 = all cold
     size_t wbytes = 0;
     letkf::wave_launch_shape(a.k, a.mode, a.npts, c->num_cu, run_req, &a.run_len, &a.wave_grid, &wbytes);
     if (wbytes > c->warm_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));   // old buffer may still be in use
     if (int rc = ensure_bytes(c, &c->warm_ws, &c->warm_ws_bytes, wbytes)) return rc;
     a.warm_ws = reinterpret_cast<double*>(c->warm_ws);
     a.warm_dbg = 0;
-    if (const char* e = std::getenv("LETKF_AMD_WARM_DBG")) a.warm_dbg = std::atoi(e);
+    if (const char* e = LETKF_KNOB("LETKF_AMD_WARM_DBG")) a.warm_dbg = std::atoi(e);
     a.prof = nullptr;
+  }
+  // every argument check is behind us: only now create the timing events (destroyed again if the launch fails)
+  EventPair ev;
+  if (c->timing) {
+    HIP_TRY(hipEventCreate(&ev.e0));
+    HIP_TRY(hipEventCreate(&ev.e1));
+    HIP_TRY(hipEventRecord(ev.e0, c->stream));
+  }
+  if (wave) {
 #ifdef LETKF_WAVE_PROF
     static unsigned long long* prof_dev = nullptr;
     if (!prof_dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&prof_dev), 10 * sizeof(unsigned long long)));
@@ -203,8 +223,9 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
   } else
     HIP_TRY(letkf::launch_point_kernel(a, p.lp, c->stream));
   if (c->timing) {
-    HIP_TRY(hipEventRecord(e1, c->stream));
-    c->events.emplace_back(e0, e1);
+    HIP_TRY(hipEventRecord(ev.e1, c->stream));
+    c->events.emplace_back(ev.e0, ev.e1);
+    ev.e0 = ev.e1 = nullptr;   // owned by the context from here
   }
   return LETKF_OK;
 }
@@ -627,6 +648,25 @@ int letkf_addinfl_weight_dev(letkf_ctx* c, int64_t nij1, const double* rig, cons
   const double cut2 = (double)13.33333333f;   // dist_zero_fac_square, a single-precision literal (letkf_obs.f90:28)
   HIP_TRY(letkf::launch_addinfl_weight(nij1, rig, rjg, nob, ob_ri, ob_rj, dx, dy, hori_loc, cut2, weight, c->num_cu,
                                        c->stream));
+  return LETKF_OK;
+}
+
+int letkf_relax_beta_dev(letkf_ctx* c, const letkf_beta_params* p, int64_t nij1, int32_t nlev, const double* rig,
+                         const double* rjg, const double* hgt, double* beta) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!p || nij1 < 0 || nlev < 1) return fail(LETKF_E_INVALID, "params is NULL or bad nij1 / nlev");
+  if (nij1 == 0) return LETKF_OK;
+  if (!rig || !rjg || !hgt || !beta) return fail(LETKF_E_INVALID, "a point array is NULL");
+  HIP_TRY(letkf::launch_relax_beta(*p, nij1, nlev, rig, rjg, hgt, beta, c->num_cu, c->stream));
+  return LETKF_OK;
+}
+
+int letkf_infl_init_dev(letkf_ctx* c, int64_t n, double* work3d, double infl_mul, double infl_mul_min) {
+  if (int rc = check_ctx(c)) return rc;
+  if (n < 0) return fail(LETKF_E_INVALID, "negative size");
+  if (n == 0) return LETKF_OK;
+  if (!work3d) return fail(LETKF_E_INVALID, "work3d is NULL");
+  HIP_TRY(letkf::launch_infl_init(n, work3d, infl_mul, infl_mul_min, c->num_cu, c->stream));
   return LETKF_OK;
 }
 

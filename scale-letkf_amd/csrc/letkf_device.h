@@ -117,6 +117,9 @@ hipError_t launch_additive(int k, int nv, long npts, long nij1, double* anal, co
 hipError_t launch_addinfl_weight(long nij1, const double* rig, const double* rjg, long nob, const double* ob_ri,
                                  const double* ob_rj, double dx, double dy, double hori_loc, double cut2, double* w,
                                  int num_cu, hipStream_t st);
+hipError_t launch_relax_beta(const letkf_beta_params& p, long nij1, int nlev, const double* rig, const double* rjg,
+                             const double* hgt, double* beta, int num_cu, hipStream_t st);
+hipError_t launch_infl_init(long n, double* w, double infl_mul, double infl_mul_min, int num_cu, hipStream_t st);
 hipError_t launch_ens_to_pert(int k, int nv, long npts, double* x, long sp, long sm, long sv, hipStream_t st);
 hipError_t launch_state_trans(const letkf_state_consts& c, int nlev, long nxy, int nv3d, double* v, int inverse,
                               hipStream_t st);

@@ -138,7 +138,7 @@ __device__ __forceinline__ double slot_sum_nw(double v, double* xs, int& ph) {
 // was already diagonal" and must not have rotations of 1e-8 pass for that).
 template <int KR, int NW, int RC = 24, bool EARLY = true>
 __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const int max_sweep, double* lds,
-                                            int* pairs_out = nullptr) {
+                                            int* pairs_out = nullptr, int* conv_out = nullptr) {
   static_assert(KR % 2 == 0, "row halves");
   constexpr int H = KR / 2;
   static_assert(RC % 2 == 0, "RC rows per conversion chunk: RC * 64 NW doubles of LDS");
@@ -164,7 +164,9 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
       xb[rr] = v2.y;
     }
   }
-  int sweep = 0, pairs_done = 0;
+  int sweep = 0, pairs_done = 0, conv = 0;
+  // (NW = 2: the loop below holds workgroup barriers inside `if (slot < S)`.  Both waves always enter it -- lane 0 of
+  // either wave is slot 0 < S -- and s_barrier counts waves, not lanes, so the barrier counts of the two waves agree.)
   if (slot < S) {
     const bool hasL = slot > 0, hasR = slot + 1 < S;
     double alA = 0.0, alB = 0.0, isA = 1.0, isB = 1.0, scA = 1.0, scB = 1.0;
@@ -300,6 +302,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
     }
     sweep = (pairs + S - 1) / S;
     pairs_done = pairs;
+    conv = done ? 1 : 0;
 #pragma unroll
     for (int rr = 0; rr < H; ++rr) {
       xa[rr] *= isA;
@@ -307,6 +310,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
     }
   }
   sweep = __builtin_amdgcn_readfirstlane(sweep);
+  if (conv_out) *conv_out = __builtin_amdgcn_readfirstlane(conv);   // 0: the sweep cap ended the iteration
   if (pairs_out) *pairs_out = __builtin_amdgcn_readfirstlane(pairs_done);   // step pairs executed (the column order
                                                                              // after them is a fixed permutation)
   // ---- row-split -> column-per-lane

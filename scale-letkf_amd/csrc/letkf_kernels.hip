@@ -116,7 +116,8 @@ constexpr int kMaxSweep = 60;
 
 // ------------------------------------------------------------------ Jacobi, 8 lanes per pair, rows in registers
 template <int RMAX>
-__device__ __forceinline__ int jacobi_cached(double* __restrict__ G, const int ldg, const int k, const int max_sweep) {
+__device__ __forceinline__ int jacobi_cached(double* __restrict__ G, const int ldg, const int k, const int max_sweep,
+                                             int& conv) {
   const int tid = threadIdx.x;
   const int l8 = tid & 7;
   const int grp = tid >> 3;
@@ -168,6 +169,7 @@ __device__ __forceinline__ int jacobi_cached(double* __restrict__ G, const int l
     }
     if (!__syncthreads_or(notconv)) {
       ++sweep;
+      conv = 1;
       break;
     }
   }
@@ -175,7 +177,8 @@ __device__ __forceinline__ int jacobi_cached(double* __restrict__ G, const int l
 }
 
 // ------------------------------------------------------------------ Jacobi, one wave per pair, streaming (any k, G anywhere)
-__device__ __forceinline__ int jacobi_stream(double* __restrict__ G, const int ldg, const int k, const int max_sweep) {
+__device__ __forceinline__ int jacobi_stream(double* __restrict__ G, const int ldg, const int k, const int max_sweep,
+                                             int& conv) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int grp = tid >> 6;
@@ -219,6 +222,7 @@ __device__ __forceinline__ int jacobi_stream(double* __restrict__ G, const int l
     }
     if (!__syncthreads_or(notconv)) {
       ++sweep;
+      conv = 1;
       break;
     }
   }
@@ -238,7 +242,7 @@ __device__ __forceinline__ int jacobi_stream(double* __restrict__ G, const int l
 // wscr: 512 doubles of LDS per wave.
 constexpr int kBlkScr = 512;
 __device__ __forceinline__ int jacobi_block_mfma(double* __restrict__ G, const int ldg, const int k, const int max_sweep,
-                                                 double* scr_all) {
+                                                 double* scr_all, int& conv) {
   using jacobi_dev::v4d;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
@@ -409,6 +413,7 @@ __device__ __forceinline__ int jacobi_block_mfma(double* __restrict__ G, const i
     }
     if (!__syncthreads_or(notconv)) {
       ++sweep;
+      conv = 1;
       break;
     }
   }
@@ -524,7 +529,7 @@ __global__ void __launch_bounds__(BIG ? 768 : 256) letkf_point_kernel(const Poin
     for (int j = tid; j < 2 * k; j += nthr) vec[j] = 0.0;        // rvec, rdvec
     if (tid < 16) red[tid] = 0.0;
     double p1 = 0.0, p3 = 0.0;                   // adaptive inflation sums (common_letkf.f90:233-249)
-    int sweeps = 0;
+    int sweeps = 0, jconv = 1;
 
     if (n > 0) {
       for (int tile0 = 0; tile0 < ntile2; tile0 += nthr * kMaxT) {
@@ -658,9 +663,10 @@ __global__ void __launch_bounds__(BIG ? 768 : 256) letkf_point_kernel(const Poin
       __syncthreads();
 
       // ---------------- phase 3: eigen-decomposition (one-sided Jacobi on G = A)
-      if constexpr (RMAX > 0) sweeps = jacobi_cached<RMAX>(G, ldg, k, A.max_sweep);
-      else if (A.big_block) sweeps = jacobi_block_mfma(G, ldg, k, A.max_sweep, dyn);
-      else sweeps = jacobi_stream(G, ldg, k, A.max_sweep);
+      jconv = 0;
+      if constexpr (RMAX > 0) sweeps = jacobi_cached<RMAX>(G, ldg, k, A.max_sweep, jconv);
+      else if (A.big_block) sweeps = jacobi_block_mfma(G, ldg, k, A.max_sweep, dyn, jconv);
+      else sweeps = jacobi_stream(G, ldg, k, A.max_sweep, jconv);
 
       // lambda_j = |g_j|, V = G / lambda
       {
@@ -700,7 +706,7 @@ __global__ void __launch_bounds__(BIG ? 768 : 256) letkf_point_kernel(const Poin
         lmx = fmax(lmx, shfl_xor_d(lmx, mk));
         lmn = fmin(lmn, shfl_xor_d(lmn, mk));
       }
-      if (sweeps >= A.max_sweep && A.max_sweep >= kMaxSweep) st = 1;
+      if (!jconv && A.max_sweep >= kMaxSweep) st = 1;   // (converging in the last permitted sweep is converged)
       else if (!(lmx > 0.0)) st = 2;
       else if (lmn < lmx * 1.4901161193847656e-08) st = 3;       // sqrt(DBL_EPSILON)
     }

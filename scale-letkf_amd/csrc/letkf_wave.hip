@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     // entry (k,k) = sum w dep^2 (parm(1) of the adaptive inflation, common_letkf.f90:233-237).
     double g[KR];
     double racc = 0.0, rdacc = 0.0, p1 = 0.0, p3 = 0.0;
-    int sweeps = 0;
+    int sweeps = 0, jconv = 1;
     double lam = km1 / infl_old;               // n == 0: T = sqrt(rho) I, Pa = rho/(k-1) I (common_letkf.f90:89-107)
     bool colvalid = lane < k;                  // does this lane hold an eigen-column?
 
@@ -947,7 +947,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         }
       }
       PROF_MARK(3)
-      sweeps = jacobi_split<KR, NW, 24, LETKF_EARLY_NW(KR, NW)>(g, k, A.max_sweep, slice);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
+      sweeps = jacobi_split<KR, NW, 24, LETKF_EARLY_NW(KR, NW)>(g, k, A.max_sweep, slice, nullptr, &jconv);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
       // per-lane values that were spilled around the eigensolve come back HERE, in one batch: reloaded lazily, each
       // scratch load sits behind the 50 workspace stores below and its s_waitcnt vmcnt(0) waits for all of them
       asm volatile("" : "+v"(racc), "+v"(rdacc), "+v"(moff));
@@ -1024,7 +1024,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
     {
       const double lmx = preduce<NW, 1>(colvalid ? lam : 0.0, red, rslot);
       const double lmn = preduce<NW, 2>(colvalid ? lam : 1e300, red, rslot);
-      if (sweeps >= A.max_sweep && A.max_sweep >= 60) st = 1;
+      if (!jconv && A.max_sweep >= 60) st = 1;   // (a solve that converges in the last permitted sweep is converged)
       else if (!(lmx > 0.0)) st = 2;
       else if (lmn < lmx * 1.4901161193847656e-08) st = 3;
     }
@@ -1438,7 +1438,9 @@ void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, int*
   const long per_wg = ppw * R;
   const long nwg = (npts + per_wg - 1) / per_wg;
   long g = (long)num_cu * 16;   // 8x oversubscribed: the static block stride balances better (measured 573 ms at 2x, 541 at 16x)
-  if (const char* e = std::getenv("LETKF_AMD_WAVE_GRID")) g = (long)num_cu * std::atoi(e);   // experiments
+#ifdef LETKF_WAVE_PROF
+  if (const char* e = std::getenv("LETKF_AMD_WAVE_GRID")) g = (long)num_cu * std::atoi(e);   // PROF twin only
+#endif
   *grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
   *run_len = R;
   // one [KR][lanes of a point] slot per wave-group of the grid

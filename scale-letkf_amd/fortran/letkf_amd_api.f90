@@ -24,7 +24,53 @@ MODULE letkf_amd_api
     INTEGER(c_int32_t) :: var_mask
   END TYPE letkf_das_args
 
+  ! include/letkf_amd.h section 7
+  TYPE, BIND(C) :: letkf_beta_params
+    INTEGER(c_int32_t) :: radar_only, ihalo, jhalo, nlong, nlatg, reserved0
+    REAL(c_double)     :: radar_zmax, vert_local_radar, boundary_buffer_width, dx, dy
+  END TYPE letkf_beta_params
+
   INTERFACE
+    ! das_letkf set-up (scale/letkf/letkf_tools.f90:130-267, relax_beta :1911-1948); the first three are host functions
+    FUNCTION letkf_var_local_classes(nvar, nlt, var_local, n2nc, n2n, nclass) &
+        BIND(C, name='letkf_var_local_classes') RESULT(rc)
+      IMPORT :: c_int, c_int32_t, c_double
+      INTEGER(c_int32_t), VALUE :: nvar, nlt
+      REAL(c_double), INTENT(IN) :: var_local(nvar, nlt)
+      INTEGER(c_int32_t), INTENT(OUT) :: n2nc(nvar), n2n(nvar), nclass
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_ctype_merge_groups(nctype, elm_u_ctype, typ_ctype, nid_obs, nobtype, ctype_merge, group_start, &
+                                      group_member, ngroup) BIND(C, name='letkf_ctype_merge_groups') RESULT(rc)
+      IMPORT :: c_int, c_int32_t
+      INTEGER(c_int32_t), VALUE :: nctype, nid_obs, nobtype
+      INTEGER(c_int32_t), INTENT(IN) :: elm_u_ctype(nctype), typ_ctype(nctype), ctype_merge(nid_obs, nobtype)
+      INTEGER(c_int32_t), INTENT(OUT) :: group_start(nctype + 1), group_member(nctype), ngroup
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_radar_only(nctype, typ_ctype, typ_radar) BIND(C, name='letkf_radar_only') RESULT(flag)
+      IMPORT :: c_int, c_int32_t
+      INTEGER(c_int32_t), VALUE :: nctype, typ_radar
+      INTEGER(c_int32_t), INTENT(IN) :: typ_ctype(nctype)
+      INTEGER(c_int) :: flag
+    END FUNCTION
+    FUNCTION letkf_relax_beta_dev(ctx, p, nij1, nlev, rig, rjg, hgt, beta) &
+        BIND(C, name='letkf_relax_beta_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t, letkf_beta_params
+      TYPE(c_ptr), VALUE :: ctx, rig, rjg, hgt, beta
+      TYPE(letkf_beta_params), INTENT(IN) :: p
+      INTEGER(c_int64_t), VALUE :: nij1
+      INTEGER(c_int32_t), VALUE :: nlev
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_infl_init_dev(ctx, n, work3d, infl_mul, infl_mul_min) &
+        BIND(C, name='letkf_infl_init_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int64_t, c_double
+      TYPE(c_ptr), VALUE :: ctx, work3d
+      INTEGER(c_int64_t), VALUE :: n
+      REAL(c_double), VALUE :: infl_mul, infl_mul_min
+      INTEGER(c_int) :: rc
+    END FUNCTION
     FUNCTION letkf_amd_abi_version() BIND(C, name='letkf_amd_abi_version') RESULT(v)
       IMPORT :: c_int
       INTEGER(c_int) :: v

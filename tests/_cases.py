@@ -147,3 +147,23 @@ def probes(k):
     """Fixed probe vectors used to pin k x k outputs too large to store."""
     rng = np.random.default_rng(777 + k)
     return rng.standard_normal((k, 4))
+
+
+def expected_status(c, inp):
+    """LETKF_ST_* the library must report for a golden case: 3 when lambda_min < lambda_max * sqrt(eps)
+    (common/common_mtx.f90:66-74), else 0; None when the spectrum sits within 1 % of that threshold."""
+    n, k = c["n"], c["k"]
+    if n == 0:
+        return 0
+    y = inp["hdxb"][:n]
+    w = (1.0 / inp["rdiag"][:n]) if c["rdiag_wloc"] else inp["rloc"][:n] / inp["rdiag"][:n]
+    shift = (k - 1) / c["infl"]
+    # lambda(A) = shift + lambda(Y^T W Y); the non-zero part of the latter from the smaller Gram matrix
+    yw = y * np.sqrt(w)[:, None]
+    s = np.linalg.eigvalsh(yw.T @ yw if k <= n else yw @ yw.T)
+    lmax = shift + max(s[-1], 0.0)
+    lmin = shift + (max(s[0], 0.0) if k <= n else 0.0)
+    ratio = lmin / lmax / 1.4901161193847656e-08
+    if 0.99 < ratio < 1.01:
+        return None
+    return 3 if ratio < 1.0 else 0

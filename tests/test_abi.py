@@ -33,7 +33,9 @@ def test_header_symbols_exported(pkg):
 
 
 def test_abi_version(pkg):
-    assert pkg.lib().letkf_amd_abi_version() == 3
+    src = open(os.path.join(ROOT, "include", "letkf_amd.h")).read()
+    want = int(re.search(r"#define LETKF_AMD_ABI_VERSION (\d+)", src).group(1))
+    assert pkg.lib().letkf_amd_abi_version() == want
 
 
 def test_fails_loudly_without_device(pkg):
@@ -48,14 +50,15 @@ def test_fails_loudly_without_device(pkg):
 def test_struct_layout_matches_header(pkg):
     # sizes of the argument blocks as the C compiler lays them out (guards the ctypes mirror)
     import subprocess, tempfile
-    code = '#include <stdio.h>\n#include "letkf_amd.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(letkf_core_batch_args), sizeof(letkf_das_args), sizeof(letkf_search_tables), sizeof(letkf_state_consts));return 0;}\n'
+    code = '#include <stdio.h>\n#include "letkf_amd.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(letkf_core_batch_args), sizeof(letkf_das_args), sizeof(letkf_search_tables), sizeof(letkf_state_consts));printf("%zu\\n", sizeof(letkf_beta_params));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "s.c")
         open(src, "w").write(code)
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
-        a, b, c, d4 = map(int, subprocess.check_output([exe]).split())
+        a, b, c, d4, e5 = map(int, subprocess.check_output([exe]).split())
         assert d4 == C.sizeof(pkg.StateConsts)
+        assert e5 == C.sizeof(pkg.BetaParams)
     assert a == C.sizeof(pkg.CoreBatchArgs)
     assert b == C.sizeof(pkg.DasArgs)
     assert c == C.sizeof(pkg.SearchTables)

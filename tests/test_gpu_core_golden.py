@@ -5,7 +5,7 @@ ill-conditioned fixtures (cond ~ 1e6: both the reference's QL and the Jacobi sol
 cond*eps there)."""
 import pytest
 
-from _cases import golden_case_list, golden_inputs
+from _cases import expected_status, golden_case_list, golden_inputs
 from test_oracle_golden import check_against_golden
 
 pytestmark = pytest.mark.gpu
@@ -27,7 +27,9 @@ def test_letkf_core_c_matches_reference_golden(golden, c):
     r = pkg.letkf_core_host(c["k"], inp["nobs"], c["n"], inp["hdxb"], inp["rdiag"], inp["rloc"], inp["dep"],
                             inp["infl"], want_transm=c["transm"], want_pao=c["pao"], rdiag_wloc=c["rdiag_wloc"],
                             infl_update=c["infl_update"], depd=inp["depd"], want_transmd=c["det"])
-    expect_status = 3 if c["cond"] == "ill" and c["k"] == 50 else None
-    if expect_status is None:
+    want = expected_status(c, inp)          # from the spectrum of A (numpy), not from the library
+    if want is None:
         assert r["status"] in (0, 3), r["status"]
+    else:
+        assert r["status"] == want, (r["status"], want)
     check_against_golden(golden, c, r, tol_for(c), tol_infl=1e-12 if c["cond"] != "ill" else 1e-9)
