@@ -34,6 +34,17 @@ CONFIGS = {
     # BASELINE configs[3] (C4: k = 50, radar-like dense obs, ~5000 local obs/point) on a small grid: the Gram dominates
     "C4-mini": dict(nx=32, ny=32, nz=8, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=600.0, err=3.0,
                     ztop=18000.0, seed=20240614),
+    # Interior pieces of the full-size configurations: halo = True extends the observation lattice past the slab by
+    # the localisation cut-off on every side, so that every point sees the local-observation count of the interior
+    # of the full domain (C2's lattice: ~200; configs[3]: ~5000) instead of a boundary-thinned one.
+    "C3-slab": dict(nx=24, ny=24, nz=6, k=320, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
+                    ztop=18000.0, seed=20240617, halo=True),
+    "C4-slab": dict(nx=24, ny=24, nz=6, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=1100.0, err=3.0,
+                    ztop=18000.0, seed=20240615, halo=True),
+    "C5-slab": dict(nx=16, ny=16, nz=3, k=1000, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
+                    ztop=18000.0, seed=20240616, halo=True),
+    "C2-slab-k100": dict(nx=48, ny=48, nz=12, k=100, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
+                         ztop=18000.0, seed=20240618, halo=True),
     "C1": dict(nx=40, ny=40, nz=30, k=20, dx=15000.0, hloc=120000.0, vloc=4000.0, spacing=30000.0, err=3.0,
                ztop=18000.0, seed=20240608),
 }
@@ -45,6 +56,17 @@ def level_heights(nz, ztop):
     return 50.0 + (ztop - 50.0) * s ** 1.6
 
 
+def lattice(cfg, device):
+    """Observation lattice coordinates (metres) and the number of halo planes on the low side (0 without halo)."""
+    sp_o, f64 = cfg["spacing"], torch.float64
+    nh = nhz = 0
+    if cfg.get("halo"):
+        nh = int(math.ceil(cfg["hloc"] * DIST_ZERO_FAC / sp_o))
+        nhz = int(math.ceil(cfg["vloc"] * DIST_ZERO_FAC / sp_o))
+    ax = lambda length, n: (torch.arange(-n, int(math.ceil(length / sp_o - 0.5)) + n, device=device, dtype=f64) + 0.5) * sp_o
+    return ax(cfg["nx"] * cfg["dx"], nh), ax(cfg["ny"] * cfg["dx"], nh), ax(cfg["ztop"], nhz), nh, nhz
+
+
 def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1):
     cfg = CONFIGS[cfg_name]
     nx, ny, nz, k = cfg["nx"], cfg["ny"], cfg["nz"], cfg["k"]
@@ -53,9 +75,7 @@ def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1):
     g.manual_seed(cfg["seed"] + 7919 * rank)
     f64 = torch.float64
     # ---- observation lattice (type-22 radar-like: vertical localisation in z, letkf_tools.f90:1857)
-    ox = torch.arange(0.5 * sp_o, nx * dx, sp_o, device=device, dtype=f64)
-    oy = torch.arange(0.5 * sp_o, ny * dx, sp_o, device=device, dtype=f64)
-    oz = torch.arange(0.5 * sp_o, cfg["ztop"], sp_o, device=device, dtype=f64)
+    ox, oy, oz, nh, nhz = lattice(cfg, device)
     nox, noy, noz = len(ox), len(oy), len(oz)
     nobs = nox * noy * noz
     kld = k + 1
@@ -74,11 +94,11 @@ def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1):
     offs = torch.arange(-rh, rh + 1, device=device)
     offv = torch.arange(-rv, rv + 1, device=device)
     nij = nx * ny
-    cix = torch.floor(px / sp_o).long()
-    ciy = torch.floor(py / sp_o).long()
+    cix = torch.floor(px / sp_o).long() + nh
+    ciy = torch.floor(py / sp_o).long() + nh
     counts_all, idx_all, rloc_all = [], [], []
     for lev in range(nz):
-        ciz = int(math.floor(float(zlev[lev]) / sp_o))
+        ciz = int(math.floor(float(zlev[lev]) / sp_o)) + nhz
         ix = cix[:, None] + offs[None, :]                                   # [nij, nh]
         iy = ciy[:, None] + offs[None, :]
         iz = ciz + offv                                                     # [nvv]
@@ -142,9 +162,7 @@ def search_tables(w, pkg, device):
     nx, ny, nz = cfg["nx"], cfg["ny"], cfg["nz"]
     dx, hloc, vloc, sp_o = cfg["dx"], cfg["hloc"], cfg["vloc"], cfg["spacing"]
     f64 = torch.float64
-    ox = torch.arange(0.5 * sp_o, nx * dx, sp_o, device=device, dtype=f64)
-    oy = torch.arange(0.5 * sp_o, ny * dx, sp_o, device=device, dtype=f64)
-    oz = torch.arange(0.5 * sp_o, cfg["ztop"], sp_o, device=device, dtype=f64)
+    ox, oy, oz, _, _ = lattice(cfg, device)
     nox, noy, noz = len(ox), len(oy), len(oz)
     # lattice row index = (iz*noy + iy)*nox + ix  (as in build())
     ri = (ox / dx).repeat(noy * noz)
@@ -186,3 +204,25 @@ def search_tables(w, pkg, device):
     prz = zlev.repeat_interleave(nx * ny)
     prl = torch.full_like(pri, 1.0e5)
     return t, keep, order, (pri, prj, prl, prz)
+
+
+def sample_points(w, pts):
+    """Host copies of everything the loop body reads for the grid points `pts` (sorted numpy int64): CSR lists
+    re-based to the sample, the sample's slice of the state.  For the CPU checker / baseline (bench.py, tests)."""
+    pts = np.asarray(pts, dtype=np.int64)
+    ns = len(pts)
+    dev = w["obs_off"].device
+    tp = torch.from_numpy(pts).to(dev)
+    o0 = w["obs_off"][tp]
+    cnt = (w["obs_off"][tp + 1] - o0)
+    off = torch.zeros(ns + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(cnt, 0)
+    nnz = int(off[-1].item())
+    # entry e of the sample list belongs to sample point searchsorted(off, e, right) - 1
+    e = torch.arange(nnz, dtype=torch.int64, device=dev)
+    sp_ = torch.searchsorted(off, e, right=True) - 1
+    sel = o0[sp_] + (e - off[sp_])
+    nv, nens, npts = w["nv"], w["nens"], w["npts"]
+    gv = w["gues"].view(nv, nens, npts)[:, :, tp].contiguous().cpu().numpy().reshape(-1)
+    return dict(off=off.cpu().numpy(), idx=w["obs_idx"][sel].cpu().numpy(), rdiag=w["rdiag"][sel].cpu().numpy(),
+                rloc=w["rloc"][sel].cpu().numpy(), gues=gv, ns=ns, pts=pts)
