@@ -48,6 +48,8 @@ struct letkf_ctx {
   size_t warm_ws_bytes = 0;
   char* scratch = nullptr;    // staging for the host-pointer entry
   size_t scratch_bytes = 0;
+  char* staged_ws = nullptr;  // staged path: per-point slabs of a batch + meta / info words
+  size_t staged_ws_bytes = 0;
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 };
@@ -164,6 +166,8 @@ struct EventPair {   // timing events that do not outlive a failed launch
   }
 };
 
+int launch_staged(letkf_ctx* c, letkf::PointArgs& a);
+
 int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
   a.ldg = p.ldg;
   a.ldy = p.ldy;
@@ -181,6 +185,9 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
   const bool force_block = LETKF_KNOB("LETKF_AMD_FORCE_BLOCK") != nullptr;
   if (a.mode == 2 && force_block) return fail(LETKF_E_INVALID, "LETKF_AMD_FORCE_BLOCK: the workgroup kernel has no fused search");
   const bool wave = !force_block && letkf::wave_kernel_supports(a.k, a.nv, a.mode);
+  // beyond the register kernels: the staged three-kernel path (the monolithic workgroup kernel below stays reachable
+  // through the PROF twin's LETKF_AMD_FORCE_BLOCK / LETKF_AMD_MONOLITHIC knobs for A/B measurements)
+  if (!wave && !force_block && a.mode != 2 && a.nv + 2 <= 16 && !LETKF_KNOB("LETKF_AMD_MONOLITHIC")) return launch_staged(c, a);
   if (wave) {
     int run_req = warm_run;
     if (const char* e = LETKF_KNOB("LETKF_AMD_RUN_LEN")) run_req = std::atoi(e);   // PROF knob: 1 = all cold
@@ -226,6 +233,61 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
     HIP_TRY(hipEventRecord(ev.e1, c->stream));
     c->events.emplace_back(ev.e0, ev.e1);
     ev.e0 = ev.e1 = nullptr;   // owned by the context from here
+  }
+  return LETKF_OK;
+}
+
+// Staged path (letkf_staged.hip): k beyond the register kernels.  The points are processed in batches whose slabs
+// fit a fixed workspace budget; per batch: Gram stage, eigen stage (workgroup Jacobi for orders <= 208, block Jacobi
+// above), apply stage -- all on the context's stream, no host synchronisation in between.
+int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
+  const int kkout = (a.trans_out || a.pa_out) ? 1 : 0;
+  const long wpp = letkf::staged_ws_per_point(a.k, a.nv, kkout);
+  const size_t budget = (size_t)6 << 30;                              // slabs of one batch: at most 6 GiB
+  long nb = (long)(budget / ((size_t)wpp * sizeof(double)));
+  const long want = (long)c->num_cu * 16;
+  if (nb > want) nb = want;
+  if (nb < 1) nb = 1;
+  if (nb > a.npts) nb = a.npts;
+  const size_t slab_bytes = (size_t)nb * (size_t)wpp * sizeof(double);
+  const size_t need = slab_bytes + (size_t)nb * 4 * sizeof(int) + 256;
+  if (need > c->staged_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc = ensure_bytes(c, &c->staged_ws, &c->staged_ws_bytes, need)) return rc;
+  letkf::StagedArgs s;
+  s.A = a;
+  s.A.ws = reinterpret_cast<double*>(c->staged_ws);
+  s.A.ws_per_block = wpp;
+  s.meta = reinterpret_cast<int*>(c->staged_ws + slab_bytes);
+  s.info = s.meta + 2 * nb;
+  s.kkout = kkout;
+  s.wg_max_order = letkf::eig_wg_max_order();
+  s.A.max_sweep = 60;
+  EventPair ev;
+  if (c->timing) {
+    HIP_TRY(hipEventCreate(&ev.e0));
+    HIP_TRY(hipEventCreate(&ev.e1));
+    HIP_TRY(hipEventRecord(ev.e0, c->stream));
+  }
+  for (long p0 = 0; p0 < a.npts; p0 += nb) {
+    s.pt0 = p0;
+    s.nbatch = (a.npts - p0 < nb) ? a.npts - p0 : nb;
+    HIP_TRY(letkf::launch_stage_gram(s, c->lds_max, c->stream));
+    letkf::EigArgs e;
+    e.ws = s.A.ws;
+    e.ws_per_point = wpp;
+    e.npts = s.nbatch;
+    e.pt0 = p0;
+    e.meta = s.meta;
+    e.info = s.info;
+    e.max_sweep = 60;
+    HIP_TRY(letkf::launch_eig_wg(e, a.k < s.wg_max_order ? a.k : s.wg_max_order, c->num_cu, c->stream));
+    if (a.k > s.wg_max_order) HIP_TRY(letkf::launch_eig_block(e, a.k, c->num_cu, c->stream));
+    HIP_TRY(letkf::launch_stage_apply(s, c->stream));
+  }
+  if (c->timing) {
+    HIP_TRY(hipEventRecord(ev.e1, c->stream));
+    c->events.emplace_back(ev.e0, ev.e1);
+    ev.e0 = ev.e1 = nullptr;
   }
   return LETKF_OK;
 }
@@ -289,6 +351,7 @@ int letkf_ctx_destroy(letkf_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->warm_ws) (void)hipFree(c->warm_ws);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->staged_ws) (void)hipFree(c->staged_ws);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   }
   delete c;

@@ -66,6 +66,36 @@ struct PointArgs {
   unsigned long long* prof;   // profiling build (-DLETKF_WAVE_PROF) only: per-phase s_memtime totals, else null
 };
 
+// Staged (three-kernel) path, letkf_staged.hip / letkf_eig.hip: per point of a batch one workspace slab
+//   G [k * ldg] | V0 [k] | V1 [k] | SC [16] | X [nv k] | TT [nb k] | PC [nb k] | QQ [nb k] | OUT [nb k] | (W [k * ldg])
+// (ldg = k | 1, nb = nv + 2), meta[2 it] = mode | solver << 8 (mode 0: no eigenproblem, 1: primal k x k, 2: dual
+// n x n; solver 1: workgroup Jacobi, 2: block Jacobi), meta[2 it + 1] = matrix order m, info[2 it] = sweeps,
+// info[2 it + 1] = converged.
+struct EigArgs {
+  double* ws;
+  long ws_per_point;
+  long npts;           // points in this batch
+  long pt0;            // first point of the batch
+  const int* meta;
+  int* info;
+  int max_sweep;
+};
+struct StagedArgs {
+  PointArgs A;
+  long pt0, nbatch;
+  int* meta;
+  int* info;
+  int kkout;           // slab carries W (k x k outputs requested)
+  int wg_max_order;    // largest order the workgroup Jacobi takes
+};
+size_t eig_wg_lds_bytes(int NP, int RP, int RBR, int SB);
+int eig_wg_max_order();
+hipError_t launch_eig_wg(const EigArgs& e, int mcap, int num_cu, hipStream_t st);
+hipError_t launch_eig_block(const EigArgs& e, int kmax, int num_cu, hipStream_t st);
+long staged_ws_per_point(int k, int nv, int kkout);
+hipError_t launch_stage_gram(const StagedArgs& s, size_t lds_max, hipStream_t st);
+hipError_t launch_stage_apply(const StagedArgs& s, hipStream_t st);
+
 struct LaunchPlan {
   bool big;
   int rmax;

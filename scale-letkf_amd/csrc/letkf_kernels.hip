@@ -876,6 +876,40 @@ __global__ void __launch_bounds__(BIG ? 768 : 256) letkf_point_kernel(const Poin
   }
 }
 
+// ------------------------------------------------------------------ staged path: eigen stage for orders beyond the
+// workgroup-resident Jacobi of letkf_eig.hip (letkf_staged.hip, solver 2): the block Jacobi on the slab's matrix
+__global__ void __launch_bounds__(768) letkf_eig_block_kernel(const EigArgs E) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  for (long it = blockIdx.x; it < E.npts; it += gridDim.x) {
+    const int m = E.meta[2 * it + 1];
+    if ((E.meta[2 * it] >> 8) != 2 || m < 2) continue;          // (uniform for the workgroup)
+    double* G = E.ws + (size_t)it * E.ws_per_point;
+    int conv = 0;
+    __syncthreads();
+    const int sweeps = jacobi_block_mfma(G, m | 1, m, E.max_sweep, smem, conv);
+    if (threadIdx.x == 0) {
+      E.info[2 * it] = sweeps;
+      E.info[2 * it + 1] = conv;
+    }
+  }
+}
+
+hipError_t launch_eig_block(const EigArgs& e, int kmax, int num_cu, hipStream_t st) {
+  const int nblk = (kmax + 15) / 16, nbe = nblk + (nblk & 1);
+  int waves = nbe / 2;
+  if (waves < 4) waves = 4;
+  if (waves > 12) waves = 12;
+  const size_t lds = (size_t)waves * kBlkScr * sizeof(double);
+  if (lds > 48 * 1024) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_eig_block_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return err;
+  }
+  const long g = e.npts < 2L * num_cu ? (e.npts > 0 ? e.npts : 1) : 2L * num_cu;
+  hipLaunchKernelGGL(letkf_eig_block_kernel, dim3((unsigned)g), dim3(64 * waves), lds, st, e);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ streaming passes either side of the loop
 // scale/letkf/letkf_tools.f90:209-230: members 0..k-1 -= mean (slot k)
 __global__ void ens_to_pert_kernel(int k, int nv, long npts, double* x, long sp, long sm, long sv) {
