@@ -350,9 +350,9 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
       for (int rr = 0; rr < RP; ++rr) {
         const int row = row0 + rr;
         const double vb = rr < RBR ? breg[rr < RBR ? rr : 0] : blds[(size_t)(rr - RBR) * NT + tid];
-        if (row < m) {
-          if (ca < m) G[(size_t)ca * ldg + row] = a[rr];
-          if (cb < m) G[(size_t)cb * ldg + row] = vb;
+        if (row < m) {                                     // all ncol columns: the zero column that pads an odd order
+          if (ca < ncol) G[(size_t)ca * ldg + row] = a[rr];   // may sit anywhere among them after the swaps (the slab
+          if (cb < ncol) G[(size_t)cb * ldg + row] = vb;      // has room for m + 1 columns)
         }
       }
     }

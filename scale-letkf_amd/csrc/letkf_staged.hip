@@ -54,13 +54,13 @@ __device__ __forceinline__ Slab slab_of(double* base, int k, int nv, int kkout) 
   const int ldg = k | 1, nb = nv + 2;
   Slab s;
   s.G = base;
-  s.V0 = s.G + (size_t)k * ldg;
+  s.V0 = s.G + (size_t)(k + 1) * ldg;   // one spare column: an odd order is padded with an inert zero column (letkf_eig.hip)
   s.V1 = s.V0 + k;
   s.SC = s.V1 + k;
   s.X = s.SC + 16;
   s.TT = s.X + (size_t)nv * k;
   s.PC = s.TT + (size_t)nb * k;
-  s.QQ = s.PC + (size_t)nb * k;
+  s.QQ = s.PC + (size_t)nb * (k + 2);   // PC rows are k + 2 long (coefficients of up to k + 1 stored columns)
   s.OUT = s.QQ + (size_t)nb * k;
   s.W = kkout ? s.OUT + (size_t)nb * k : nullptr;
   return s;
@@ -103,7 +103,7 @@ struct ObsView {
 
 long staged_ws_per_point(int k, int nv, int kkout) {
   const long ldg = k | 1, nb = nv + 2;
-  long w = (long)k * ldg + 2L * k + 16 + (long)nv * k + 4L * nb * k;
+  long w = (long)(k + 1) * ldg + 2L * k + 16 + (long)nv * k + 4L * nb * k + 2L * nb;
   if (kkout) w += (long)k * ldg;
   return (w + 1) & ~1L;
 }
@@ -401,12 +401,12 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
   const int k = A.k, nv = A.nv, nb = nv + 2;
   const double km1 = (double)(k - 1);
-  double* lam = smem;
-  double* tau = lam + k;
-  double* pis = tau + k;
-  double* om = pis + k;
-  double* swl = om + k;
-  double* xsm = swl + k;
+  double* lam = smem;                  // k + 2 each (up to k + 1 stored columns)
+  double* tau = lam + (k + 2);
+  double* pis = tau + (k + 2);
+  double* om = pis + (k + 2);
+  double* swl = om + (k + 2);
+  double* xsm = swl + (k + 2);
   double* xmean = xsm;
   double* xdet = xsm + nv;
   double* cfac = xsm + 2 * nv;
@@ -444,6 +444,9 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
     }
     const bool dual = mode == 2;
     const int ldg = m | 1;
+    // the workgroup Jacobi pads an odd order with a zero column that ends up anywhere among the stored columns
+    const int mc = solver == 1 ? (m + 1) & ~1 : m;
+    const int kq = k + 2;                               // row length of PC
     const double shift = sl.SC[3], infl_old = sl.SC[4];
     ObsView ov;
     ov.A = &A;
@@ -460,12 +463,12 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
     const int n = ov.n;
 
     // ---------------- normalise the eigen-columns: lambda_j = |g_j|, e_j = g_j / lambda_j (in place)
-    for (int j = wv; j < m; j += nwv) {
+    for (int j = wv; j < mc; j += nwv) {
       double* gj = sl.G + (size_t)j * ldg;
       double ss = 0.0;
       for (int r = lane; r < m; r += 64) ss = fma(gj[r], gj[r], ss);
       ss = wsum(ss);
-      const double l = sqrt(ss), il = 1.0 / l;
+      const double l = sqrt(ss), il = ss > 0.0 ? 1.0 / l : 0.0;   // (ss == 0: the padding column)
       for (int r = lane; r < m; r += 64) gj[r] *= il;
       if (lane == 0) lam[j] = l;
     }
@@ -482,9 +485,9 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
     int st = 0;
     {
       double lmx = 0.0, lmn = 1e300;
-      for (int j = lane; j < m; j += 64) {
+      for (int j = lane; j < mc; j += 64) {
         lmx = fmax(lmx, lam[j]);
-        lmn = fmin(lmn, lam[j]);
+        if (lam[j] > 0.0 || mc == m) lmn = fmin(lmn, lam[j]);
       }
 #pragma unroll
       for (int mk = 1; mk < 64; mk <<= 1) {
@@ -503,8 +506,12 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
     const double sqc = sqrt(shift), sqkm1 = sqrt(km1);
     const double tau0 = dual ? sqrt(km1 / shift) : 0.0;            // f_T(c) = sqrt(rho)
     const double pi0 = dual ? 1.0 / shift : 0.0;                   // f_Pa(c) = rho / (k-1)
-    for (int j = tid; j < m; j += nthr) {
+    for (int j = tid; j < mc; j += nthr) {
       const double l = lam[j];
+      if (!(l > 0.0) && mc != m) {                     // padding column: no contribution anywhere
+        om[j] = tau[j] = pis[j] = 0.0;
+        continue;
+      }
       om[j] = 1.0 / l;
       if (dual) {
         const double sl_ = sqrt(l);
@@ -562,7 +569,7 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
     __syncthreads();
 
     // ---------------- coefficients P[b][j] = e_j . TT[b]
-    cols_dot(sl.G, ldg, m, m, sl.TT, k, nbr, sl.PC, k);
+    cols_dot(sl.G, ldg, m, mc, sl.TT, k, nbr, sl.PC, kq);
     // var_g per variable (RTPS), needed with or without observations
     if (das)
       for (int v = wv; v < nv; v += nwv) {
@@ -584,8 +591,8 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
         } else if (A.relax_alpha_spread != 0.0) {      // RTPS: var_a = x'^T Pa x' = pi0 |x'|^2 + sum_j pi_j P_j^2
           const double var_g = varg[v];
           double var_a = 0.0;
-          for (int j = 0; j < m; ++j) {
-            const double p = sl.PC[(size_t)(2 + v) * k + j];
+          for (int j = 0; j < mc; ++j) {
+            const double p = sl.PC[(size_t)(2 + v) * kq + j];
             var_a = fma(p * p, pis[j], var_a);
           }
           var_a = fma(pi0, var_g, var_a);
@@ -597,17 +604,17 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
       }
     __syncthreads();
     // ---------------- C = spectrum * P  (in place): rows 0, 1 with 1/lambda (w-bar), rows 2.. with the T spectrum
-    for (int e = tid; e < nbr * m; e += nthr) {
-      const int b = e / m, j = e - b * m;
-      sl.PC[(size_t)b * k + j] *= (b < 2) ? om[j] : tau[j];
+    for (int e = tid; e < nbr * mc; e += nthr) {
+      const int b = e / mc, j = e - b * mc;
+      sl.PC[(size_t)b * kq + j] *= (b < 2) ? om[j] : tau[j];
     }
     __syncthreads();
 
     // ---------------- back to member space: OUT[b][mm]
     if (!dual) {
-      rows_comb(sl.G, ldg, k, m, sl.PC, k, nbr, sl.OUT, k);
+      rows_comb(sl.G, ldg, k, mc, sl.PC, kq, nbr, sl.OUT, k);
     } else {
-      rows_comb(sl.G, ldg, n, m, sl.PC, k, nbr, sl.QQ, k);       // q_b = U c_b  (obs space)
+      rows_comb(sl.G, ldg, n, mc, sl.PC, kq, nbr, sl.QQ, k);      // q_b = U c_b  (obs space)
       __syncthreads();
       // OUT[b][mm] = sum_i Z[i][mm] q_b[i]: one thread per member, the obs rows streamed (coalesced along mm)
       for (int mm = tid; mm < k; mm += nthr) {
@@ -720,7 +727,7 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
         // W[j][mm] = sum_i U[i][j] Z[i][mm]  (n x n x k): one thread per member, per eigen-column a pass over the rows
         __syncthreads();
         for (int mm = tid; mm < k; mm += nthr) {
-          for (int j0 = 0; j0 < m; j0 += 8) {
+          for (int j0 = 0; j0 < mc; j0 += 8) {
             double acc[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc[u] = 0.0;
@@ -730,11 +737,11 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
               const double z = yr[(long)mm * ms] * swl[i];
 #pragma unroll
               for (int u = 0; u < 8; ++u)
-                if (j0 + u < m) acc[u] = fma(z, sl.G[(size_t)(j0 + u) * ldg + i], acc[u]);
+                if (j0 + u < mc) acc[u] = fma(z, sl.G[(size_t)(j0 + u) * ldg + i], acc[u]);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-              if (j0 + u < m) sl.W[(size_t)(j0 + u) * (k | 1) + mm] = acc[u];
+              if (j0 + u < mc) sl.W[(size_t)(j0 + u) * (k | 1) + mm] = acc[u];
           }
         }
         __syncthreads();
@@ -744,7 +751,7 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
       for (long e = tid; e < (long)k * k; e += nthr) {
         const int c = (int)(e / k), r = (int)(e - (long)c * k);   // column-major, coalesced over r
         double t = 0.0, pp = 0.0;
-        for (int j = 0; j < m; ++j) {
+        for (int j = 0; j < mc; ++j) {
           const double vv = E[(size_t)j * lde + r] * E[(size_t)j * lde + c];
           t = fma(vv, tau[j], t);
           pp = fma(vv, pis[j], pp);
@@ -788,7 +795,7 @@ hipError_t launch_stage_gram(const StagedArgs& s, size_t lds_max, hipStream_t st
 }
 
 hipError_t launch_stage_apply(const StagedArgs& s, hipStream_t st) {
-  const size_t lds = ((size_t)5 * s.A.k + 8 * (size_t)s.A.nv + 32) * sizeof(double);
+  const size_t lds = ((size_t)5 * (s.A.k + 2) + 8 * (size_t)s.A.nv + 32) * sizeof(double);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_stage_apply_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
