@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- grid-point LETKF solves/s of the batched das_letkf body on MI355X (BASELINE.json metric).
+"""bench.py -- grid-point LETKF solves/s of the das_letkf-equivalent call on MI355X (BASELINE.json metric).
 
-One "step" = one full analysis of the workload grid (every (ij, ilev) point: local-obs gather by index +
-k x k eigen-solve + relaxation + transform of the nv=11 variables), through the C ABI
-(letkf_das_points_dev), inputs resident in HBM.  At N=1 the workload is BASELINE.json configs[1]
-(240x240x60 grid, k=50, ~200 local obs/point).  For N>1 (torchrun, one rank per GPU, RCCL) every rank owns a
+One "step" = one full analysis of the workload grid, through the C ABI with every input resident in HBM:
+obs_local for all points on the device (letkf_obs_search_columns_dev: the local-observation lists are rebuilt inside
+every timed step) followed by the batched loop body (letkf_das_points_dev: local-obs gather by index, k x k or n x n
+eigen-solve, relaxation, transform of the nv = 11 variables).  At N = 1 the workload is BASELINE.json configs[1]
+(240x240x60 grid, k = 50, ~200 local obs/point).  For N > 1 (torchrun, one rank per GPU, RCCL) every rank owns a
 tile of that size (weak scaling) and each step starts with the path's one exchange: the all-gather of the
-observation table shards (the localisation-halo exchange of scale/letkf/letkf_obs.f90:1036-1046).
+observation-table shards (the localisation-halo exchange of scale/letkf/letkf_obs.f90:1036-1046).
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0: the contract fields, `roofline` for the dominant kernel (its name and average launch
+duration come from the library: HIP events on the launch stream), `cpu_baseline` (the oracle's OpenMP restatement on a
+bounded sample of the same points, kind "port") with `parity_sample_max_rel` = the GPU analysis against that very
+oracle run (exit status 3 if it exceeds 1e-10), and `cpu_baseline_reference` (the reference's own letkf_core compiled
+into oracle/_ref, kind "reference", when that library travelled with the repository).
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,11 +35,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--relax", default="rtps", choices=["rtps", "rtpp", "none"])
-    ap.add_argument("--lists", default="torch", choices=["torch", "search", "columns", "fused"],
-                    help="where the local-obs lists come from: the torch workload builder, or letkf_obs_search_dev "
-                         "(on-device obs_local; its time is reported separately as search_ms)")
-    ap.add_argument("--search-in-step", action="store_true",
-                    help="with --lists search: rebuild the local lists with the device search inside every timed step")
+    ap.add_argument("--lists", default="columns", choices=["columns", "search", "torch", "fused"],
+                    help="where the local-obs lists come from: letkf_obs_search_columns_dev (default), the per-point "
+                         "letkf_obs_search_dev, the torch workload builder (no search on the device), or obs_local "
+                         "fused into the loop-body kernel")
+    ap.add_argument("--no-search-in-step", action="store_true",
+                    help="build the lists once, outside the timed region (times the loop body alone)")
+    ap.add_argument("--ensval", default="iid", choices=["iid", "correlated"],
+                    help="obs-space perturbations: independent draws, or an H-like combination of the (spatially "
+                         "smooth) state perturbations around every observation + noise (SURVEY.md section 8(d))")
+    ap.add_argument("--max-nobs", type=int, default=0,
+                    help="MAX_NOBS_PER_GRID: two radar ctypes on the lattice, each limited to this many observations")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(affinity, cgroup quota, 16 = the box's CPU share)")
     args = ap.parse_args()
 
@@ -60,7 +72,7 @@ def main():
     from __graft_entry__ import load_package
     import bench_workload as bw
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = env_world
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -81,29 +93,30 @@ def main():
     stream = torch.cuda.current_stream()
     ctx = pkg.Context(local_rank, stream.cuda_stream)
 
-    w = bw.build(args.workload, dev, rank=rank, world=world)
+    if args.max_nobs > 0 and args.lists not in ("columns", "search"):
+        sys.exit("--max-nobs needs --lists columns or search (the device obs_local)")
+    w = bw.build(args.workload, dev, rank=rank, world=world, ensval=args.ensval)
     k, nv, npts = w["k"], w["nv"], w["npts"]
     # the streaming passes either side of the loop: mean into slot k, members -> perturbations
     ctx.ens_mean(k, nv, npts, w["gues"], w["sp"], w["sm"], w["sv"])
     ctx.to_perturbations(k, nv, npts, w["gues"], w["sp"], w["sm"], w["sv"])
+    if args.ensval == "correlated":
+        bw.correlate_ensval(w)      # needs the perturbations
     search_ms = None
-    if args.lists == "fused":
-        # obs_local fused into the loop body (letkf_das_points_fused_dev): no lists at all
-        t_s, keep_s, order_s, pts_s = bw.search_tables(w, pkg, dev)
+    in_step = args.lists in ("search", "columns") and not args.no_search_in_step
+    if args.lists != "torch":
+        # the table as set_letkf_obs leaves it behind: rows in mesh order, prefix sums per cell
+        t_s, keep_s, order_s, pts_s = bw.search_tables(w, pkg, dev, max_nobs=args.max_nobs)
         w["ensval"] = w["ensval"][order_s].contiguous()
         w["dep"] = w["dep"][order_s].contiguous()
     if args.lists in ("search", "columns"):
-        # obs_local on the device: rebuild the lists with the search kernel on the mesh-sorted table
-        t_s, keep_s, order_s, pts_s = bw.search_tables(w, pkg, dev)
         n_torch = int(w["obs_off"][-1].item())
-        w["ensval"] = w["ensval"][order_s].contiguous()
-        w["dep"] = w["dep"][order_s].contiguous()
         nij_s = w["cfg"]["nx"] * w["cfg"]["ny"]
+        rig_s, rjg_s = pts_s[0][:nij_s].contiguous(), pts_s[1][:nij_s].contiguous()
 
         def do_search():
             if args.lists == "columns":   # one wave per horizontal point, all levels (letkf_obs_search_columns_dev)
-                return ctx.obs_search_columns(t_s, nij_s, w["cfg"]["nz"], pts_s[0][:nij_s].contiguous(),
-                                              pts_s[1][:nij_s].contiguous(), pts_s[2], pts_s[3])
+                return ctx.obs_search_columns(t_s, nij_s, w["cfg"]["nz"], rig_s, rjg_s, pts_s[2], pts_s[3])
             return ctx.obs_search(t_s, *pts_s)
 
         for rep in range(2):
@@ -112,8 +125,11 @@ def main():
             off_s, idx_s, rd_s, rl_s = do_search()
             torch.cuda.synchronize()
             search_ms = (time.perf_counter() - t0s) * 1e3
-        assert int(off_s[-1].item()) == n_torch, "device search and torch builder disagree on the list sizes"
+        if args.max_nobs == 0:
+            assert int(off_s[-1].item()) == n_torch, "device search and torch builder disagree on the list sizes"
         w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"] = off_s, idx_s, rd_s, rl_s
+        cnt = (off_s[1:] - off_s[:-1])
+        w["n_mean"], w["n_max"] = float(cnt.double().mean()), int(cnt.max())
     anal = torch.empty_like(w["gues"])
     infl = torch.ones(npts * nv, dtype=torch.float64, device=dev)
     status = torch.zeros(npts, dtype=torch.int32, device=dev)
@@ -134,7 +150,7 @@ def main():
         ens = w["ensval"]
         if world > 1:
             ens, _ = sharding.allgatherv_rows(shard)
-        if args.lists in ("search", "columns") and args.search_in_step:
+        if in_step:
             # the whole das_letkf-equivalent call: obs_local for every point, then the batched loop body
             w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"] = do_search()
         if args.lists == "fused":
@@ -172,6 +188,7 @@ def main():
     value = solves / elapsed
 
     out = None
+    rc = 0
     if rank == 0:
         n_mean = w["n_mean"]
         b_alg = bw.alg_bytes_per_solve(n_mean, k, nv)
@@ -183,7 +200,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload:
+                if tj.get("workload") == args.workload and args.ensval == "iid" and args.max_nobs == 0:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -193,34 +210,46 @@ def main():
         hbm = {"achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": (achieved / 8000.0) if achieved else None}
         fp64 = {"achieved": tflops, "peak": 78.6, "unit": "TFLOP/s", "frac": (tflops / 78.6) if tflops else None}
         compute_bound = f_alg / b_alg > 78.6e12 / 8.0e12
-        main = fp64 if compute_bound else hbm
-        roofline = {"bound": "mfma" if compute_bound else "hbm", "achieved": main["achieved"], "peak": main["peak"],
-                    "unit": main["unit"], "frac": main["frac"], "traffic": traffic,
-                    "kernel": "letkf_wave_kernel<50,11>" if k <= 64 else "letkf_point_kernel", "kernel_ms": kern_ms,
+        main_ = fp64 if compute_bound else hbm
+        roofline = {"bound": "mfma" if compute_bound else "hbm", "achieved": main_["achieved"], "peak": main_["peak"],
+                    "unit": main_["unit"], "frac": main_["frac"], "traffic": traffic,
+                    "kernel": ctx.last_path(), "kernel_ms": kern_ms,
                     "launches": nlaunch, "alg_bytes_per_solve": b_alg, "alg_flops_per_solve": f_alg,
                     "arithmetic_intensity": f_alg / b_alg, "fp64": fp64, "hbm": hbm,
                     "note": "bound = the roof the algorithmic intensity puts the kernel under; 'mfma' stands for the "
                             "FP64 peak (78.6 TFLOP/s, same for v_fma_f64 and v_mfma_f64): the Gram runs on the matrix "
-                            "cores, the eigensolve on the vector ALUs"}
-        cpu = None
+                            "cores, the eigensolve on the vector ALUs; kernel_ms = the loop-body launch(es) only "
+                            "(HIP events), ms_per_step also holds obs_local when search_in_step"}
+        cpu = cpu_ref = None
+        parity = None
         if n_gpus == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(w, relax, args.cpu_seconds, args.cpu_threads)
+            cpu, parity = cpu_baseline(w, relax, args.cpu_seconds, args.cpu_threads, anal)
+            cpu_ref = cpu_baseline_reference(w, args.cpu_threads, min(args.cpu_seconds, 10.0))
+            if parity is not None and not (parity <= 1e-10):
+                rc = 3
         out = {"metric": "grid-point LETKF solves/sec", "value": value, "unit": "solves/s", "n_gpus": n_gpus,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic",
                "config": {"workload": f"{args.workload}: {w['cfg']['nx']}x{w['cfg']['ny']}x{w['cfg']['nz']} grid, "
                                       f"k={k} members, nv={nv}, mean {n_mean:.1f} (max {w['n_max']}) local obs/point, "
-                                      f"relax={args.relax}", "points_per_gpu": npts, "obs_table_rows": w["nobs"],
+                                      f"relax={args.relax}, ensval={args.ensval}"
+                                      + (f", MAX_NOBS_PER_GRID={args.max_nobs} x 2 ctypes" if args.max_nobs else ""),
+                          "points_per_gpu": npts, "obs_table_rows": int(w["ensval"].shape[0]),
                           "parallelism": f"grid-point shard x{n_gpus}" + (" + RCCL obs all-gather" if world > 1 else "")},
-               "analysis_wall_s": elapsed / args.steps, "nonzero_status_points": bad,
+               "analysis_wall_s": elapsed / args.steps, "cycle_ms": elapsed / args.steps * 1e3,
+               "solve_only_solves_per_s": (npts * world / kern_s) if kern_s > 0 else None,
+               "nonzero_status_points": bad,
                "jacobi_sweeps_mean": sweeps_mean, "lists": args.lists, "search_ms": search_ms,
-               "search_in_step": bool(args.lists in ("search", "columns") and args.search_in_step),
-               "roofline": roofline, "cpu_baseline": cpu}
+               "search_in_step": bool(in_step),
+               "parity_sample_max_rel": parity, "parity_tolerance": 1e-10,
+               "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_reference": cpu_ref}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
     return out
 
 
@@ -237,52 +266,130 @@ def host_threads(requested):
     return min(n, 16)   # a one-GPU box's CPU share is 16 cores
 
 
-def cpu_baseline(w, relax, seconds, threads=0):
+def cpu_baseline(w, relax, seconds, threads, anal):
     """The oracle's OpenMP restatement of the same loop body on a bounded sample of the same points (kind "port"),
-    timed on this box's host cores.  A reported baseline, not the target."""
+    timed on this box's host cores -- and the GPU analysis of those very points checked against it
+    (max over variables of |d xa| / max(|x-bar|, |x'|)).  A reported baseline, not the target."""
     import numpy as np
+    import torch
+    import bench_workload as bw
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle
     ncores = host_threads(threads)
-    k, nv, npts = w["k"], w["nv"], w["npts"]
+    k, nv, npts, nens = w["k"], w["nv"], w["npts"], w["nens"]
     ens = w["ensval"].cpu().numpy()
     dep = w["dep"].cpu().numpy()
-    off_all = w["obs_off"].cpu().numpy()
     rng = np.random.default_rng(1)
 
-    def sample(ns):
-        pts = np.sort(rng.choice(npts, size=ns, replace=False))
-        cnt = off_all[pts + 1] - off_all[pts]
-        off = np.zeros(ns + 1, dtype=np.int64)
-        np.cumsum(cnt, out=off[1:])
-        sel = np.concatenate([np.arange(off_all[p], off_all[p + 1]) for p in pts]) if ns else np.zeros(0, np.int64)
-        st = torch_index(w, sel)
-        gv = w["gues"].view(nv, w["nens"], npts)[:, :, pts].contiguous().cpu().numpy().reshape(-1)
-        return off, st, gv, ns
-
-    def torch_index(w, sel):
-        import torch
-        s = torch.from_numpy(sel).to(w["obs_idx"].device)
-        return (w["obs_idx"][s].cpu().numpy(), w["rdiag"][s].cpu().numpy(), w["rloc"][s].cpu().numpy())
-
     def run(ns):
-        off, (idx, rd, rl), gv, ns = sample(ns)
+        pts = np.sort(rng.choice(npts, size=ns, replace=False))
+        s = bw.sample_points(w, pts)
         prm = _oracle.DasParams(k=k, nv=nv, det_run=0, infl_adaptive=0, relax_to_inflated_prior=0,
                                 relax_alpha=relax.get("relax_alpha", 0.0),
                                 relax_alpha_spread=relax.get("relax_alpha_spread", 0.0), q_update_top=0.0,
                                 q_sprd_max=0.0, iv_p=4, iv_q_first=5, iv_q_last=10, nthreads=ncores)
         t0 = time.perf_counter()
-        r = _oracle.das_points(prm, off, idx, rd, rl, ens, dep, None, np.ones(ns * nv), gv, 1, ns, ns * w["nens"])
+        r = _oracle.das_points(prm, s["off"], s["idx"], s["rdiag"], s["rloc"], ens, dep, None, np.ones(ns * nv),
+                               s["gues"], 1, ns, ns * nens)
         dt = time.perf_counter() - t0
         assert r["rc"] == 0
-        return ns / dt
+        # parity of the GPU result on the same points
+        tp = torch.from_numpy(pts).to(anal.device)
+        got = anal.view(nv, nens, npts)[:, :k, tp].cpu().numpy()
+        exp = r["anal"].reshape(nv, nens, ns)[:, :k]
+        x = s["gues"].reshape(nv, nens, ns)
+        worst = 0.0
+        for v in range(nv):
+            scale = max(np.abs(x[v, k]).max(), np.abs(x[v, :k]).max())
+            worst = max(worst, float(np.abs(got[v] - exp[v]).max() / scale))
+        return ns / dt, worst
 
-    rate0 = run(min(npts, 64 * ncores))
+    rate0, p0 = run(min(npts, 64 * ncores))
     ns = int(min(npts, max(64 * ncores, rate0 * seconds)))
-    rate = run(ns)
-    return {"value": rate, "unit": "solves/s", "cores": ncores, "kind": "port",
-            "sample": f"{ns} randomly chosen grid points of the same workload (all {nv} variables, same relaxation), "
-                      f"oracle/letkf_oracle.c orc_das_letkf_points, OpenMP dynamic over points"}
+    rate, p1 = run(ns)
+    return ({"value": rate, "unit": "solves/s", "cores": ncores, "kind": "port",
+             "sample": f"{ns} randomly chosen grid points of the same workload (all {nv} variables, same relaxation), "
+                       f"oracle/letkf_oracle.c orc_das_letkf_points, OpenMP dynamic over points"}, max(p0, p1))
+
+
+def cpu_baseline_reference(w, threads, seconds):
+    """The reference's own letkf_core (common/common_letkf.f90 compiled into oracle/_ref/libletkf_ref.so, EISPACK rs +
+    the reference DGEMM) on local-observation slices of sampled points of this workload: kind "reference".  It times
+    letkf_core alone (the loop body's relaxation and transform are not part of the compiled reference); problems are
+    dealt to `cores` host threads, each running ref_letkf_core_loop on its share.  None when oracle/_ref is absent."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle
+    lib = _oracle.ref()
+    if lib is None:
+        return None
+    ncores = host_threads(threads)
+    k, npts = w["k"], w["npts"]
+    off = w["obs_off"]
+    rng = np.random.default_rng(2)
+    n_fix = max(1, int(round(w["n_mean"])))
+    threading.stack_size(512 * 1024 * 1024 if k > 200 else 64 * 1024 * 1024)   # letkf_core's automatic arrays
+
+    def make(nprob):
+        cand = rng.choice(npts, size=min(npts, 4 * nprob), replace=False)
+        cnt = (off[cand + 1] - off[cand]).cpu().numpy() if hasattr(off, "cpu") else off[cand + 1] - off[cand]
+        cand = cand[cnt >= n_fix][:nprob]
+        if len(cand) == 0:
+            return None
+        nprob = len(cand)
+        H = np.empty((nprob, k, n_fix))
+        rd = np.empty((nprob, n_fix))
+        rl = np.empty((nprob, n_fix))
+        dp = np.empty((nprob, n_fix))
+        ens = w["ensval"]
+        for i, p in enumerate(cand):
+            o0 = int(off[p])
+            idx = w["obs_idx"][o0:o0 + n_fix].long()
+            H[i] = ens[idx, :k].T.cpu().numpy()
+            rd[i] = w["rdiag"][o0:o0 + n_fix].cpu().numpy()
+            rl[i] = w["rloc"][o0:o0 + n_fix].cpu().numpy()
+            dp[i] = w["dep"][idx].cpu().numpy()
+        return H, rd, rl, dp
+
+    def run(nprob):
+        m = make(nprob)
+        if m is None:
+            return None, 0
+        H, rd, rl, dp = m
+        nprob = H.shape[0]
+        infl = np.ones(nprob)
+        trans = np.empty((nprob, k, k))
+        transm = np.empty((nprob, k))
+        pao = np.empty((nprob, k, k))
+        dpt = C.POINTER(C.c_double)
+        f = lambda a, i0: (a[i0:].ctypes.data_as(dpt))
+        cuts = [round(nprob * r / ncores) for r in range(ncores + 1)]
+
+        def work(r):
+            i0, i1 = cuts[r], cuts[r + 1]
+            if i1 > i0:
+                lib.ref_letkf_core_loop(C.c_int(i1 - i0), C.c_int(k), C.c_int(n_fix), C.c_int(n_fix), f(H, i0), f(rd, i0),
+                                        f(rl, i0), f(dp, i0), f(infl, i0), f(trans, i0), f(transm, i0), f(pao, i0))
+        th = [threading.Thread(target=work, args=(r,)) for r in range(ncores)]
+        t0 = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        return nprob / (time.perf_counter() - t0), nprob
+
+    rate0, n0 = run(4 * ncores)
+    if rate0 is None:
+        return None
+    nprob = int(max(4 * ncores, min(20000, rate0 * seconds)))
+    rate, n1 = run(nprob)
+    return {"value": rate, "unit": "letkf_core calls/s", "cores": ncores, "kind": "reference",
+            "sample": f"{n1} letkf_core problems (k={k}, the first {n_fix} local observations of sampled points of this "
+                      f"workload, transm + pao returned, rdiag_wloc) through ref_letkf_core_loop of oracle/_ref/"
+                      f"libletkf_ref.so = /root/reference/common/common_letkf.f90 + common_mtx.f90 + netlib.f + "
+                      f"netlibblas.f compiled with amdflang -O2; {ncores} host threads, one share of the problems each; "
+                      f"letkf_core only (no relaxation / transform)"}
 
 
 if __name__ == "__main__":

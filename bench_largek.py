@@ -19,7 +19,7 @@ def main():
     pkg.build()
     ctx = pkg.Context(0, torch.cuda.current_stream().cuda_stream)
     out = {}
-    for k, nb in [(64, 4096), (100, 2048), (128, 1024), (320, 512), (1000, 256)]:
+    for k, nb in [(64, 4096), (100, 4096), (128, 4096), (160, 4096), (320, 4096), (1000, 1024)]:
         n = 200
         g = torch.Generator(device="cuda").manual_seed(k)
         H = torch.randn(nb, k, n, generator=g, dtype=torch.float64, device="cuda")

@@ -67,7 +67,7 @@ def lattice(cfg, device):
     return ax(cfg["nx"] * cfg["dx"], nh), ax(cfg["ny"] * cfg["dx"], nh), ax(cfg["ztop"], nhz), nh, nhz
 
 
-def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1):
+def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval="iid"):
     cfg = CONFIGS[cfg_name]
     nx, ny, nz, k = cfg["nx"], cfg["ny"], cfg["nz"], cfg["k"]
     dx, hloc, vloc, sp_o, err = cfg["dx"], cfg["hloc"], cfg["vloc"], cfg["spacing"], cfg["err"]
@@ -137,9 +137,44 @@ def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1):
     mean0 = [10.0, 5.0, 0.1, 280.0, 8.0e4] + [5e-3] * (nv - 5)
     for v in range(nv):
         gv[v].normal_(mean0[v], sig[v], generator=g)
+    if ensval == "correlated":
+        # spatially smooth member perturbations (coarse noise, trilinear upsampling) under the white part, so that the
+        # H-like obs-space perturbations of correlate_ensval() are correlated between neighbouring observations
+        import torch.nn.functional as F
+        nzc, nyc, nxc = max(2, nz // 4), max(2, ny // 8), max(2, nx // 8)
+        for v in range(nv):
+            coarse = torch.randn(1, k, nzc, nyc, nxc, generator=g, device=device, dtype=torch.float32)
+            up = F.interpolate(coarse, size=(nz, ny, nx), mode="trilinear", align_corners=True)[0].reshape(k, npts)
+            gv[v, :k] = mean0[v] + 0.3 * (gv[v, :k] - mean0[v]) + (0.95 * sig[v]) * up.to(f64)
+            del coarse, up
     return dict(cfg=cfg, name=cfg_name, k=k, nv=nv, npts=npts, nens=nens, kld=kld, nobs=nobs, ensval=ensval, dep=dep,
                 obs_off=obs_off, obs_idx=obs_idx, rdiag=rdiag, rloc=rloc, gues=gues, sp=1, sm=npts, sv=npts * nens,
-                n_mean=float(counts.double().mean()), n_max=int(counts.max()), det_run=det_run)
+                n_mean=float(counts.double().mean()), n_max=int(counts.max()), det_run=det_run, ensval_kind=ensval,
+                sig=sig, gen=g)
+
+
+def correlate_ensval(w):
+    """obs-space perturbations as an H-like linear combination of the state perturbations
+    around the observation (here: of u and T at the nearest grid point) plus unit noise, so that Y and X' -- and the
+    rows of Y among themselves -- are correlated.  Call after the perturbation pass (gues holds x')."""
+    cfg = w["cfg"]
+    dev_ = w["gues"].device
+    nx, ny, nz, k = cfg["nx"], cfg["ny"], cfg["nz"], w["k"]
+    ox, oy, oz, _, _ = lattice(cfg, dev_)
+    nox, noy = len(ox), len(oy)
+    zlev = torch.from_numpy(level_heights(nz, cfg["ztop"])).to(dev_)
+    ix = torch.clamp(torch.floor(ox / cfg["dx"]).long(), 0, nx - 1)
+    iy = torch.clamp(torch.floor(oy / cfg["dx"]).long(), 0, ny - 1)
+    iz = torch.argmin((oz[:, None] - zlev[None, :]).abs(), dim=1)
+    # lattice row index = (iz*noy + iy)*nox + ix
+    pt = ((iz[:, None, None] * ny + iy[None, :, None]) * nx + ix[None, None, :]).reshape(-1)
+    gv = w["gues"].view(w["nv"], w["nens"], w["npts"])
+    sig = w["sig"]
+    noise = torch.randn(w["nobs"], k, generator=w["gen"], device=dev_, dtype=torch.float64)
+    noise -= noise.mean(dim=1, keepdim=True)
+    y = (1.2 / sig[0]) * gv[0, :k][:, pt].T + (0.8 / sig[3]) * gv[3, :k][:, pt].T + 0.5 * noise
+    w["ensval"][:, :k] = 1.6 * y
+    del noise, y
 
 
 def alg_bytes_per_solve(n, k, nv, det=False):
@@ -154,7 +189,7 @@ def alg_flops_per_solve(n, k, nv, rtps=True):
     return f
 
 
-def search_tables(w, pkg, device):
+def search_tables(w, pkg, device, max_nobs=0):
     """The same C2-style lattice as build(), described the way set_letkf_obs leaves it behind (one radar ctype, mesh of
     letkf_obs.f90:655-695, rows sorted (j, i)), so that the lists can come from letkf_obs_search_dev instead of
     torch.  Returns (tables struct, keepalive, row order, point coordinate tensors)."""
@@ -194,6 +229,31 @@ def search_tables(w, pkg, device):
                 ac_off=torch.zeros(1, dtype=torch.int64, device=device), ac_ext=ac.reshape(-1).to(torch.int32),
                 ob_ri=ri[order].contiguous(), ob_rj=rj[order].contiguous(), ob_lev=lev[order].contiguous(),
                 ob_dat=torch.full_like(ri, 1.0e5), ob_err=torch.full_like(ri, cfg["err"]))
+    t.limit_hint = 2 if max_nobs > 0 else 1
+    if max_nobs > 0:
+        # SURVEY.md section 8(d) variant: two radar ctypes (REF, Vr) on the same lattice, each limited to max_nobs
+        # observations per grid point.  The second ctype's rows follow the first's in the table (its own prefix sums
+        # shifted by the row count) and get their own obs-space perturbations and departures.
+        nrow = ri.numel()
+        g2 = torch.Generator(device=device)
+        g2.manual_seed(cfg["seed"] + 4242)
+        ens2 = torch.randn(w["ensval"].shape, generator=g2, device=device, dtype=f64) * 2.0
+        ens2[:, :w["k"]] -= ens2[:, :w["k"]].mean(dim=1, keepdim=True)
+        dep2 = torch.randn(nrow, generator=g2, device=device, dtype=f64) * float(w["dep"].std())
+        w["ensval"] = torch.cat([w["ensval"], ens2])
+        w["dep"] = torch.cat([w["dep"], dep2])
+        order = torch.cat([order, order + nrow])
+        t.nctype, t.ngroup = 2, 2
+        rep = lambda a: a.repeat(2)
+        keep = dict(group_start=i32([0, 1, 2]), group_member=i32([0, 1]), vmode=i32([1, 1]),
+                    hori_loc=rep(keep["hori_loc"]), vert_loc=rep(keep["vert_loc"]), varloc=d64([1.0, 1.0]),
+                    max_nobs=i32([max_nobs, max_nobs]), ngrd_i=rep(keep["ngrd_i"]), ngrd_j=rep(keep["ngrd_j"]),
+                    ngrdsch_i=rep(keep["ngrdsch_i"]), ngrdsch_j=rep(keep["ngrdsch_j"]),
+                    ngrdext_i=rep(keep["ngrdext_i"]), ngrdext_j=rep(keep["ngrdext_j"]),
+                    ac_off=torch.tensor([0, keep["ac_ext"].numel()], dtype=torch.int64, device=device),
+                    ac_ext=torch.cat([keep["ac_ext"], keep["ac_ext"] + nrow]).contiguous(),
+                    ob_ri=rep(keep["ob_ri"]), ob_rj=rep(keep["ob_rj"]), ob_lev=rep(keep["ob_lev"]),
+                    ob_dat=rep(keep["ob_dat"]), ob_err=rep(keep["ob_err"]))
     for k, v in keep.items():
         setattr(t, k, v.data_ptr())
     zlev = torch.from_numpy(level_heights(nz, cfg["ztop"])).to(device)

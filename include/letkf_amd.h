@@ -209,7 +209,9 @@ typedef struct {
   int32_t ngroup;             /* merged groups (letkf_tools.f90:167-192); a lone ctype is a group of one */
   int32_t criterion;          /* MAX_NOBS_PER_GRID_CRITERION: 1 distance, 2 weight, 3 error */
   int32_t nlon, nlat;         /* interior size of the (sub)domain the mesh was built on */
-  int32_t reserved0;
+  int32_t limit_hint;         /* what the HOST knows about max_nobs (a device array): 0 unknown -- the search entries read
+                                 it back and synchronise the stream once per call; 1 no combined type has a limit;
+                                 2 at least one has.  Set it to keep a pipeline of calls free of host synchronisation. */
   double dx, dy;              /* DX, DY */
   double i_org, j_org;        /* ri - i_org is (ril - IHALO - 0.5) of ij_obsgrd_ext (letkf_obs.f90:1221) */
   double rain_base;           /* VERT_LOCAL_RAIN_BASE */
@@ -235,7 +237,7 @@ typedef struct {
  * Two-phase CSR build: call with fill = 0 to get counts[npts]; exclusive-scan them into obs_off[npts+1] (any
  * scan; torch.cumsum in the harness); call again with fill = 1 to write obs_idx / rdiag_l / rloc_l.
  * All pointers are device pointers (the tables struct itself is passed by value from the host).  Synchronises the
- * stream once (max_nobs is read back: tables with a limit get an LDS candidate cache). */
+ * stream once (max_nobs is read back: tables with a limit get an LDS candidate cache) unless tables->limit_hint is set. */
 int letkf_obs_search_dev(letkf_ctx *ctx, const letkf_search_tables *tables, int64_t npts, const double *ri,
                          const double *rj, const double *rlev, const double *rz, int32_t fill, int32_t *counts,
                          const int64_t *obs_off, int32_t *obs_idx, double *rdiag_l, double *rloc_l);
@@ -243,16 +245,25 @@ int letkf_obs_search_dev(letkf_ctx *ctx, const letkf_search_tables *tables, int6
 
 /* (3a) Column-cooperative variant for the reference's own point layout: point p = ij + nij1*lev, rig / rjg [nij1]
  * (rig1, rjg1), rlev / rz [nij1*nlev] (gues3d(:,:,mmean,iv3d_p), hgt1).  One wavefront per horizontal point evaluates
- * the horizontal part of obs_local_cal once per observation and only the vertical part per level; lists identical,
- * entry for entry, to letkf_obs_search_dev on the expanded coordinates.  No-limit mode only (every max_nobs == 0),
- * else LETKF_E_INVALID.  Same two-phase protocol (fill = 0: counts[nij1*nlev]; fill = 1: write).  nobs_ctype (dev
- * [nij1*nlev][nctype] or NULL, either phase): accepted rows per combined type = nobsl_t of obs_local
- * (letkf_tools.f90:1473-1475), the input of the NOBS_OUT diagnostic (:440-447; its cut-off distances are the constants
- * hori_loc * dist_zero_fac in this mode, :1384-1389).  Synchronises the stream once (it checks max_nobs). */
+ * the horizontal part of obs_local_cal once per observation and only the vertical part per level.
+ * Without a limit: lists identical, entry for entry, to letkf_obs_search_dev on the expanded coordinates.
+ * With MAX_NOBS_PER_GRID (all three criteria, merged groups under the master's limit, :1434-1436, :1479-1729): per
+ * level the N best of the column's survivors are chosen by the same radix select -- the same selected SET as
+ * letkf_obs_search_dev and the reference (up to ties), emitted in candidate order.
+ * Same two-phase protocol (fill = 0: counts[nij1*nlev]; fill = 1: write).  Diagnostics, either phase, dev
+ * [nij1*nlev][nctype] or NULL -- the inputs of NOBS_OUT (:440-447):
+ *   nobs_ctype  nobsl_t of obs_local: accepted rows per combined type; for a limited group the selected count, on
+ *               its master (:1633, :1713), 0 on the other members;
+ *   cutd_ctype  cutd_t (:1384-1389, :1636-1640, :1716-1727) on the master of every group: criterion 1
+ *               hori_loc * dist_zero_fac, or hori_loc * sqrt(largest selected distance) once the limit is hit;
+ *               criterion 2 / 3: 0, or the smallest selected weight / largest selected error once it is hit.  (When
+ *               exactly N observations lie inside the cut-off the reference reports the one its incremental search
+ *               found LAST, :1637; here it is the farthest of the N.)
+ * Synchronises the stream once unless tables->limit_hint says what max_nobs holds. */
 int letkf_obs_search_columns_dev(letkf_ctx *ctx, const letkf_search_tables *tables, int64_t nij1, int32_t nlev,
                                  const double *rig, const double *rjg, const double *rlev, const double *rz,
                                  int32_t fill, int32_t *counts, const int64_t *obs_off, int32_t *obs_idx,
-                                 double *rdiag_l, double *rloc_l, int32_t *nobs_ctype);
+                                 double *rdiag_l, double *rloc_l, int32_t *nobs_ctype, double *cutd_ctype);
 
 /* (3b) The loop body with obs_local FUSED IN: no local lists at all -- every wavefront walks the sorting mesh of
  * `tables` for its own point (same candidate order as letkf_obs_search_dev, so the results are bit-identical to
@@ -443,6 +454,9 @@ int letkf_infl_init_dev(letkf_ctx *ctx, int64_t n, double *work3d, double infl_m
 /* Kernel timing helper for bench.py: average duration (ms) of the last
  * letkf_das_points_dev / letkf_core_batch_dev launches measured with HIP events on the
  * context's stream since the previous reset; *nlaunch receives the count. */
+/* Name(s) of the kernel(s) the context's last letkf_das_points*_dev / letkf_core_batch_dev call went through, as a
+ * NUL-terminated string (truncated to len): what bench.py reports as roofline.kernel. */
+int letkf_ctx_last_path(letkf_ctx *ctx, char *buf, int32_t len);
 int letkf_ctx_timing_enable(letkf_ctx *ctx, int enable);
 int letkf_ctx_timing_read(letkf_ctx *ctx, double *avg_ms, int64_t *nlaunch, int reset);
 

@@ -59,7 +59,7 @@ class DasArgs(C.Structure):
 class SearchTables(C.Structure):
     """letkf_search_tables (include/letkf_amd.h section 3)"""
     _fields_ = [("nctype", C.c_int32), ("ngroup", C.c_int32), ("criterion", C.c_int32), ("nlon", C.c_int32),
-                ("nlat", C.c_int32), ("reserved0", C.c_int32), ("dx", C.c_double), ("dy", C.c_double),
+                ("nlat", C.c_int32), ("limit_hint", C.c_int32), ("dx", C.c_double), ("dy", C.c_double),
                 ("i_org", C.c_double), ("j_org", C.c_double), ("rain_base", C.c_double),
                 ("group_start", C.c_void_p), ("group_member", C.c_void_p), ("vmode", C.c_void_p),
                 ("hori_loc", C.c_void_p), ("vert_loc", C.c_void_p), ("varloc", C.c_void_p), ("max_nobs", C.c_void_p),
@@ -136,7 +136,7 @@ EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", 
            "letkf_additive_inflation_dev", "letkf_addinfl_weight_dev",
            "letkf_var_local_classes", "letkf_ctype_merge_groups", "letkf_radar_only", "letkf_relax_beta_dev",
            "letkf_infl_init_dev",
-           "letkf_ctx_timing_enable", "letkf_ctx_timing_read"]
+           "letkf_ctx_timing_enable", "letkf_ctx_timing_read", "letkf_ctx_last_path"]
 
 _lib = None
 
@@ -199,6 +199,11 @@ class Context:
 
     def timing_enable(self, on=True):
         self._check(self._l.letkf_ctx_timing_enable(self._c, C.c_int(1 if on else 0)))
+
+    def last_path(self):
+        buf = C.create_string_buffer(256)
+        self._check(self._l.letkf_ctx_last_path(self._c, buf, C.c_int32(256)))
+        return buf.value.decode()
 
     def timing_read(self, reset=True):
         avg = C.c_double(0.0)
@@ -267,14 +272,14 @@ class Context:
                                                  _ptr(obs_idx), _ptr(rdiag), _ptr(rloc)))
         return obs_off, obs_idx[:nnz], rdiag[:nnz], rloc[:nnz]
 
-    def obs_search_columns(self, tables, nij1, nlev, rig, rjg, rlev, rz, nobs_ctype=None):
+    def obs_search_columns(self, tables, nij1, nlev, rig, rjg, rlev, rz, nobs_ctype=None, cutd_ctype=None):
         """Column-cooperative obs_local for points p = ij + nij1*lev; same return as obs_search."""
         import torch
         npts = nij1 * nlev
         counts = torch.zeros(npts, dtype=torch.int32, device=rig.device)
         f = self._l.letkf_obs_search_columns_dev
         self._check(f(self._c, C.byref(tables), C.c_int64(nij1), C.c_int32(nlev), _ptr(rig), _ptr(rjg), _ptr(rlev),
-                      _ptr(rz), C.c_int32(0), _ptr(counts), None, None, None, None, _ptr(nobs_ctype)))
+                      _ptr(rz), C.c_int32(0), _ptr(counts), None, None, None, None, _ptr(nobs_ctype), _ptr(cutd_ctype)))
         obs_off = torch.zeros(npts + 1, dtype=torch.int64, device=rig.device)
         obs_off[1:] = torch.cumsum(counts.to(torch.int64), 0)
         nnz = int(obs_off[-1].item())
@@ -282,7 +287,7 @@ class Context:
         rdiag = torch.empty(max(nnz, 1), dtype=torch.float64, device=rig.device)
         rloc = torch.empty(max(nnz, 1), dtype=torch.float64, device=rig.device)
         self._check(f(self._c, C.byref(tables), C.c_int64(nij1), C.c_int32(nlev), _ptr(rig), _ptr(rjg), _ptr(rlev),
-                      _ptr(rz), C.c_int32(1), None, _ptr(obs_off), _ptr(obs_idx), _ptr(rdiag), _ptr(rloc), None))
+                      _ptr(rz), C.c_int32(1), None, _ptr(obs_off), _ptr(obs_idx), _ptr(rdiag), _ptr(rloc), None, None))
         return obs_off, obs_idx[:nnz], rdiag[:nnz], rloc[:nnz]
 
     # ---- (5) set_letkf_obs on the device

@@ -50,6 +50,7 @@ struct letkf_ctx {
   size_t scratch_bytes = 0;
   char* staged_ws = nullptr;  // staged path: per-point slabs of a batch + meta / info words
   size_t staged_ws_bytes = 0;
+  std::string last_path;      // kernels the last loop-body / letkf_core launch went through (bench.py reports it)
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 };
@@ -215,6 +216,8 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
     a.prof = prof_dev;
 #endif
     HIP_TRY(letkf::launch_wave_kernel(a, c->num_cu, c->stream));
+    c->last_path = "letkf_wave_kernel<KR=" + std::to_string(letkf::wave_kernel_kr(a.k)) + ",NV=" + std::to_string(a.nv) +
+                   ",NW=" + (a.k <= 62 ? "1" : "2") + (a.mode == 2 ? ",FUSED" : "") + ">";
 #ifdef LETKF_WAVE_PROF
     {
       unsigned long long h[10];
@@ -227,8 +230,10 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
       std::fprintf(stderr, " total=%llu\n", tot);
     }
 #endif
-  } else
+  } else {
     HIP_TRY(letkf::launch_point_kernel(a, p.lp, c->stream));
+    c->last_path = p.lp.big ? "letkf_point_kernel<BIG>" : "letkf_point_kernel<LDS>";
+  }
   if (c->timing) {
     HIP_TRY(hipEventRecord(ev.e1, c->stream));
     c->events.emplace_back(ev.e0, ev.e1);
@@ -289,6 +294,9 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
     c->events.emplace_back(ev.e0, ev.e1);
     ev.e0 = ev.e1 = nullptr;
   }
+  c->last_path = std::string("staged: letkf_stage_gram_kernel + ") +
+                 (a.k <= 128 ? "letkf_eig_wg_kernel<4,32,32,1>" : "letkf_eig_wg_kernel<4,52,16,2>") +
+                 (a.k > s.wg_max_order ? " / letkf_eig_block_kernel" : "") + " + letkf_stage_apply_kernel";
   return LETKF_OK;
 }
 
@@ -372,6 +380,12 @@ int letkf_ctx_synchronize(letkf_ctx* c) {
   return LETKF_OK;
 }
 
+int letkf_ctx_last_path(letkf_ctx* c, char* buf, int32_t len) {
+  if (!c || !buf || len < 1) return fail(LETKF_E_INVALID, "bad argument");
+  std::snprintf(buf, (size_t)len, "%s", c->last_path.c_str());
+  return LETKF_OK;
+}
+
 int letkf_ctx_timing_enable(letkf_ctx* c, int enable) {
   if (int rc = check_ctx(c)) return rc;
   c->timing = enable != 0;
@@ -439,6 +453,20 @@ int letkf_core_batch_dev(letkf_ctx* c, const letkf_core_batch_args* g) {
 
 namespace {
 
+// does any combined type carry a MAX_NOBS_PER_GRID limit?  From the host's hint when given, else read back (one sync)
+int tables_limited(letkf_ctx* c, const letkf_search_tables* t, bool* limited) {
+  if (t->limit_hint == 1 || t->limit_hint == 2) {
+    *limited = t->limit_hint == 2;
+    return LETKF_OK;
+  }
+  std::vector<int32_t> mx(t->nctype);
+  HIP_TRY(hipMemcpyAsync(mx.data(), t->max_nobs, sizeof(int32_t) * t->nctype, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *limited = false;
+  for (int ic = 0; ic < t->nctype; ++ic) *limited |= mx[ic] > 0;
+  return LETKF_OK;
+}
+
 // shared by the list-driven and the fused-search entry
 int das_points_impl(letkf_ctx* c, const letkf_das_args* g, const letkf_search_tables* t, const double* ri,
                     const double* rj, const double* rlev, const double* rz, int32_t* nobs_out) {
@@ -499,13 +527,11 @@ int das_points_impl(letkf_ctx* c, const letkf_das_args* g, const letkf_search_ta
       return fail(LETKF_E_INVALID, "the fused search needs the one-wave kernel (k <= 62, nv = 11): build lists with "
                                    "letkf_obs_search_dev and call letkf_das_points_dev instead");
     // only the no-limit mode of obs_local is fused (letkf_tools.f90:1438-1476)
-    std::vector<int32_t> mx(t->nctype);
-    HIP_TRY(hipMemcpyAsync(mx.data(), t->max_nobs, sizeof(int32_t) * t->nctype, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int ic = 0; ic < t->nctype; ++ic)
-      if (mx[ic] > 0)
-        return fail(LETKF_E_INVALID, "MAX_NOBS_PER_GRID > 0: build lists with letkf_obs_search_dev (radix select) "
-                                     "and call letkf_das_points_dev");
+    bool limited = false;
+    if (int rc = tables_limited(c, t, &limited)) return rc;
+    if (limited)
+      return fail(LETKF_E_INVALID, "MAX_NOBS_PER_GRID > 0: build lists with letkf_obs_search_columns_dev / "
+                                   "letkf_obs_search_dev (radix select) and call letkf_das_points_dev");
     if (g->trans_out || g->pa_out) return fail(LETKF_E_INVALID, "the fused search has no k x k outputs");
     a.mode = 2;
     a.stab = *t;
@@ -572,12 +598,10 @@ int letkf_obs_search_dev(letkf_ctx* c, const letkf_search_tables* t, int64_t npt
   a.obs_idx = obs_idx;
   a.rdiag_l = rdiag_l;
   a.rloc_l = rloc_l;
-  {   // MAX_NOBS_PER_GRID anywhere?  (nctype ints back to the host; the fill phase then gets its LDS candidate cache)
-    std::vector<int32_t> mx(t->nctype);
-    HIP_TRY(hipMemcpyAsync(mx.data(), t->max_nobs, sizeof(int32_t) * t->nctype, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    a.limited = 0;
-    for (int ic = 0; ic < t->nctype; ++ic) a.limited |= mx[ic] > 0;
+  {   // MAX_NOBS_PER_GRID anywhere?  (the fill phase then gets its LDS candidate cache)
+    bool limited = false;
+    if (int rc = tables_limited(c, t, &limited)) return rc;
+    a.limited = limited ? 1 : 0;
   }
   HIP_TRY(letkf::launch_search(a, c->num_cu, c->stream));
   return LETKF_OK;
@@ -586,25 +610,28 @@ int letkf_obs_search_dev(letkf_ctx* c, const letkf_search_tables* t, int64_t npt
 int letkf_obs_search_columns_dev(letkf_ctx* c, const letkf_search_tables* t, int64_t nij1, int32_t nlev,
                                  const double* rig, const double* rjg, const double* rlev, const double* rz,
                                  int32_t fill, int32_t* counts, const int64_t* obs_off, int32_t* obs_idx,
-                                 double* rdiag_l, double* rloc_l, int32_t* nobs_ctype) {
+                                 double* rdiag_l, double* rloc_l, int32_t* nobs_ctype, double* cutd_ctype) {
   if (int rc = check_ctx(c)) return rc;
   if (!t || nij1 < 0 || nlev < 1) return fail(LETKF_E_INVALID, "tables is NULL or bad nij1 / nlev");
   if (nij1 == 0) return LETKF_OK;
   if (!rig || !rjg || !rlev || !rz) return fail(LETKF_E_INVALID, "a point coordinate array is NULL");
-  if (t->nctype < 1 || t->ngroup < 1) return fail(LETKF_E_INVALID, "bad nctype / ngroup");
+  if (t->nctype < 1 || t->ngroup < 1 || t->criterion < 1 || t->criterion > 3)
+    return fail(LETKF_E_INVALID, "bad nctype / ngroup / criterion");
   if (fill ? (!obs_off || !obs_idx || !rdiag_l || !rloc_l) : !counts)
     return fail(LETKF_E_INVALID, "missing output array for this phase");
-  if ((size_t)4 * (4 * 512 + 2 * ((nlev + 1) & ~1)) * sizeof(double) > c->lds_max)
+  if ((size_t)4 * (4 * 512 + 2 * ((nlev + 1) & ~1)) * sizeof(double) > c->lds_max ||
+      (size_t)4 * (5 * 896 + ((nlev + 1) & ~1)) * sizeof(double) + 4096 > c->lds_max)
     return fail(LETKF_E_INVALID, "too many levels for the column kernel's LDS counters");
-  std::vector<int32_t> mx(t->nctype);
-  HIP_TRY(hipMemcpyAsync(mx.data(), t->max_nobs, sizeof(int32_t) * t->nctype, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  for (int ic = 0; ic < t->nctype; ++ic)
-    if (mx[ic] > 0)
-      return fail(LETKF_E_INVALID, "MAX_NOBS_PER_GRID > 0: use letkf_obs_search_dev (per-point radix select)");
-  HIP_TRY(letkf::launch_search_columns(*t, nij1, nlev, rig, rjg, rlev, rz, fill, counts,
-                                       reinterpret_cast<const long*>(obs_off), obs_idx, rdiag_l, rloc_l, nobs_ctype,
-                                       c->num_cu, c->stream));
+  bool limited = false;
+  if (int rc = tables_limited(c, t, &limited)) return rc;
+  if (limited || cutd_ctype)
+    HIP_TRY(letkf::launch_search_columns_limited(*t, nij1, nlev, rig, rjg, rlev, rz, fill, counts,
+                                                 reinterpret_cast<const long*>(obs_off), obs_idx, rdiag_l, rloc_l,
+                                                 nobs_ctype, cutd_ctype, c->num_cu, c->stream));
+  else
+    HIP_TRY(letkf::launch_search_columns(*t, nij1, nlev, rig, rjg, rlev, rz, fill, counts,
+                                         reinterpret_cast<const long*>(obs_off), obs_idx, rdiag_l, rloc_l, nobs_ctype,
+                                         c->num_cu, c->stream));
   return LETKF_OK;
 }
 

@@ -124,8 +124,13 @@ hipError_t launch_search_columns(const letkf_search_tables& t, long nij1, int nl
                                  const long* obs_off, int* obs_idx, double* rdiag_l, double* rloc_l, int* nobs_ctype,
                                  int num_cu, hipStream_t st);
 
+hipError_t launch_search_columns_limited(const letkf_search_tables& t, long nij1, int nlev, const double* rig,
+                                         const double* rjg, const double* rlev, const double* rz, int fill, int* counts,
+                                         const long* obs_off, int* obs_idx, double* rdiag_l, double* rloc_l,
+                                         int* nobs_ctype, double* cutd_ctype, int num_cu, hipStream_t st);
 hipError_t launch_point_kernel(const PointArgs& a, const LaunchPlan& p, hipStream_t st);
 bool wave_kernel_supports(int k, int nv, int mode);
+int wave_kernel_kr(int k);   // rows of the instantiation that serves k
 void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, int* run_len, int* grid, size_t* ws_bytes);
 hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st);
 hipError_t launch_obs_departure(const letkf_qc_params& p, long nobs, const int* elm, const double* dat, const double* err,

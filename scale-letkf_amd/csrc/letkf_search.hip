@@ -509,6 +509,369 @@ __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Column-cooperative search WITH an observation-number limit (MAX_NOBS_PER_GRID > 0, letkf_tools.f90:1479-1729; the
+// production setting of the reference's radar configurations).  Per merged group (:1434-1436: the master's limit
+// rules the group) the horizontal survivors of ALL its members wait in LDS -- once per column, as above -- and every
+// level then (1) runs the vertical part over them and leaves each candidate's selection key in LDS, (2) if more than
+// nmax were accepted finds the nmax-th smallest key with the MSB-first radix select of the per-point kernel, on the
+// LDS keys, (3) walks the survivors once more in candidate order and emits the selected ones, re-evaluating the two
+// or three expressions of the vertical part for those (the same device function as in step 1: bit-identical).
+// The selected SET equals the per-point kernel's (and the reference's, up to ties); groups without a limit emit in
+// step 1.  A group whose survivors do not fit the buffer falls back to the per-point multi-sweep for that column.
+// Also fills the NOBS_OUT inputs (letkf_tools.f90:440-447): nobsl_t per combined type and the cut-off measure
+// cutd_t of :1604-1660 / :1716-1727 (criterion 1: hori_loc * sqrt(largest selected distance) once the limit is hit,
+// else hori_loc * dist_zero_fac; criterion 2 / 3: the smallest selected weight / largest selected error, else 0).
+// ---------------------------------------------------------------------------------------------
+constexpr int kSurvL = 896;                 // survivors of one group buffered per wave (32 B + 8 B key each)
+constexpr unsigned long long kNoKey = ~0ull;
+
+struct VertOut {
+  double nd, rloc, rdiag;
+  bool acc;
+};
+__device__ __forceinline__ VertOut vertical_cal(const int vm, const double vloc, const double varloc, const double vconst,
+                                                const double vref, const double nd_h, const double vobs, const double err) {
+#pragma clang fp contract(off)
+  VertOut o{0.0, 0.0, 0.0, false};
+  double nd_v;
+  if (vloc == 0.0) nd_v = 0.0;                        // :1851-1865
+  else if (vm == 3) nd_v = vconst;
+  else nd_v = fabs(vobs - vref) / vloc;
+  if (nd_v > kDistZeroFac) return o;                  // :1869
+  const double nd = nd_h * nd_h + nd_v * nd_v;        // :1888
+  if (nd > kDistZeroFacSq) return o;                  // :1891
+  o.nd = nd;
+  o.rloc = varloc * exp(-0.5 * nd);                   // :1899
+  o.rdiag = err * err / o.rloc;                       // :1903
+  o.acc = o.rloc != 0.0;                              // letkf_tools.f90:1460
+  return o;
+}
+
+// nmax-th smallest of the nk keys in LDS (kNoKey entries are never reached: want <= number of real keys)
+__device__ __forceinline__ void radix_thresh(const unsigned long long* keyl, const int nk, const int nmax,
+                                             unsigned int* hist, unsigned long long& thresh, int& tie_budget) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long prefix = 0ull;
+  int want = nmax;
+  for (int round = 0; round < 8; ++round) {
+    for (int b = lane; b < 256; b += 64) hist[b] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int shift = 56 - 8 * round;
+    for (int e = lane; e < nk; e += 64) {
+      const unsigned long long key = keyl[e];
+      if (key != kNoKey && (round == 0 || (key >> (shift + 8)) == prefix))
+        atomicAdd(&hist[(unsigned int)(key >> shift) & 0xFFu], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int cum = 0, bsel = 255;
+    find_bin(hist, want, bsel, cum);
+    want -= cum;
+    prefix = (round == 0) ? (unsigned long long)bsel : ((prefix << 8) | (unsigned long long)bsel);
+  }
+  thresh = prefix;
+  tie_budget = want;
+}
+
+struct ColLimArgs {
+  ColArgs c;
+  double* cutd_ctype;    // [npts][nctype] or null
+};
+
+__global__ void __launch_bounds__(256) letkf_search_columns_limited_kernel(const ColLimArgs L) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) double smem_lim[];
+  __shared__ unsigned int hist_all[4][256];
+  const ColArgs& A = L.c;
+  const letkf_search_tables& t = A.t;
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int nlev = A.nlev;
+  const int nl2 = (nlev + 1) & ~1;
+  const int cstride = 5 * kSurvL + nl2;                           // doubles per wave
+  double* sb = smem_lim + (size_t)wv * cstride;                   // [kSurvL][4]: (row, member), nd_h, v_obs, err
+  unsigned long long* keyl = reinterpret_cast<unsigned long long*>(sb + 4 * kSurvL);   // [kSurvL]
+  int* cntl = reinterpret_cast<int*>(sb + 5 * kSurvL);            // [nlev] entries emitted so far per level
+  unsigned int* hist = hist_all[wv];
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  SearchArgs PA;                                                  // for the per-point fall-back
+  PA.t = t;
+  PA.fill = A.fill;
+  PA.obs_idx = A.obs_idx;
+  PA.rdiag_l = A.rdiag_l;
+  PA.rloc_l = A.rloc_l;
+
+  for (long col = (long)blockIdx.x * 4 + wv; col < A.nij1; col += (long)gridDim.x * 4) {
+    const double ri = A.rig[col], rj = A.rjg[col];
+    for (int l = lane; l < nlev; l += 64) cntl[l] = 0;
+    if (A.nobs_ctype || L.cutd_ctype)                             // defaults: letkf_tools.f90:1380-1391, :1427-1432
+      for (int e = lane; e < nlev * t.nctype; e += 64) {
+        const int l = e / t.nctype, ic = e - l * t.nctype;
+        const long p = col + A.nij1 * (long)l;
+        if (A.nobs_ctype) A.nobs_ctype[p * t.nctype + ic] = 0;
+        if (L.cutd_ctype) L.cutd_ctype[p * t.nctype + ic] = 0.0;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    for (int ig = 0; ig < t.ngroup; ++ig) {
+      const int gs = t.group_start[ig], ge = t.group_start[ig + 1];
+      const int icm = t.group_member[gs];                         // master
+      const int nmax = t.max_nobs[icm];
+      // ---- horizontal part, all members of the group
+      int ns = 0;
+      bool overflow = false;
+      for (int m = gs; m < ge && !overflow; ++m) {
+        const int ic = t.group_member[m];
+        if (t.varloc[ic] < kTiny) continue;                       // local_cal :1843
+        const int vm = t.vmode[ic];
+        const double vloc = t.vert_loc[ic], hloc = t.hori_loc[ic];
+        const double dzi = hloc * kDistZeroFac / t.dx, dzj = hloc * kDistZeroFac / t.dy;
+        int imin, imax, jmin, jmax;
+        ij_obsgrd_ext(t, ic, ri - dzi, rj - dzj, imin, jmin);
+        ij_obsgrd_ext(t, ic, ri + dzi, rj + dzj, imax, jmax);
+        imin = max(imin, 1);
+        jmin = max(jmin, 1);
+        imax = min(imax, t.ngrdext_i[ic]);
+        jmax = min(jmax, t.ngrdext_j[ic]);
+        if (imin > imax || jmin > jmax) continue;
+        const long acb = t.ac_off[ic];
+        const int ld = t.ngrdext_i[ic] + 1;
+        for (int j = jmin; j <= jmax && !overflow; ++j) {
+          const int lo = t.ac_ext[acb + (imin - 1) + (long)ld * (j - 1)];
+          const int hi = t.ac_ext[acb + imax + (long)ld * (j - 1)];
+          for (int base = lo; base < hi; base += 64) {
+            const int row = base + lane;
+            bool ok = false;
+            double nd_h = 0.0, vobs = 0.0, err = 0.0;
+            if (row < hi) {
+              const double rdx = (ri - t.ob_ri[row]) * t.dx;      // :1876-1878
+              const double rdy = (rj - t.ob_rj[row]) * t.dy;
+              nd_h = sqrt(rdx * rdx + rdy * rdy) / hloc;
+              ok = !(nd_h > kDistZeroFac);                        // :1881
+              if (ok) {
+                if (vloc != 0.0) {
+                  if (vm == 1) vobs = t.ob_lev[row];
+                  else if (vm == 2) vobs = log(t.ob_dat[row]);
+                  else if (vm != 3) vobs = log(t.ob_lev[row]);
+                }
+                err = t.ob_err[row];
+              }
+            }
+            const unsigned long long mk = __ballot(ok);
+            const int na = __popcll(mk);
+            if (ns + na > kSurvL) {                               // (wave-uniform)
+              overflow = true;
+              break;
+            }
+            if (ok) {
+              const int si = ns + __popcll(mk & lt_mask);
+              const long packed = (long)(unsigned int)row | ((long)(m - gs) << 32);
+              *reinterpret_cast<double2*>(&sb[4 * si]) = double2{__longlong_as_double(packed), nd_h};
+              *reinterpret_cast<double2*>(&sb[4 * si + 2]) = double2{vobs, err};
+            }
+            ns += na;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const double cut_default = (t.criterion == 1) ? t.hori_loc[icm] * kDistZeroFac : 0.0;   // :1384-1389
+
+      for (int lev = 0; lev < nlev; ++lev) {
+        const long p = col + A.nij1 * (long)lev;
+        const long out = (A.fill ? A.obs_off[p] : 0) + cntl[lev];
+        int nsel = 0;
+        double cutd = cut_default;
+        int cm[4] = {0, 0, 0, 0};                                 // no-limit group: accepted rows per member (nobsl_t)
+        if (overflow) {
+          // ---- per-point multi-sweep for this (level, group): letkf_search_kernel's slow path
+          const double rlev = A.rlev[p], rz = A.rz[p];
+          SelState st{0ull, 56, 0ull, 0, 0};
+          if (nmax <= 0) {
+            nsel = A.fill ? sweep_group<kEmitAll>(PA, gs, ge, ri, rj, rlev, rz, out, st, hist)
+                          : sweep_group<kCount>(PA, gs, ge, ri, rj, rlev, rz, out, st, hist);
+          } else {
+            const int cnt = sweep_group<kCount>(PA, gs, ge, ri, rj, rlev, rz, out, st, hist);
+            if (cnt <= nmax) {
+              nsel = cnt;
+              if (A.fill) sweep_group<kEmitAll>(PA, gs, ge, ri, rj, rlev, rz, out, st, hist);
+            } else {
+              nsel = nmax;
+              if (A.fill || L.cutd_ctype) {
+                int want = nmax;
+                for (int round = 0; round < 8; ++round) {
+                  for (int b = lane; b < 256; b += 64) hist[b] = 0;
+                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                  __builtin_amdgcn_wave_barrier();
+                  st.shift = 56 - 8 * round;
+                  sweep_group<kHist>(PA, gs, ge, ri, rj, rlev, rz, out, st, hist);
+                  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                  __builtin_amdgcn_wave_barrier();
+                  int cum = 0, bsel = 255;
+                  find_bin(hist, want, bsel, cum);
+                  want -= cum;
+                  st.prefix = (round == 0) ? (unsigned long long)bsel : ((st.prefix << 8) | (unsigned long long)bsel);
+                }
+                st.thresh = st.prefix;
+                st.tie_budget = want;
+                st.emitted = 0;
+                if (A.fill) sweep_group<kEmitSelect>(PA, gs, ge, ri, rj, rlev, rz, out, st, hist);
+                const double kv = __longlong_as_double((long long)(t.criterion == 2 ? 0x7FFFFFFFFFFFFFFFull - st.thresh : st.thresh));
+                cutd = (t.criterion == 1) ? t.hori_loc[icm] * sqrt(kv) : kv;
+              }
+            }
+          }
+        } else {
+          const double vz = A.rz[p], vlnp = log(A.rlev[p]);
+          const double lnrain = log(t.rain_base);
+          // ---- (1) vertical part: keys (limited group) or straight emission (no limit)
+          int acc_n = 0;
+          for (int s0 = 0; s0 < ns; s0 += 64) {
+            const int si = s0 + lane;
+            VertOut vo{0.0, 0.0, 0.0, false};
+            int row = 0, ic = icm;
+            if (si < ns) {
+              const double2 a2 = *reinterpret_cast<const double2*>(&sb[4 * si]);
+              const double2 b2 = *reinterpret_cast<const double2*>(&sb[4 * si + 2]);
+              const long packed = __double_as_longlong(a2.x);
+              row = (int)(packed & 0xFFFFFFFFl);
+              ic = t.group_member[gs + (int)(packed >> 32)];
+              const int vm = t.vmode[ic];
+              const double vloc = t.vert_loc[ic];
+              const double vref = (vloc != 0.0) ? (vm == 1 ? vz : vlnp) : 0.0;
+              const double vconst = (vm == 3 && vloc != 0.0) ? fabs(lnrain - vref) / vloc : 0.0;
+              vo = vertical_cal(vm, vloc, t.varloc[ic], vconst, vref, a2.y, b2.x, b2.y);
+            }
+            const unsigned long long mk = __ballot(vo.acc);
+            if (nmax > 0) {
+              unsigned long long key = kNoKey;
+              if (vo.acc) {
+                CalOut c{vo.rloc, vo.rdiag, vo.nd};
+                key = key_bits(t.criterion, c);
+              }
+              if (si < ns) keyl[si] = key;
+            } else {
+              if (A.fill && vo.acc) {
+                const long o = out + acc_n + __popcll(mk & lt_mask);
+                A.obs_idx[o] = row;
+                A.rdiag_l[o] = vo.rdiag;
+                A.rloc_l[o] = vo.rloc;
+              }
+              if (A.nobs_ctype) {
+#pragma unroll
+                for (int mo = 0; mo < 4; ++mo)
+                  if (gs + mo < ge) cm[mo] += __popcll(__ballot(vo.acc && ic == t.group_member[gs + mo]));
+              }
+            }
+            acc_n += __popcll(mk);
+          }
+          nsel = acc_n;
+          if (nmax > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            nsel = min(acc_n, nmax);
+            unsigned long long thresh = kNoKey;                  // every real key is below it
+            int tie_budget = 0;
+            if (acc_n >= nmax && (acc_n > nmax ? (A.fill || L.cutd_ctype) : L.cutd_ctype != nullptr)) {
+              // (2) the nmax-th smallest key: selection threshold, and the cut-off measure once the limit is hit
+              radix_thresh(keyl, ns, nmax, hist, thresh, tie_budget);
+              const double kv = __longlong_as_double((long long)(t.criterion == 2 ? 0x7FFFFFFFFFFFFFFFull - thresh : thresh));
+              cutd = (t.criterion == 1) ? t.hori_loc[icm] * sqrt(kv) : kv;
+              if (acc_n == nmax) {
+                thresh = kNoKey;
+                tie_budget = 0;
+              }
+            }
+            if (A.fill) {
+              // (3) emission in candidate order
+              int emitted = 0;
+              for (int s0 = 0; s0 < ns; s0 += 64) {
+                const int si = s0 + lane;
+                bool take = false, tie = false;
+                if (si < ns) {
+                  const unsigned long long key = keyl[si];
+                  take = key != kNoKey && key < thresh;
+                  tie = key != kNoKey && thresh != kNoKey && key == thresh;
+                }
+                const unsigned long long mk = __ballot(take);
+                const unsigned long long tk = __ballot(tie);
+                const int tpos = __popcll(tk & lt_mask);
+                const bool tsel = tie && tpos < tie_budget;
+                if (take || tsel) {
+                  const double2 a2 = *reinterpret_cast<const double2*>(&sb[4 * si]);
+                  const double2 b2 = *reinterpret_cast<const double2*>(&sb[4 * si + 2]);
+                  const long packed = __double_as_longlong(a2.x);
+                  const int ic = t.group_member[gs + (int)(packed >> 32)];
+                  const int vm = t.vmode[ic];
+                  const double vloc = t.vert_loc[ic];
+                  const double vref = (vloc != 0.0) ? (vm == 1 ? vz : vlnp) : 0.0;
+                  const double vconst = (vm == 3 && vloc != 0.0) ? fabs(lnrain - vref) / vloc : 0.0;
+                  const VertOut vo = vertical_cal(vm, vloc, t.varloc[ic], vconst, vref, a2.y, b2.x, b2.y);
+                  const long o = out + emitted + (take ? __popcll(mk & lt_mask) : __popcll(mk) + tpos);
+                  A.obs_idx[o] = (int)(packed & 0xFFFFFFFFl);
+                  A.rdiag_l[o] = vo.rdiag;
+                  A.rloc_l[o] = vo.rloc;
+                }
+                const int nt = min(__popcll(tk), tie_budget);
+                tie_budget -= nt;
+                emitted += __popcll(mk) + nt;
+              }
+            }
+            if (acc_n < nmax) cutd = cut_default;
+          }
+        }
+        if (lane == 0) {
+          cntl[lev] += nsel;
+          if (A.nobs_ctype) {
+            if (nmax > 0) {
+              A.nobs_ctype[p * t.nctype + icm] = nsel;            // nobsl_t of the master (:1633, :1713)
+            } else if (!overflow) {
+#pragma unroll
+              for (int mo = 0; mo < 4; ++mo)
+                if (gs + mo < ge) A.nobs_ctype[p * t.nctype + t.group_member[gs + mo]] = cm[mo];
+            } else {
+              A.nobs_ctype[p * t.nctype + icm] = nsel;            // (fall-back path: the group's total on its master)
+            }
+          }
+          if (L.cutd_ctype) L.cutd_ctype[p * t.nctype + icm] = cutd;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    if (!A.fill)
+      for (int l = lane; l < nlev; l += 64) A.counts[col + A.nij1 * (long)l] = cntl[l];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+hipError_t launch_search_columns_limited(const letkf_search_tables& t, long nij1, int nlev, const double* rig,
+                                         const double* rjg, const double* rlev, const double* rz, int fill, int* counts,
+                                         const long* obs_off, int* obs_idx, double* rdiag_l, double* rloc_l,
+                                         int* nobs_ctype, double* cutd_ctype, int num_cu, hipStream_t st) {
+  ColLimArgs a{{t, nij1, nlev, rig, rjg, rlev, rz, fill, counts, obs_off, obs_idx, rdiag_l, rloc_l, nobs_ctype},
+               cutd_ctype};
+  const size_t lds = (size_t)4 * (5 * kSurvL + ((nlev + 1) & ~1)) * sizeof(double);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_search_columns_limited_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const long nwg = (nij1 + 3) / 4;
+  const long g = (long)num_cu * 8;
+  const int grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
+  hipLaunchKernelGGL(letkf_search_columns_limited_kernel, dim3(grid), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_search_columns(const letkf_search_tables& t, long nij1, int nlev, const double* rig,
                                  const double* rjg, const double* rlev, const double* rz, int fill, int* counts,
                                  const long* obs_off, int* obs_idx, double* rdiag_l, double* rloc_l, int* nobs_ctype,

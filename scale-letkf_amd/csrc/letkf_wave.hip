@@ -1415,7 +1415,9 @@ bool wave_kernel_supports(int k, int nv, int mode) {
   return nv == 0;
 }
 
-static int wave_kr(int k) {
+int wave_kernel_kr(int k);
+static int wave_kr(int k) { return wave_kernel_kr(k); }
+int wave_kernel_kr(int k) {
   return k <= 16 ? 16 : k <= 32 ? 32 : k <= 48 ? 48 : k <= 50 ? 50 : k <= 62 ? 64 : k <= 64 ? 64 : k <= 80 ? 80 : 100;
 }
 

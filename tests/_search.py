@@ -11,7 +11,7 @@ DIST_ZERO_FAC = float(np.float32(3.651483717))
 
 class SearchTables(C.Structure):
     _fields_ = [("nctype", C.c_int32), ("ngroup", C.c_int32), ("criterion", C.c_int32), ("nlon", C.c_int32),
-                ("nlat", C.c_int32), ("reserved0", C.c_int32), ("dx", C.c_double), ("dy", C.c_double),
+                ("nlat", C.c_int32), ("limit_hint", C.c_int32), ("dx", C.c_double), ("dy", C.c_double),
                 ("i_org", C.c_double), ("j_org", C.c_double), ("rain_base", C.c_double),
                 ("group_start", C.c_void_p), ("group_member", C.c_void_p), ("vmode", C.c_void_p),
                 ("hori_loc", C.c_void_p), ("vert_loc", C.c_void_p), ("varloc", C.c_void_p), ("max_nobs", C.c_void_p),

@@ -89,7 +89,88 @@ def test_column_search_equals_point_search(nlev):
     assert torch.equal(o1, o2) and int(o1[-1]) > 100 * nlev
     assert torch.equal(i1, i2)
     assert torch.equal(d1, d2) and torch.equal(l1, l2)
-    limited = build_case(31, npts=90, max_nobs=(25, 25, 10, 5))
-    t2, keep2 = device_struct(limited, "cuda")
-    with pytest.raises(RuntimeError):
-        c.obs_search_columns(t2, nij1, nlev, dev(rig), dev(rjg), dev(rlev), dev(rz))
+
+
+@pytest.mark.parametrize("criterion", [1, 2, 3])
+@pytest.mark.parametrize("nlev,max_nobs", [(7, (25, 25, 10, 5)), (3, (40, 0, 0, 7)), (60, (30, 30, 30, 30))])
+def test_column_search_with_obs_number_limit(criterion, nlev, max_nobs):
+    """MAX_NOBS_PER_GRID on the column path (letkf_tools.f90:1479-1729; merged group (0, 1) under its master's limit,
+    :1434-1436): per point the same SET as the per-point kernel -- which the oracle tests pin to the reference's
+    selection -- with the same weights, plus the NOBS_OUT inputs nobsl_t and cutd_t (:1633-1640, :1713-1727)."""
+    from _gpu import ctx, dev
+    case = build_case(33 + criterion, npts=70, max_nobs=max_nobs, criterion=criterion)
+    t, keep = device_struct(case, "cuda")
+    p = case["pts"]
+    nij1 = 70
+    rng = np.random.default_rng(nlev)
+    rig, rjg = p["ri"], p["rj"]
+    rlev = rng.uniform(2.5e4, 1.0e5, nij1 * nlev)
+    rz = rng.uniform(0.0, 12000.0, nij1 * nlev)
+    c = ctx()
+    o1, i1, d1, l1 = c.obs_search(t, dev(np.tile(rig, nlev)), dev(np.tile(rjg, nlev)), dev(rlev), dev(rz))
+    nct = torch.full((nij1 * nlev, 4), -1, dtype=torch.int32, device="cuda")
+    cut = torch.full((nij1 * nlev, 4), -1.0, dtype=torch.float64, device="cuda")
+    o2, i2, d2, l2 = c.obs_search_columns(t, nij1, nlev, dev(rig), dev(rjg), dev(rlev), dev(rz), nobs_ctype=nct,
+                                          cutd_ctype=cut)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
+    o1, i1, d1, l1, i2, d2, l2 = (x.cpu().numpy() for x in (o1, i1, d1, l1, i2, d2, l2))
+    nct, cut = nct.cpu().numpy(), cut.cpu().numpy()
+    edges = np.asarray(case["ctype_rows"])
+    a = case["arr"]
+    groups = case["groups"]
+    hit = 0
+    for pt in range(nij1 * nlev):
+        s = slice(o1[pt], o1[pt + 1])
+        e1 = sorted(zip(i1[s].tolist(), d1[s].tolist(), l1[s].tolist()))
+        e2 = sorted(zip(i2[s].tolist(), d2[s].tolist(), l2[s].tolist()))
+        assert e1 == e2, pt                                     # same rows, weights to the last bit
+        which = np.searchsorted(edges, i2[s], side="right") - 1
+        for g in groups:
+            master = g[0]
+            nmax = max_nobs[master]
+            sel = np.isin(which, g)
+            nsel = int(sel.sum())
+            if nmax > 0:
+                assert nsel <= nmax
+                assert nct[pt, master] == nsel
+                for ic in g[1:]:
+                    assert nct[pt, ic] == 0 and cut[pt, ic] == 0.0
+                default = a["hori_loc"][master] * float(np.float32(3.651483717)) if criterion == 1 else 0.0
+                if nsel < nmax:
+                    assert cut[pt, master] == default
+                else:
+                    hit += 1
+                    rl, rd = l2[s][sel], d2[s][sel]
+                    if criterion == 2:
+                        assert cut[pt, master] == rl.min()
+                    elif criterion == 3:
+                        assert cut[pt, master] == rd.max()
+                    else:
+                        # largest selected normalised distance^2: rloc = varloc exp(-nd / 2), per member varloc
+                        vl = a["varloc"][which[sel]]
+                        nd = -2.0 * np.log(rl / vl)
+                        want = a["hori_loc"][master] * np.sqrt(nd.max())
+                        assert abs(cut[pt, master] - want) <= 1e-9 * want
+            else:
+                for ic in g:
+                    assert nct[pt, ic] == int((which == ic).sum())
+    assert hit > 20                                             # the limit was actually reached
+
+
+def test_search_limit_hint_spares_the_sync():
+    """limit_hint = 1 / 2 must give the same lists as the read-back (hint 0)"""
+    from _gpu import ctx, dev
+    for mx, hint in (((0, 0, 0, 0), 1), ((20, 20, 5, 0), 2)):
+        case = build_case(5, npts=40, max_nobs=mx)
+        p = case["pts"]
+        c = ctx()
+        t0, k0 = device_struct(case, "cuda")
+        t1, k1 = device_struct(case, "cuda")
+        t1.limit_hint = hint
+        a = c.obs_search_columns(t0, 40, 1, dev(p["ri"]), dev(p["rj"]), dev(p["rlev"]), dev(p["rz"]))
+        b = c.obs_search_columns(t1, 40, 1, dev(p["ri"]), dev(p["rj"]), dev(p["rlev"]), dev(p["rz"]))
+        a2 = c.obs_search(t0, dev(p["ri"]), dev(p["rj"]), dev(p["rlev"]), dev(p["rz"]))
+        b2 = c.obs_search(t1, dev(p["ri"]), dev(p["rj"]), dev(p["rlev"]), dev(p["rz"]))
+        for x, y in zip(a + a2, b + b2):
+            assert torch.equal(x, y)
