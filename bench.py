@@ -95,7 +95,7 @@ def main():
 
     if args.max_nobs > 0 and args.lists not in ("columns", "search"):
         sys.exit("--max-nobs needs --lists columns or search (the device obs_local)")
-    w = bw.build(args.workload, dev, rank=rank, world=world, ensval=args.ensval)
+    w = bw.build(args.workload, dev, rank=rank, world=world, ensval_kind=args.ensval)
     k, nv, npts = w["k"], w["nv"], w["npts"]
     # the streaming passes either side of the loop: mean into slot k, members -> perturbations
     ctx.ens_mean(k, nv, npts, w["gues"], w["sp"], w["sm"], w["sv"])

@@ -67,7 +67,7 @@ def lattice(cfg, device):
     return ax(cfg["nx"] * cfg["dx"], nh), ax(cfg["ny"] * cfg["dx"], nh), ax(cfg["ztop"], nhz), nh, nhz
 
 
-def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval="iid"):
+def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval_kind="iid"):
     cfg = CONFIGS[cfg_name]
     nx, ny, nz, k = cfg["nx"], cfg["ny"], cfg["nz"], cfg["k"]
     dx, hloc, vloc, sp_o, err = cfg["dx"], cfg["hloc"], cfg["vloc"], cfg["spacing"], cfg["err"]
@@ -137,7 +137,7 @@ def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval="iid")
     mean0 = [10.0, 5.0, 0.1, 280.0, 8.0e4] + [5e-3] * (nv - 5)
     for v in range(nv):
         gv[v].normal_(mean0[v], sig[v], generator=g)
-    if ensval == "correlated":
+    if ensval_kind == "correlated":
         # spatially smooth member perturbations (coarse noise, trilinear upsampling) under the white part, so that the
         # H-like obs-space perturbations of correlate_ensval() are correlated between neighbouring observations
         import torch.nn.functional as F
@@ -149,7 +149,7 @@ def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval="iid")
             del coarse, up
     return dict(cfg=cfg, name=cfg_name, k=k, nv=nv, npts=npts, nens=nens, kld=kld, nobs=nobs, ensval=ensval, dep=dep,
                 obs_off=obs_off, obs_idx=obs_idx, rdiag=rdiag, rloc=rloc, gues=gues, sp=1, sm=npts, sv=npts * nens,
-                n_mean=float(counts.double().mean()), n_max=int(counts.max()), det_run=det_run, ensval_kind=ensval,
+                n_mean=float(counts.double().mean()), n_max=int(counts.max()), det_run=det_run, ensval_kind=ensval_kind,
                 sig=sig, gen=g)
 
 
@@ -209,8 +209,10 @@ def search_tables(w, pkg, device, max_nobs=0):
     nsch_i = math.ceil(hloc * DIST_ZERO_FAC / (dx * nx / ngrd_i))
     nsch_j = math.ceil(hloc * DIST_ZERO_FAC / (dx * ny / ngrd_j))
     next_i, next_j = ngrd_i + 2 * nsch_i, ngrd_j + 2 * nsch_j
-    ogi = torch.ceil(ri * ngrd_i / nx).long() + nsch_i
-    ogj = torch.ceil(rj * ngrd_j / ny).long() + nsch_j
+    # (lattice rows beyond the extended mesh -- a halo lattice can reach a fraction of a spacing past the cut-off -- are
+    # clamped into its edge cells: they are outside every point's cut-off anyway)
+    ogi = (torch.ceil(ri * ngrd_i / nx).long() + nsch_i).clamp(1, next_i)
+    ogj = (torch.ceil(rj * ngrd_j / ny).long() + nsch_j).clamp(1, next_j)
     cell = (ogj - 1) * next_i + (ogi - 1)
     order = torch.argsort(cell, stable=True)
     counts = torch.bincount(cell, minlength=next_i * next_j).view(next_j, next_i)
