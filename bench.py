@@ -46,6 +46,9 @@ def main():
                          "smooth) state perturbations around every observation + noise (SURVEY.md section 8(d))")
     ap.add_argument("--max-nobs", type=int, default=0,
                     help="MAX_NOBS_PER_GRID: two radar ctypes on the lattice, each limited to this many observations")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "lib"],
+                    help="N > 1: the obs all-gather through torch.distributed (default) or through the library's own "
+                         "letkf_obs_allgatherv_dev on an RCCL communicator this script creates (ncclCommInitRank)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(affinity, cgroup quota, 16 = the box's CPU share)")
     args = ap.parse_args()
 
@@ -145,11 +148,34 @@ def main():
         rows = w["ensval"].shape[0]
         cuts = [round(rows * r / world) for r in range(world + 1)]
         shard = w["ensval"][cuts[rank]:cuts[rank + 1]].clone()
+        if args.exchange == "lib":
+            # the host's side of C-ABI section 8: an RCCL communicator of its own (the unique id travels through the
+            # process group that is already up), handed to the library as a plain pointer
+            import ctypes as C
+
+            class UniqueId(C.Structure):
+                _fields_ = [("internal", C.c_char * 128)]
+            rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+            uid = UniqueId()
+            if rank == 0:
+                assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+            ub = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=dev)
+            dist.broadcast(ub, 0)
+            C.memmove(C.byref(uid), bytes(ub.cpu().tolist()), 128)
+            ncomm = C.c_void_p()
+            rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+            assert rccl.ncclCommInitRank(C.byref(ncomm), world, uid, rank) == 0
+            counts_x = [cuts[r + 1] - cuts[r] for r in range(world)]
+            gathered = torch.empty_like(w["ensval"])
 
     def step():
         ens = w["ensval"]
         if world > 1:
-            ens, _ = sharding.allgatherv_rows(shard)
+            if args.exchange == "lib":
+                ctx.obs_allgatherv(ncomm.value, rank, counts_x, shard, gathered)
+                ens = gathered
+            else:
+                ens, _ = sharding.allgatherv_rows(shard)
         if in_step:
             # the whole das_letkf-equivalent call: obs_local for every point, then the batched loop body
             w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"] = do_search()
@@ -236,7 +262,7 @@ def main():
                                       f"relax={args.relax}, ensval={args.ensval}"
                                       + (f", MAX_NOBS_PER_GRID={args.max_nobs} x 2 ctypes" if args.max_nobs else ""),
                           "points_per_gpu": npts, "obs_table_rows": int(w["ensval"].shape[0]),
-                          "parallelism": f"grid-point shard x{n_gpus}" + (" + RCCL obs all-gather" if world > 1 else "")},
+                          "parallelism": f"grid-point shard x{n_gpus}" + ((" + RCCL obs all-gather (" + args.exchange + ")") if world > 1 else "")},
                "analysis_wall_s": elapsed / args.steps, "cycle_ms": elapsed / args.steps * 1e3,
                "solve_only_solves_per_s": (npts * world / kern_s) if kern_s > 0 else None,
                "nonzero_status_points": bad,

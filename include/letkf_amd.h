@@ -454,6 +454,19 @@ int letkf_infl_init_dev(letkf_ctx *ctx, int64_t n, double *work3d, double infl_m
 /* Kernel timing helper for bench.py: average duration (ms) of the last
  * letkf_das_points_dev / letkf_core_batch_dev launches measured with HIP events on the
  * context's stream since the previous reset; *nlaunch receives the count. */
+/*---------------------------------------------------------------------------
+ * (8) The path's one exchange: MPI_ALLGATHERV of the sorted observation buffers (and, with the same call, of the
+ *     mesh-cell counts) over the subdomain ranks, scale/letkf/letkf_obs.f90:1036-1046 / :826-831, on an RCCL
+ *     communicator owned by the host (nccl_comm = the host's ncclComm_t, created with ncclCommInitRank; one rank per
+ *     GPU).  Grouped ncclSend / ncclRecv with the TRUE row counts on the context's stream: rank r's counts[r] rows of
+ *     row_bytes bytes land in recv behind the rows of ranks 0 .. r-1 (rank-major = the receive buffer obsbufr the
+ *     extended-subdomain plan of section 5 indexes).  counts: HOST [nranks] (every rank knows them from the
+ *     all-reduced cell counts, as in the reference).  send: dev [counts[myrank] * row_bytes], recv: dev
+ *     [sum(counts) * row_bytes].  Asynchronous on the stream; LETKF_E_INVALID when RCCL is not loadable.
+ *-------------------------------------------------------------------------*/
+int letkf_obs_allgatherv_dev(letkf_ctx *ctx, void *nccl_comm, int32_t nranks, int32_t myrank, const int64_t *counts,
+                             int64_t row_bytes, const void *send, void *recv);
+
 /* Name(s) of the kernel(s) the context's last letkf_das_points*_dev / letkf_core_batch_dev call went through, as a
  * NUL-terminated string (truncated to len): what bench.py reports as roofline.kernel. */
 int letkf_ctx_last_path(letkf_ctx *ctx, char *buf, int32_t len);

@@ -135,7 +135,7 @@ EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", 
            "letkf_obs_gather_rows_dev", "letkf_obs_gather_i32_dev", "letkf_monit_dep_dev",
            "letkf_additive_inflation_dev", "letkf_addinfl_weight_dev",
            "letkf_var_local_classes", "letkf_ctype_merge_groups", "letkf_radar_only", "letkf_relax_beta_dev",
-           "letkf_infl_init_dev",
+           "letkf_infl_init_dev", "letkf_obs_allgatherv_dev",
            "letkf_ctx_timing_enable", "letkf_ctx_timing_read", "letkf_ctx_last_path"]
 
 _lib = None
@@ -355,6 +355,16 @@ class Context:
                                                      C.c_int64(ob_ri.numel()), _ptr(ob_ri), _ptr(ob_rj),
                                                      C.c_double(dx), C.c_double(dy), C.c_double(hori_loc), _ptr(w)))
         return w
+
+    # ---- (8) the exchange, on an RCCL communicator the caller owns (an integer / c_void_p ncclComm_t)
+    def obs_allgatherv(self, nccl_comm, myrank, counts, send, recv):
+        """counts: python ints per rank (rows); send / recv: device tensors whose rows are contiguous."""
+        n = len(counts)
+        cnt = (C.c_int64 * n)(*[int(x) for x in counts])
+        row_bytes = send.element_size() * (send[0].numel() if send.dim() > 1 and send.shape[0] > 0 else
+                                           (recv[0].numel() if recv.dim() > 1 else 1))
+        self._check(self._l.letkf_obs_allgatherv_dev(self._c, C.c_void_p(nccl_comm), C.c_int32(n), C.c_int32(myrank),
+                                                     cnt, C.c_int64(row_bytes), _ptr(send), _ptr(recv)))
 
     # ---- (7) das_letkf set-up
     def relax_beta(self, params, nij1, nlev, rig, rjg, hgt, beta):

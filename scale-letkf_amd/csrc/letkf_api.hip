@@ -741,6 +741,24 @@ int letkf_addinfl_weight_dev(letkf_ctx* c, int64_t nij1, const double* rig, cons
   return LETKF_OK;
 }
 
+int letkf_obs_allgatherv_dev(letkf_ctx* c, void* nccl_comm, int32_t nranks, int32_t myrank, const int64_t* counts,
+                             int64_t row_bytes, const void* send, void* recv) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!nccl_comm || nranks < 1 || myrank < 0 || myrank >= nranks || !counts || row_bytes < 1)
+    return fail(LETKF_E_INVALID, "bad communicator / rank layout / counts");
+  int64_t total = 0;
+  for (int r = 0; r < nranks; ++r) {
+    if (counts[r] < 0) return fail(LETKF_E_INVALID, "negative row count");
+    total += counts[r];
+  }
+  if ((counts[myrank] > 0 && !send) || (total > 0 && !recv)) return fail(LETKF_E_INVALID, "a buffer is NULL");
+  const char* what = "";
+  const int rc = letkf::rccl_allgatherv(nccl_comm, nranks, myrank, counts, row_bytes, send, recv, c->stream, &what);
+  if (rc == -1) return fail(LETKF_E_INVALID, "RCCL (librccl.so.1) is not available in this process");
+  if (rc != 0) return fail(LETKF_E_HIP, std::string("RCCL: ") + what);
+  return LETKF_OK;
+}
+
 int letkf_relax_beta_dev(letkf_ctx* c, const letkf_beta_params* p, int64_t nij1, int32_t nlev, const double* rig,
                          const double* rjg, const double* hgt, double* beta) {
   if (int rc = check_ctx(c)) return rc;

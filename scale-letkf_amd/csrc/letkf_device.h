@@ -152,6 +152,8 @@ hipError_t launch_additive(int k, int nv, long npts, long nij1, double* anal, co
 hipError_t launch_addinfl_weight(long nij1, const double* rig, const double* rjg, long nob, const double* ob_ri,
                                  const double* ob_rj, double dx, double dy, double hori_loc, double cut2, double* w,
                                  int num_cu, hipStream_t st);
+int rccl_allgatherv(void* comm, int nranks, int myrank, const int64_t* counts, int64_t row_bytes, const void* send,
+                    void* recv, hipStream_t st, const char** what);
 hipError_t launch_relax_beta(const letkf_beta_params& p, long nij1, int nlev, const double* rig, const double* rjg,
                              const double* hgt, double* beta, int num_cu, hipStream_t st);
 hipError_t launch_infl_init(long n, double* w, double infl_mul, double infl_mul_min, int num_cu, hipStream_t st);

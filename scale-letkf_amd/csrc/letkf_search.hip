@@ -124,6 +124,18 @@ __device__ __forceinline__ int sweep_group(const SearchArgs& A, const int gs, co
 // per candidate: 634 ms for C2 with two ctypes limited to 100, more than the solve).  A group whose accepted
 // candidates do not fit the cache (kCacheCap) falls back to that multi-sweep path.
 // ---------------------------------------------------------------------------------------------
+// inclusive prefix sum over the 64 lanes on the vector ALU (DPP row shifts + row broadcasts: the sequence LLVM's
+// atomic optimiser emits for gfx9), instead of six ds_bpermute round trips
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // In which of the 256 histogram bins does the `want`-th smallest key (1-based) fall, and how many keys lie in the bins
 // before it?  Lane l owns bins 4l..4l+3; a wave prefix sum over the lane totals finds the lane, the lane its bin.
 // (The first version walked the 256 bins one dependent LDS read at a time: 8 rounds x 256 reads per group dominated
@@ -132,12 +144,7 @@ __device__ __forceinline__ void find_bin(const unsigned int* hist, const int wan
   const int lane = threadIdx.x & 63;
   const uint4 h = *reinterpret_cast<const uint4*>(&hist[4 * lane]);
   const int s = (int)(h.x + h.y + h.z + h.w);
-  int incl = s;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += o;
-  }
+  const int incl = wave_incl_scan(s);            // DPP, not six ds_bpermute round trips
   const int excl = incl - s;
   const bool here = excl < want && incl >= want;
   int b = 4 * lane, cum = excl;
@@ -160,8 +167,8 @@ __device__ __forceinline__ void find_bin(const unsigned int* hist, const int wan
     return;
   }
   const int src = __ffsll((long long)mk) - 1;
-  bsel = __shfl(b, src, 64);
-  before = __shfl(cum, src, 64);
+  bsel = __builtin_amdgcn_readlane(b, src);
+  before = __builtin_amdgcn_readlane(cum, src);
 }
 
 constexpr int kCacheCap = 512;
@@ -549,7 +556,30 @@ __device__ __forceinline__ VertOut vertical_cal(const int vm, const double vloc,
   return o;
 }
 
-// nmax-th smallest of the nk keys in LDS (kNoKey entries are never reached: want <= number of real keys)
+// the cut-off tests alone (distance criterion: the selection key is nd itself, and rloc = varloc exp(-nd/2) cannot
+// be zero inside the cut-off unless varloc is denormal-small, so the exponential and the error division are only
+// needed for the observations that end up selected)
+__device__ __forceinline__ VertOut vertical_nd(const int vm, const double vloc, const double varloc, const double vconst,
+                                               const double vref, const double nd_h, const double vobs, const double err) {
+#pragma clang fp contract(off)
+  if (varloc < 1e-290) return vertical_cal(vm, vloc, varloc, vconst, vref, nd_h, vobs, err);
+  VertOut o{0.0, 0.0, 0.0, false};
+  double nd_v;
+  if (vloc == 0.0) nd_v = 0.0;
+  else if (vm == 3) nd_v = vconst;
+  else nd_v = fabs(vobs - vref) / vloc;
+  if (nd_v > kDistZeroFac) return o;
+  const double nd = nd_h * nd_h + nd_v * nd_v;
+  if (nd > kDistZeroFacSq) return o;
+  o.nd = nd;
+  o.acc = true;
+  return o;
+}
+
+// nmax-th smallest of the nk keys in LDS (kNoKey entries are never reached: want <= number of real keys).  MSB-first,
+// 8 bits per round; the rounds stop as soon as the bin that holds the wanted key holds nothing else -- with ~500
+// double keys that is after 3-4 rounds, not 8 (the top two bytes are sign / exponent and nearly constant).
+// (10-bit digits were measured too: fewer rounds, but clearing and scanning 1024 bins per round cost more.)
 __device__ __forceinline__ void radix_thresh(const unsigned long long* keyl, const int nk, const int nmax,
                                              unsigned int* hist, unsigned long long& thresh, int& tie_budget) {
   const int lane = threadIdx.x & 63;
@@ -571,6 +601,22 @@ __device__ __forceinline__ void radix_thresh(const unsigned long long* keyl, con
     find_bin(hist, want, bsel, cum);
     want -= cum;
     prefix = (round == 0) ? (unsigned long long)bsel : ((prefix << 8) | (unsigned long long)bsel);
+    if (round < 7 && hist[bsel] == 1u) {
+      // a single key left in the class: it is the threshold
+      unsigned long long found = 0ull;
+      for (int e = lane; e < nk; e += 64) {
+        const unsigned long long key = keyl[e];
+        if (key != kNoKey && (key >> shift) == prefix) found = key;
+      }
+      // (a key is 0 only for a distance of exactly zero: then `found` stays 0 in every lane, and 0 is the answer)
+      const unsigned long long mk = __ballot(found != 0ull);
+      const int src = mk ? __ffsll((long long)mk) - 1 : 0;
+      const unsigned int flo = __builtin_amdgcn_readlane((unsigned int)found, src);
+      const unsigned int fhi = __builtin_amdgcn_readlane((unsigned int)(found >> 32), src);
+      thresh = ((unsigned long long)fhi << 32) | flo;
+      tie_budget = 1;
+      return;
+    }
   }
   thresh = prefix;
   tie_budget = want;
@@ -682,6 +728,19 @@ __global__ void __launch_bounds__(256) letkf_search_columns_limited_kernel(const
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const double cut_default = (t.criterion == 1) ? t.hori_loc[icm] * kDistZeroFac : 0.0;   // :1384-1389
+      // the members' vertical parameters, once per group (wave-uniform; up to 4 members are selected per lane by
+      // compares -- per-lane table look-ups inside the level loop were a third of the kernel's time)
+      int vm_m[4], ic_m[4];
+      double vloc_m[4], varloc_m[4];
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) {
+        const int ic = t.group_member[min(gs + mo, ge - 1)];
+        ic_m[mo] = ic;
+        vm_m[mo] = t.vmode[ic];
+        vloc_m[mo] = t.vert_loc[ic];
+        varloc_m[mo] = t.varloc[ic];
+      }
+      const bool many = ge - gs > 4;                              // (not expected: the reference merges two types)
 
       for (int lev = 0; lev < nlev; ++lev) {
         const long p = col + A.nij1 * (long)lev;
@@ -741,12 +800,28 @@ __global__ void __launch_bounds__(256) letkf_search_columns_limited_kernel(const
               const double2 b2 = *reinterpret_cast<const double2*>(&sb[4 * si + 2]);
               const long packed = __double_as_longlong(a2.x);
               row = (int)(packed & 0xFFFFFFFFl);
-              ic = t.group_member[gs + (int)(packed >> 32)];
-              const int vm = t.vmode[ic];
-              const double vloc = t.vert_loc[ic];
+              const int mo = (int)(packed >> 32);
+              int vm = vm_m[0];
+              double vloc = vloc_m[0], varloc = varloc_m[0];
+              ic = ic_m[0];
+#pragma unroll
+              for (int u = 1; u < 4; ++u)
+                if (mo == u) {
+                  vm = vm_m[u];
+                  vloc = vloc_m[u];
+                  varloc = varloc_m[u];
+                  ic = ic_m[u];
+                }
+              if (many && mo >= 4) {
+                ic = t.group_member[gs + mo];
+                vm = t.vmode[ic];
+                vloc = t.vert_loc[ic];
+                varloc = t.varloc[ic];
+              }
               const double vref = (vloc != 0.0) ? (vm == 1 ? vz : vlnp) : 0.0;
               const double vconst = (vm == 3 && vloc != 0.0) ? fabs(lnrain - vref) / vloc : 0.0;
-              vo = vertical_cal(vm, vloc, t.varloc[ic], vconst, vref, a2.y, b2.x, b2.y);
+              vo = (nmax > 0 && t.criterion == 1) ? vertical_nd(vm, vloc, varloc, vconst, vref, a2.y, b2.x, b2.y)
+                                                  : vertical_cal(vm, vloc, varloc, vconst, vref, a2.y, b2.x, b2.y);
             }
             const unsigned long long mk = __ballot(vo.acc);
             if (nmax > 0) {
@@ -766,7 +841,7 @@ __global__ void __launch_bounds__(256) letkf_search_columns_limited_kernel(const
               if (A.nobs_ctype) {
 #pragma unroll
                 for (int mo = 0; mo < 4; ++mo)
-                  if (gs + mo < ge) cm[mo] += __popcll(__ballot(vo.acc && ic == t.group_member[gs + mo]));
+                  if (gs + mo < ge) cm[mo] += __popcll(__ballot(vo.acc && ic == ic_m[mo]));
               }
             }
             acc_n += __popcll(mk);
@@ -808,12 +883,25 @@ __global__ void __launch_bounds__(256) letkf_search_columns_limited_kernel(const
                   const double2 a2 = *reinterpret_cast<const double2*>(&sb[4 * si]);
                   const double2 b2 = *reinterpret_cast<const double2*>(&sb[4 * si + 2]);
                   const long packed = __double_as_longlong(a2.x);
-                  const int ic = t.group_member[gs + (int)(packed >> 32)];
-                  const int vm = t.vmode[ic];
-                  const double vloc = t.vert_loc[ic];
+                  const int mo = (int)(packed >> 32);
+                  int vm = vm_m[0];
+                  double vloc = vloc_m[0], varloc = varloc_m[0];
+#pragma unroll
+                  for (int u = 1; u < 4; ++u)
+                    if (mo == u) {
+                      vm = vm_m[u];
+                      vloc = vloc_m[u];
+                      varloc = varloc_m[u];
+                    }
+                  if (many && mo >= 4) {
+                    const int ic = t.group_member[gs + mo];
+                    vm = t.vmode[ic];
+                    vloc = t.vert_loc[ic];
+                    varloc = t.varloc[ic];
+                  }
                   const double vref = (vloc != 0.0) ? (vm == 1 ? vz : vlnp) : 0.0;
                   const double vconst = (vm == 3 && vloc != 0.0) ? fabs(lnrain - vref) / vloc : 0.0;
-                  const VertOut vo = vertical_cal(vm, vloc, t.varloc[ic], vconst, vref, a2.y, b2.x, b2.y);
+                  const VertOut vo = vertical_cal(vm, vloc, varloc, vconst, vref, a2.y, b2.x, b2.y);
                   const long o = out + emitted + (take ? __popcll(mk & lt_mask) : __popcll(mk) + tpos);
                   A.obs_idx[o] = (int)(packed & 0xFFFFFFFFl);
                   A.rdiag_l[o] = vo.rdiag;

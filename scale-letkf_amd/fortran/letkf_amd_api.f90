@@ -71,6 +71,16 @@ MODULE letkf_amd_api
       REAL(c_double), VALUE :: infl_mul, infl_mul_min
       INTEGER(c_int) :: rc
     END FUNCTION
+    ! the exchange of letkf_obs.f90:1036-1046 on the host's RCCL communicator (section 8); counts is a HOST array
+    FUNCTION letkf_obs_allgatherv_dev(ctx, nccl_comm, nranks, myrank, counts, row_bytes, send, recv) &
+        BIND(C, name='letkf_obs_allgatherv_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t
+      TYPE(c_ptr), VALUE :: ctx, nccl_comm, send, recv
+      INTEGER(c_int32_t), VALUE :: nranks, myrank
+      INTEGER(c_int64_t), INTENT(IN) :: counts(nranks)
+      INTEGER(c_int64_t), VALUE :: row_bytes
+      INTEGER(c_int) :: rc
+    END FUNCTION
     FUNCTION letkf_amd_abi_version() BIND(C, name='letkf_amd_abi_version') RESULT(v)
       IMPORT :: c_int
       INTEGER(c_int) :: v

@@ -1,0 +1,38 @@
+"""The exchange entry of the library (C ABI section 8, letkf_obs_allgatherv_dev = MPI_ALLGATHERV of
+scale/letkf/letkf_obs.f90:1036-1046 as grouped ncclSend / ncclRecv) on a real RCCL communicator.  One GPU is all a test
+box has, so the communicator has one rank (send-to-self inside the group): that exercises the run-time binding of
+RCCL, the communicator hand-over from the host, stream ordering and the byte arithmetic; the N-rank behaviour is the
+same call pattern and is covered for the Python twin by tests/test_sharding_gloo.py."""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rccl():
+    return C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+
+def test_allgatherv_on_a_one_rank_communicator():
+    from _gpu import ctx
+    lib = rccl()
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(0)
+    assert lib.ncclCommInitAll(C.byref(comm), C.c_int(1), devs) == 0
+    try:
+        c = ctx()
+        for rows, cols, dt in [(1000, 51, torch.float64), (0, 51, torch.float64), (777, 1, torch.int32)]:
+            send = (torch.randn(rows, cols, device="cuda") * 100).to(dt)
+            recv = torch.full((max(rows, 1), cols), -1, dtype=dt, device="cuda")
+            c.obs_allgatherv(comm.value, 0, [rows], send, recv)
+            torch.cuda.synchronize()
+            assert torch.equal(recv[:rows], send)
+        # argument errors are reported, not executed
+        from _gpu import pkg
+        with pytest.raises(pkg.LetkfError):
+            c.obs_allgatherv(comm.value, 1, [5], send, recv)          # myrank out of range
+    finally:
+        lib.ncclCommDestroy(comm)
