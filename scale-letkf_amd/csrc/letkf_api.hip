@@ -185,7 +185,9 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
   // point with the matrix in LDS, or in the HBM workspace for large k (letkf_kernels.hip)
   const bool force_block = LETKF_KNOB("LETKF_AMD_FORCE_BLOCK") != nullptr;
   if (a.mode == 2 && force_block) return fail(LETKF_E_INVALID, "LETKF_AMD_FORCE_BLOCK: the workgroup kernel has no fused search");
-  const bool wave = !force_block && letkf::wave_kernel_supports(a.k, a.nv, a.mode);
+  bool wave = !force_block && letkf::wave_kernel_supports(a.k, a.nv, a.mode);
+  if (const char* e = LETKF_KNOB("LETKF_AMD_STAGED_MIN_K"))   // PROF knob: A/B the staged path against the two-wave kernel
+    if (a.mode != 2 && a.k >= std::atoi(e)) wave = false;
   // beyond the register kernels: the staged three-kernel path (the monolithic workgroup kernel below stays reachable
   // through the PROF twin's LETKF_AMD_FORCE_BLOCK / LETKF_AMD_MONOLITHIC knobs for A/B measurements)
   if (!wave && !force_block && a.mode != 2 && a.nv + 2 <= 16 && !LETKF_KNOB("LETKF_AMD_MONOLITHIC")) return launch_staged(c, a);

@@ -47,7 +47,8 @@ using jacobi_dev::fast_rsqrt1;
 
 struct Rot {
   double c, s, tg;   // cosine, sine, t * gamma
-  bool notconv;
+  bool notconv;      // |cos| > 1e-10
+  bool notconv2;     // |cos| > 1e-8 or |t| > 1e-6: the early-stop rule of letkf_jacobi_dev.h (kEarlyTol2W, kEarlyT2W)
 };
 
 // rotation that orthogonalises (lower column: norm^2 a, upper column: norm^2 b, inner product g); letkf_jacobi_dev.h
@@ -61,6 +62,7 @@ __device__ __forceinline__ Rot make_rot(const double a, const double b, const do
   const double hh = x * fast_rsqrt1(x);
   double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
   tt = rot ? tt : 0.0;
+  r.notconv2 = enable && (g2 > jacobi_dev::kEarlyTol2W * ab || tt * tt > jacobi_dev::kEarlyT2W);
   const double w = fma(tt, tt, 1.0);
   r.c = fast_rsqrt(w);
   r.s = r.c * tt;
@@ -69,9 +71,9 @@ __device__ __forceinline__ Rot make_rot(const double a, const double b, const do
 }
 
 // hipcc hoists every LDS read of an unrolled row loop to its top (17 doubles in flight, 34 VGPRs -- with 128 VGPRs per
-// lane that spills the columns themselves); a compiler-level fence every few rows keeps the loads where they are used
+// lane that spills the columns themselves); a compiler-level fence every 8 rows keeps the loads near their use (8 in flight)
 #define EIG_ROW_FENCE(rr) \
-  if (((rr) & 3) == 3) asm volatile("" ::: "memory")
+  if (((rr) & 7) == 7) asm volatile("" ::: "memory")
 
 // The two row updates, written as instruction sequences that work IN PLACE.  From C++ hipcc puts every new element of
 // the lower column into a fresh register (the old one is still an operand of the upper column's update), i.e. it
@@ -95,6 +97,8 @@ __device__ __forceinline__ void axpby_inplace(double& x, const double f, const d
       : "+v"(x)
       : "v"(f), "v"(g), "v"(y));
 }
+
+constexpr int kPF = 4;   // LDS rows in flight ahead of their use
 
 template <int NP>
 __device__ __forceinline__ double sum_parts(const double* p, const int stride) {
@@ -127,7 +131,8 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
   double* bbQ = bbP + kParts * RP;         // [8][RP]     mailbox: upper column of slot 63 (for slot 64)
   int* flags = reinterpret_cast<int*>(bbQ + kParts * RP);   // [2][16] convergence votes of the waves
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the branches on part / sb below are wave-uniform)
   const int part = wave / SB, sb = wave % SB;
   const int slot = sb * 64 + lane;
   const int tidm1 = tid > 0 ? tid - 1 : 0;
@@ -167,20 +172,21 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
       }
     }
     double alA = 0.0, alB = 0.0;
-    int quiet = 0, pairs = 0, sweep = 0;
-    bool done = false, odd_notconv_prev = false;
+    int quiet = 0, quiet2 = 0, pairs = 0, sweep = 0;
+    bool done = false, odd_notconv_prev = false, odd_notconv2_prev = false;
     int vph = 0;
     __syncthreads();
 
     for (; sweep < E.max_sweep && !done; ++sweep) {
       // ---- refresh the squared norms (they are carried by the rotation identities inside a sweep)
       {
-        double sa = 0.0, sbq = 0.0;
+        double sa = 0.0, sbq = 0.0, sab = 0.0;
 #pragma unroll
         for (int rr = 0; rr < RP; ++rr) {
           const double vb = rr < RBR ? breg[rr < RBR ? rr : 0] : blds[(size_t)(rr - RBR) * NT + tid];
           sa = fma(a[rr], a[rr], sa);
           sbq = fma(vb, vb, sbq);
+          sab = fma(a[rr], vb, sab);
           EIG_ROW_FENCE(rr);
         }
         pe[part * NS + slot] = sa;
@@ -189,40 +195,39 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
         alA = sum_parts<NP>(pe + slot, NS);
         alB = sum_parts<NP>(po + slot, NS);
         __syncthreads();
+        pe[part * NS + slot] = sab;                       // the first even step's inner product (see the odd step)
       }
       for (int t = 0; t < ncol && !done; t += 2) {
-        // ================= even step: the slot's own two columns
-        {
-          double p0 = 0.0, p1 = 0.0;
-#pragma unroll
-          for (int rr = 0; rr < RP; ++rr) {
-            const double vb = rr < RBR ? breg[rr < RBR ? rr : 0] : blds[(size_t)(rr - RBR) * NT + tid];
-            if (rr & 1) p1 = fma(a[rr], vb, p1);
-            else p0 = fma(a[rr], vb, p0);
-            EIG_ROW_FENCE(rr);
-          }
-          pe[part * NS + slot] = p0 + p1;
-        }
+        // ================= even step: the slot's own two columns.  Their inner product was accumulated while the
+        // previous odd step (or the norm refresh) had both columns in its hands: no pass of its own
         __syncthreads();                                  // (1)
-        bool notconv;
+        bool notconv, notconv2;
         {
           const double ga = sum_parts<NP>(pe + slot, NS);
           const Rot r = make_rot(alA, alB, ga, true);
           notconv = r.notconv;
+          notconv2 = r.notconv2;
           // rotate and swap: position 2s takes c B + s A, position 2s+1 takes c A - s B
           const double nA = alB + r.tg, nB = alA - r.tg;
           alA = nA;
           alB = nB;
+          // LDS rows: the loads run kPF rows ahead of their use, written out in the source -- hipcc cannot move a row's
+          // read above the previous row's write (every row has its own address register: no alias information), and
+          // left alone it emits read, s_waitcnt lgkmcnt(0), use for every single row
+          double pf[kPF];
+#pragma unroll
+          for (int u = 0; u < kPF; ++u)
+            if (RBR + u < RP) pf[u] = blds[(size_t)u * NT + tid];
 #pragma unroll
           for (int rr = 0; rr < RP; ++rr) {
             if (rr < RBR) {
               rot_inplace(a[rr], breg[rr < RBR ? rr : 0], r.c, r.s);
             } else {
-              double vb = blds[(size_t)(rr - RBR) * NT + tid];
+              double vb = pf[(rr - RBR) % kPF];
+              if (rr + kPF < RP) pf[(rr - RBR) % kPF] = blds[(size_t)(rr + kPF - RBR) * NT + tid];
               rot_inplace(a[rr], vb, r.c, r.s);
               blds[(size_t)(rr - RBR) * NT + tid] = vb;
             }
-            EIG_ROW_FENCE(rr);
           }
           if (part == 0) {
             pn[2 * slot] = alA;
@@ -242,39 +247,46 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
           }
           __syncthreads();                                // (2)
         }
-        // ================= odd step: upper column of slot s (Q_s) with the lower column of slot s+1 (P_{s+1})
+        // ================= odd step: upper column of slot s (Q_s) with the lower column of slot s+1 (P_{s+1}).
+        // The row loops below carry no branch, so that hipcc can issue the LDS reads of a fence group together (with a
+        // conditional mailbox read per row every LDS read was followed by its own s_waitcnt lgkmcnt(0): ~260 exposed
+        // LDS latencies per step pair, 2/3 of the kernel's time).  The slot pair that straddles the slot-blocks gets
+        // its partner through an UNCONDITIONAL term: every wave reads its mailbox row (one address for the whole wave)
+        // and multiplies it by a coefficient that is zero in all lanes but the one concerned.
+        const double* mbx = (SB == 2 && sb == 1) ? bbQ + part * RP : bbP + part * RP;   // (wave-uniform)
+        const double selP = bndR ? 1.0 : 0.0;
         {
           double p0 = 0.0, p1 = 0.0;
+          double pf[kPF];
+#pragma unroll
+          for (int u = 0; u < kPF; ++u)
+            if (RBR + u < RP) pf[u] = blds[(size_t)u * NT + tid];
 #pragma unroll
           for (int rr = 0; rr < RP; ++rr) {
-#if 1   // (see above)
+            // (register-only fences: without them hipcc fetches ALL rows of the neighbour first -- a third column in
+            // registers; volatile asm statements keep their order, so each row's fetch waits for the previous row's FMA)
             asm volatile("" : "+v"(a[rr]));
-#endif
-            double pr = dpp_shift0<0x130>(a[rr]);          // lane + 1
-            if constexpr (SB == 2) {
-              if (sb == 0) {                               // (wave-uniform)
-                const double mb = bbP[part * RP + rr];
-                pr = bndR ? mb : pr;
-              }
+            double pr = dpp_shift0<0x130>(a[rr]);          // lane + 1 (0 for lane 63)
+            if constexpr (SB == 2) pr = fma(selP, mbx[rr], pr);   // slot 63: its partner's column is in the mailbox
+            double q;
+            if (rr < RBR) {
+              q = breg[rr < RBR ? rr : 0];
+            } else {
+              q = pf[(rr - RBR) % kPF];
+              if (rr + kPF < RP) pf[(rr - RBR) % kPF] = blds[(size_t)(rr + kPF - RBR) * NT + tid];
             }
-            const double q = rr < RBR ? breg[rr < RBR ? rr : 0] : blds[(size_t)(rr - RBR) * NT + tid];
             if (rr & 1) {
               p1 = fma(q, pr, p1);
-#if 1   // (see above)
               asm volatile("" : "+v"(p1));
-#endif
             } else {
               p0 = fma(q, pr, p0);
-#if 1   // (see above)
               asm volatile("" : "+v"(p0));
-#endif
             }
-            EIG_ROW_FENCE(rr);
           }
-          po[part * NS + slot] = p0 + p1;
+          const double podd = p0 + p1;
+          po[part * NS + slot] = podd;
           // vote: this step pair's even step and the previous step pair's odd step
-          const bool v = notconv || odd_notconv_prev;
-          const int anyv = __any(v) ? 1 : 0;
+          const int anyv = (__any(notconv || odd_notconv_prev) ? 1 : 0) | (__any(notconv2 || odd_notconv2_prev) ? 2 : 0);
           if (lane == 0) flags[16 * vph + wave] = anyv;
         }
         __syncthreads();                                  // (3)
@@ -287,6 +299,7 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
           const Rot rR = make_rot(alB, nPr, gR, hasR);     // lower = Q_s, upper = P_{s+1}
           const Rot rL = make_rot(nQl, alA, gL, hasL);     // lower = Q_{s-1}, upper = P_s
           odd_notconv_prev = rR.notconv;
+          odd_notconv2_prev = rR.notconv2;
           // new upper column of slot s (position 2s+1) = c P_{s+1} + s Q_s ; new lower column (position 2s) = c Q_{s-1} - s P_s
           const double cp = hasR ? rR.c : 0.0, cq = hasR ? rR.s : 1.0;
           const double cql = hasL ? rL.c : 0.0, ca = hasL ? -rL.s : 1.0;
@@ -296,31 +309,36 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
 #pragma unroll
           for (int w = 0; w < NP * SB; ++w) anyf |= flags[16 * vph + w];
           vph ^= 1;
+          double fe0 = 0.0, fe1 = 0.0;
+          double pfq[kPF], pfl[kPF];
+#pragma unroll
+          for (int u = 0; u < kPF; ++u)
+            if (RBR + u < RP) {
+              pfq[u] = blds[(size_t)u * NT + tid];
+              pfl[u] = blds[(size_t)u * NT + tidm1];
+            }
 #pragma unroll
           for (int rr = 0; rr < RP; ++rr) {
-#if 1
+            // the neighbour's rows are fetched a second time (once for the inner product, once here); laundering a[rr]
+            // keeps hipcc from merging the two fetches across the barrier, and orders this row behind the previous one
             asm volatile("" : "+v"(a[rr]));
-#endif
             double pr = dpp_shift0<0x130>(a[rr]);
-            if constexpr (SB == 2) {
-              if (sb == 0) {
-                const double mb = bbP[part * RP + rr];
-                pr = bndR ? mb : pr;
-              }
-            }
             double q, ql;
             if (rr < RBR) {
               q = breg[rr < RBR ? rr : 0];
-              ql = dpp_shift0<0x138>(q);                   // lane - 1
+              ql = dpp_shift0<0x138>(q);                   // lane - 1 (0 for lane 0)
             } else {
-              q = blds[(size_t)(rr - RBR) * NT + tid];
-              ql = blds[(size_t)(rr - RBR) * NT + tidm1];
+              q = pfq[(rr - RBR) % kPF];
+              ql = pfl[(rr - RBR) % kPF];
+              if (rr + kPF < RP) {
+                pfq[(rr - RBR) % kPF] = blds[(size_t)(rr + kPF - RBR) * NT + tid];
+                pfl[(rr - RBR) % kPF] = blds[(size_t)(rr + kPF - RBR) * NT + tidm1];
+              }
             }
             if constexpr (SB == 2) {
-              if (sb == 1) {
-                const double mb = bbQ[part * RP + rr];
-                ql = bndL ? mb : ql;
-              }
+              const double mb = mbx[rr];
+              pr = fma(selP, mb, pr);                      // slot 63 <- lower column of slot 64
+              ql = bndL ? mb : ql;                         // slot 64 <- upper column of slot 63
             }
             if (rr < RBR) {
               axpby_inplace(breg[rr < RBR ? rr : 0], cq, cp, pr);
@@ -329,11 +347,23 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
               blds[(size_t)(rr - RBR) * NT + tid] = q;
             }
             axpby_inplace(a[rr], ca, cql, ql);
-            EIG_ROW_FENCE(rr);
+            // both new columns of the slot are in registers here: the next even step's inner product, for free
+            {
+              const double qn = rr < RBR ? breg[rr < RBR ? rr : 0] : q;
+              if (rr & 1) {
+                fe1 = fma(a[rr], qn, fe1);
+                asm volatile("" : "+v"(fe1));              // (keeps the rows in order: see the odd step's inner product)
+              } else {
+                fe0 = fma(a[rr], qn, fe0);
+                asm volatile("" : "+v"(fe0));
+              }
+            }
           }
+          pe[part * NS + slot] = fe0 + fe1;
           ++pairs;
-          quiet = anyf ? 0 : quiet + 1;
-          done = quiet >= S + 1;
+          quiet = (anyf & 1) ? 0 : quiet + 1;
+          quiet2 = (anyf & 2) ? 0 : quiet2 + 1;
+          done = quiet >= S + 1 || quiet2 >= S + 1;
         }
         if constexpr (SB == 2) {
           // the LDS rows of slot 63's upper column were just rewritten by its own wave while slot 64 (other wave) read
