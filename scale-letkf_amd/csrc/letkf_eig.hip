@@ -35,6 +35,12 @@
 #ifndef EIG_RBR2
 #define EIG_RBR2 16
 #endif
+#ifndef EIG_PF
+#define EIG_PF 4
+#endif
+#ifndef EIG_PM
+#define EIG_PM 4
+#endif
 
 namespace letkf {
 
@@ -98,7 +104,8 @@ __device__ __forceinline__ void axpby_inplace(double& x, const double f, const d
       : "v"(f), "v"(g), "v"(y));
 }
 
-constexpr int kPF = 4;   // LDS rows in flight ahead of their use
+constexpr int kPF = EIG_PF;   // LDS rows in flight ahead of their use
+constexpr int kPM = EIG_PM;   // mailbox rows in flight
 
 template <int NP>
 __device__ __forceinline__ double sum_parts(const double* p, const int stride) {
@@ -257,17 +264,25 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
         const double selP = bndR ? 1.0 : 0.0;
         {
           double p0 = 0.0, p1 = 0.0;
-          double pf[kPF];
+          double pf[kPF], pm[kPM];
 #pragma unroll
           for (int u = 0; u < kPF; ++u)
             if (RBR + u < RP) pf[u] = blds[(size_t)u * NT + tid];
+          if constexpr (SB == 2) {
+#pragma unroll
+            for (int u = 0; u < kPM; ++u)
+              if (u < RP) pm[u] = mbx[u];
+          }
 #pragma unroll
           for (int rr = 0; rr < RP; ++rr) {
             // (register-only fences: without them hipcc fetches ALL rows of the neighbour first -- a third column in
             // registers; volatile asm statements keep their order, so each row's fetch waits for the previous row's FMA)
             asm volatile("" : "+v"(a[rr]));
             double pr = dpp_shift0<0x130>(a[rr]);          // lane + 1 (0 for lane 63)
-            if constexpr (SB == 2) pr = fma(selP, mbx[rr], pr);   // slot 63: its partner's column is in the mailbox
+            if constexpr (SB == 2) {                        // slot 63: its partner's column is in the mailbox
+              pr = fma(selP, pm[rr % kPM], pr);
+              if (rr + kPM < RP) pm[rr % kPM] = mbx[rr + kPM];
+            }
             double q;
             if (rr < RBR) {
               q = breg[rr < RBR ? rr : 0];
@@ -310,13 +325,18 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
           for (int w = 0; w < NP * SB; ++w) anyf |= flags[16 * vph + w];
           vph ^= 1;
           double fe0 = 0.0, fe1 = 0.0;
-          double pfq[kPF], pfl[kPF];
+          double pfq[kPF], pfl[kPF], pm[kPM];
 #pragma unroll
           for (int u = 0; u < kPF; ++u)
             if (RBR + u < RP) {
               pfq[u] = blds[(size_t)u * NT + tid];
               pfl[u] = blds[(size_t)u * NT + tidm1];
             }
+          if constexpr (SB == 2) {
+#pragma unroll
+            for (int u = 0; u < kPM; ++u)
+              if (u < RP) pm[u] = mbx[u];
+          }
 #pragma unroll
           for (int rr = 0; rr < RP; ++rr) {
             // the neighbour's rows are fetched a second time (once for the inner product, once here); laundering a[rr]
@@ -336,7 +356,8 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
               }
             }
             if constexpr (SB == 2) {
-              const double mb = mbx[rr];
+              const double mb = pm[rr % kPM];
+              if (rr + kPM < RP) pm[rr % kPM] = mbx[rr + kPM];
               pr = fma(selP, mb, pr);                      // slot 63 <- lower column of slot 64
               ql = bndL ? mb : ql;                         // slot 64 <- upper column of slot 63
             }
