@@ -256,6 +256,10 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
   if (nb > want) nb = want;
   if (nb < 1) nb = 1;
   if (nb > a.npts) nb = a.npts;
+  {   // equal batches (a last batch of a few points would leave the chip idle for a whole eigen-solve)
+    const long nbat = (a.npts + nb - 1) / nb;
+    nb = (a.npts + nbat - 1) / nbat;
+  }
   const size_t slab_bytes = (size_t)nb * (size_t)wpp * sizeof(double);
   const size_t need = slab_bytes + (size_t)nb * 4 * sizeof(int) + 256;
   if (need > c->staged_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));

@@ -394,8 +394,12 @@ __device__ __forceinline__ void rows_comb(const double* __restrict__ Cm, const i
 
 }  // namespace
 
-// LDS: lam [k] | tau [k] | pi [k] | om [k] | swl [k] | small [8 nv + 32]
-__global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const StagedArgs S) {
+__device__ __forceinline__ int ov_n_of(const PointArgs& A, long pt) {
+  return A.mode == 0 ? (int)(A.obs_off[pt + 1] - A.obs_off[pt]) : A.nobsl[pt];
+}
+
+// LDS: lam [k] | tau [k] | pi [k] | om [k] | swl [k] | small [8 nv + 32] | P / C, q
+__global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const StagedArgs S, const int pcq_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const PointArgs& A = S.A;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
@@ -415,6 +419,7 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
   double* sdotd = xsm + 5 * nv;
   double* varg = xsm + 6 * nv;
   double* red = xsm + 8 * nv;          // 32 scalars
+  double* pcq = red + 32;              // [pcq_doubles]: the coefficient matrices P / C and q when they fit (see below)
 
   for (long it = blockIdx.x; it < S.nbatch; it += gridDim.x) {
     const long pt = S.pt0 + it;
@@ -446,7 +451,15 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
     const int ldg = m | 1;
     // the workgroup Jacobi pads an odd order with a zero column that ends up anywhere among the stored columns
     const int mc = solver == 1 ? (m + 1) & ~1 : m;
-    const int kq = k + 2;                               // row length of PC
+    // P / C [nb][mc] and (dual) q [nb][n] are read as broadcasts in the innermost loops below: in LDS when they fit
+    // (from the slab in L2 every one of those reads was an exposed ~0.7 us latency: 3/4 of this kernel's time)
+    const int mq = (mc + 2) & ~1, nq = (ov_n_of(A, pt) + 2) & ~1;
+    const bool pc_lds = (long)nb * mq <= pcq_doubles;
+    const bool qq_lds = pc_lds && (long)nb * (mq + nq) <= pcq_doubles;
+    double* PCp = pc_lds ? pcq : sl.PC;
+    const int kq = pc_lds ? mq : k + 2;                 // row length of PC
+    double* QQp = qq_lds ? pcq + (size_t)nb * mq : sl.QQ;
+    const int qld = qq_lds ? nq : k;
     const double shift = sl.SC[3], infl_old = sl.SC[4];
     ObsView ov;
     ov.A = &A;
@@ -569,7 +582,7 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
     __syncthreads();
 
     // ---------------- coefficients P[b][j] = e_j . TT[b]
-    cols_dot(sl.G, ldg, m, mc, sl.TT, k, nbr, sl.PC, kq);
+    cols_dot(sl.G, ldg, m, mc, sl.TT, k, nbr, PCp, kq);
     // var_g per variable (RTPS), needed with or without observations
     if (das)
       for (int v = wv; v < nv; v += nwv) {
@@ -592,7 +605,7 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
           const double var_g = varg[v];
           double var_a = 0.0;
           for (int j = 0; j < mc; ++j) {
-            const double p = sl.PC[(size_t)(2 + v) * kq + j];
+            const double p = PCp[(size_t)(2 + v) * kq + j];
             var_a = fma(p * p, pis[j], var_a);
           }
           var_a = fma(pi0, var_g, var_a);
@@ -606,15 +619,15 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
     // ---------------- C = spectrum * P  (in place): rows 0, 1 with 1/lambda (w-bar), rows 2.. with the T spectrum
     for (int e = tid; e < nbr * mc; e += nthr) {
       const int b = e / mc, j = e - b * mc;
-      sl.PC[(size_t)b * kq + j] *= (b < 2) ? om[j] : tau[j];
+      PCp[(size_t)b * kq + j] *= (b < 2) ? om[j] : tau[j];
     }
     __syncthreads();
 
     // ---------------- back to member space: OUT[b][mm]
     if (!dual) {
-      rows_comb(sl.G, ldg, k, mc, sl.PC, kq, nbr, sl.OUT, k);
+      rows_comb(sl.G, ldg, k, mc, PCp, kq, nbr, sl.OUT, k);
     } else {
-      rows_comb(sl.G, ldg, n, mc, sl.PC, kq, nbr, sl.QQ, k);      // q_b = U c_b  (obs space)
+      rows_comb(sl.G, ldg, n, mc, PCp, kq, nbr, QQp, qld);      // q_b = U c_b  (obs space)
       __syncthreads();
       // OUT[b][mm] = sum_i Z[i][mm] q_b[i]: one thread per member, the obs rows streamed (coalesced along mm)
       for (int mm = tid; mm < k; mm += nthr) {
@@ -627,7 +640,7 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
           const double z = yr[(long)mm * ms] * swl[i];
 #pragma unroll
           for (int b = 0; b < kMaxNb; ++b)
-            if (b < nbr) acc[b] = fma(z, sl.QQ[(size_t)b * k + i], acc[b]);
+            if (b < nbr) acc[b] = fma(z, QQp[(size_t)b * qld + i], acc[b]);
         }
 #pragma unroll
         for (int b = 0; b < kMaxNb; ++b)
@@ -795,13 +808,18 @@ hipError_t launch_stage_gram(const StagedArgs& s, size_t lds_max, hipStream_t st
 }
 
 hipError_t launch_stage_apply(const StagedArgs& s, hipStream_t st) {
-  const size_t lds = ((size_t)5 * (s.A.k + 2) + 8 * (size_t)s.A.nv + 32) * sizeof(double);
+  const int k = s.A.k, nb = s.A.nv + 2;
+  const size_t fixed = (size_t)5 * (k + 2) + 8 * (size_t)s.A.nv + 32;
+  // room for P / C (primal: up to k + 2 columns) and, while it fits, for q as well (dual: two matrices of ~n columns)
+  size_t pcq = (size_t)2 * nb * (k + 4);
+  while ((fixed + pcq) * sizeof(double) > 150 * 1024 && pcq > 0) pcq = pcq > (size_t)nb * 64 ? pcq - (size_t)nb * 64 : 0;
+  const size_t lds = (fixed + pcq) * sizeof(double);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_stage_apply_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(letkf_stage_apply_kernel, dim3((unsigned)s.nbatch), dim3(kABlock), lds, st, s);
+  hipLaunchKernelGGL(letkf_stage_apply_kernel, dim3((unsigned)s.nbatch), dim3(kABlock), lds, st, s, (int)pcq);
   return hipGetLastError();
 }
 
