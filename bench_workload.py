@@ -183,10 +183,25 @@ def alg_bytes_per_solve(n, k, nv, det=False):
 
 
 def alg_flops_per_solve(n, k, nv, rtps=True):
+    """SURVEY.md section 8(d), the k x k ("primal") count: Gram, Y^T d, symmetric eigensolve with vectors (nominal
+    9 k^3), T, w-bar, transform (+ Pa for RTPS)."""
     f = 2.0 * n * k * k + 2.0 * n * k + 9.0 * k ** 3 + 2.0 * k ** 3 + 2.0 * k * k + 2.0 * nv * k * k
     if rtps:
         f += 2.0 * k ** 3 + 2.0 * nv * k * k
     return f
+
+
+def alg_flops_dual(n, k, nv):
+    """The same analysis through the n x n observation-space eigenproblem (n < k; letkf_staged.hip): Z Z^T, the
+    eigensolve at order n (nominal 9 n^3), and for the nb = nv + 2 right-hand sides Z b, U^T t, U c, Z^T q.  What a
+    point with fewer observations than members REQUIRES is the smaller of the two counts."""
+    nb = nv + 2
+    return 2.0 * n * n * k + 9.0 * n ** 3 + 2.0 * (2.0 * n * k * nb) + 2.0 * (2.0 * n * n * nb) + 4.0 * nv * k
+
+
+def alg_flops_required(n, k, nv, rtps=True):
+    f = alg_flops_per_solve(n, k, nv, rtps)
+    return min(f, alg_flops_dual(n, k, nv)) if n < k else f
 
 
 def search_tables(w, pkg, device, max_nobs=0):
