@@ -46,6 +46,9 @@ def main():
                          "smooth) state perturbations around every observation + noise (SURVEY.md section 8(d))")
     ap.add_argument("--max-nobs", type=int, default=0,
                     help="MAX_NOBS_PER_GRID: two radar ctypes on the lattice, each limited to this many observations")
+    ap.add_argument("--state-layout", default="ref", choices=["ref", "member"],
+                    help="ensemble state in HBM: the reference's gues3d(nij1*nlev, nens, nv3d) (point-fastest) or the "
+                         "point-major member-fastest layout the ABI's strides also allow (sm = 1)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "lib"],
                     help="N > 1: the obs all-gather through torch.distributed (default) or through the library's own "
                          "letkf_obs_allgatherv_dev on an RCCL communicator this script creates (ncclCommInitRank)")
@@ -100,6 +103,7 @@ def main():
         sys.exit("--max-nobs needs --lists columns or search (the device obs_local)")
     w = bw.build(args.workload, dev, rank=rank, world=world, ensval_kind=args.ensval)
     k, nv, npts = w["k"], w["nv"], w["npts"]
+    bw.relayout_state(w, args.state_layout)
     # the streaming passes either side of the loop: mean into slot k, members -> perturbations
     ctx.ens_mean(k, nv, npts, w["gues"], w["sp"], w["sm"], w["sv"])
     ctx.to_perturbations(k, nv, npts, w["gues"], w["sp"], w["sm"], w["sv"])
@@ -226,11 +230,12 @@ def main():
         kern_s = kern_ms * 1e-3
         achieved = b_alg * npts / kern_s / 1e9 if kern_s > 0 else None
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_member.json" if args.state_layout == "member" else "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and args.ensval == "iid" and args.max_nobs == 0:
+                if (tj.get("workload") == args.workload and args.ensval == "iid" and args.max_nobs == 0
+                        and tj.get("state_layout", "ref") == args.state_layout):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -264,7 +269,7 @@ def main():
                "data": "synthetic",
                "config": {"workload": f"{args.workload}: {w['cfg']['nx']}x{w['cfg']['ny']}x{w['cfg']['nz']} grid, "
                                       f"k={k} members, nv={nv}, mean {n_mean:.1f} (max {w['n_max']}) local obs/point, "
-                                      f"relax={args.relax}, ensval={args.ensval}"
+                                      f"relax={args.relax}, ensval={args.ensval}" + (", state member-fastest" if args.state_layout == "member" else "")
                                       + (f", MAX_NOBS_PER_GRID={args.max_nobs} x 2 ctypes" if args.max_nobs else ""),
                           "points_per_gpu": npts, "obs_table_rows": int(w["ensval"].shape[0]),
                           "parallelism": f"grid-point shard x{n_gpus}" + ((" + RCCL obs all-gather (" + args.exchange + ")") if world > 1 else "")},
@@ -326,7 +331,7 @@ def cpu_baseline(w, relax, seconds, threads, anal):
         assert r["rc"] == 0
         # parity of the GPU result on the same points
         tp = torch.from_numpy(pts).to(anal.device)
-        got = anal.view(nv, nens, npts)[:, :k, tp].cpu().numpy()
+        got = bw.state_view(w, anal)[:, :k, tp].cpu().numpy()
         exp = r["anal"].reshape(nv, nens, ns)[:, :k]
         x = s["gues"].reshape(nv, nens, ns)
         worst = 0.0

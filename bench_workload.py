@@ -153,6 +153,24 @@ def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval_kind="
                 sig=sig, gen=g)
 
 
+def state_view(w, t):
+    """[v, m, p] view of a state buffer in the workload's layout (element (p, m, v) at p*sp + m*sm + v*sv)."""
+    return torch.as_strided(t, (w["nv"], w["nens"], w["npts"]), (w["sv"], w["sm"], w["sp"]))
+
+
+def relayout_state(w, layout):
+    """layout "member": the point-major, member-fastest layout the C ABI's strides also allow (sm = 1, sv = nens,
+    sp = nens*nv: a point's 11 x (k+1) doubles are one contiguous 4.5 KB block) instead of the reference's
+    gues3d(nij1*nlev, nens, nv3d) (sp = 1)."""
+    if layout != "member":
+        return
+    nv, nens, npts = w["nv"], w["nens"], w["npts"]
+    g = w["gues"].view(nv, nens, npts).permute(2, 0, 1).contiguous()      # [p][v][m]
+    w["gues"] = g.reshape(-1)
+    w["sp"], w["sm"], w["sv"] = nens * nv, 1, nens
+    del g
+
+
 def correlate_ensval(w):
     """obs-space perturbations as an H-like linear combination of the state perturbations
     around the observation (here: of u and T at the nearest grid point) plus unit noise, so that Y and X' -- and the
@@ -168,7 +186,7 @@ def correlate_ensval(w):
     iz = torch.argmin((oz[:, None] - zlev[None, :]).abs(), dim=1)
     # lattice row index = (iz*noy + iy)*nox + ix
     pt = ((iz[:, None, None] * ny + iy[None, :, None]) * nx + ix[None, None, :]).reshape(-1)
-    gv = w["gues"].view(w["nv"], w["nens"], w["npts"])
+    gv = state_view(w, w["gues"])
     sig = w["sig"]
     noise = torch.randn(w["nobs"], k, generator=w["gen"], device=dev_, dtype=torch.float64)
     noise -= noise.mean(dim=1, keepdim=True)
@@ -300,6 +318,6 @@ def sample_points(w, pts):
     sp_ = torch.searchsorted(off, e, right=True) - 1
     sel = o0[sp_] + (e - off[sp_])
     nv, nens, npts = w["nv"], w["nens"], w["npts"]
-    gv = w["gues"].view(nv, nens, npts)[:, :, tp].contiguous().cpu().numpy().reshape(-1)
+    gv = state_view(w, w["gues"])[:, :, tp].contiguous().cpu().numpy().reshape(-1)
     return dict(off=off.cpu().numpy(), idx=w["obs_idx"][sel].cpu().numpy(), rdiag=w["rdiag"][sel].cpu().numpy(),
                 rloc=w["rloc"][sel].cpu().numpy(), gues=gv, ns=ns, pts=pts)
