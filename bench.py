@@ -46,6 +46,10 @@ def main():
                          "smooth) state perturbations around every observation + noise (SURVEY.md section 8(d))")
     ap.add_argument("--max-nobs", type=int, default=0,
                     help="MAX_NOBS_PER_GRID: two radar ctypes on the lattice, each limited to this many observations")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank owns a domain of the workload's size (the contract line); strong = ONE "
+                         "domain cut into tiles, each rank running set_letkf_obs (sort, exchange, halo plan) + obs_local + "
+                         "the loop body for its tile (bench_tiles.py)")
     ap.add_argument("--state-layout", default="ref", choices=["ref", "member"],
                     help="ensemble state in HBM: the reference's gues3d(nij1*nlev, nens, nv3d) (point-fastest) or the "
                          "point-major member-fastest layout the ABI's strides also allow (sm = 1)")
@@ -85,10 +89,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists)"
+    # LETKF_BENCH_BACKEND=gloo: rehearsal of the N > 1 paths on a box with fewer GPUs than ranks (the ranks share the
+    # devices round-robin and exchange through gloo; RCCL refuses two ranks on one device).  Not a measurement.
+    backend = os.environ.get("LETKF_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     n_gpus = world
 
     pkg = load_package()
@@ -99,6 +110,37 @@ def main():
     stream = torch.cuda.current_stream()
     ctx = pkg.Context(local_rank, stream.cuda_stream)
 
+    if args.scaling == "strong":
+        import bench_tiles
+        r = bench_tiles.run(args, ctx, pkg, dev, rank, world)
+        if rank == 0:
+            k_, nv_ = r["k"], r["nv"]
+            b_alg = bw.alg_bytes_per_solve(r["n_mean"], k_, nv_)
+            f_alg = bw.alg_flops_required(r["n_mean"], k_, nv_, rtps=(args.relax == "rtps"))
+            per_rank = r["npts_total"] / world
+            ks = r["kern_ms"] * 1e-3
+            tfl = f_alg * per_rank / ks / 1e12 if ks > 0 else None
+            print(json.dumps({
+                "metric": "grid-point LETKF solves/sec", "value": r["npts_total"] * args.steps / r["elapsed"],
+                "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": r["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"{args.workload}: ONE {bw.CONFIGS[args.workload]['nx']}x{bw.CONFIGS[args.workload]['ny']}x"
+                                       f"{bw.CONFIGS[args.workload]['nz']} domain as {r['tiles']}, k={k_}, nv={nv_}, mean "
+                                       f"{r['n_mean']:.1f} local obs/point, relax={args.relax}; per step and rank: mesh sort, "
+                                       f"obs all-gather ({args.exchange}), halo plan, obs_local, loop body",
+                           "points_total": r["npts_total"], "obs_rows_global": r["nobs"],
+                           "obs_rows_per_rank_with_halo": r["halo_rows_mean"], "parallelism": f"tiles x{world}"},
+                "nonzero_status_points": r["bad"], "jacobi_sweeps_mean": r["sweeps_mean"],
+                "roofline": {"bound": "mfma", "achieved": tfl, "peak": 78.6, "unit": "TFLOP/s",
+                             "frac": (tfl / 78.6) if tfl else None, "traffic": None, "kernel": ctx.last_path(),
+                             "kernel_ms": r["kern_ms"], "launches": r["nlaunch"], "alg_bytes_per_solve": b_alg,
+                             "alg_flops_per_solve": f_alg, "note": "loop-body launch of the slowest rank, per GPU"},
+                "cpu_baseline": None}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return None
     if args.max_nobs > 0 and args.lists not in ("columns", "search"):
         sys.exit("--max-nobs needs --lists columns or search (the device obs_local)")
     w = bw.build(args.workload, dev, rank=rank, world=world, ensval_kind=args.ensval)
