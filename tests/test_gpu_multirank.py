@@ -1,0 +1,43 @@
+"""The N > 1 paths of bench.py on real kernels, rehearsed on the one GPU a test box has: the ranks share the device and
+exchange through gloo (LETKF_BENCH_BACKEND=gloo; RCCL refuses two ranks on one device), everything else -- mesh sort,
+the all-gather of the sorted observation buffers and cell counts, the extended-subdomain plan with its halo, obs_local
+and the loop body per tile -- is the code the 8-GPU run executes.  Checked: every rank finishes, no point reports a
+status, and the tiled domain finds exactly the local observations of the single domain (same mean list length)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from __graft_entry__ import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*extra):
+    env = dict(os.environ, LETKF_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "C2-mini", "--steps", "1",
+                          "--warmup", "1", "--no-cpu-baseline", *extra], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_strong_scaling_tiles_two_and_four_ranks():
+    one = run_bench("--scaling", "strong")
+    n1 = float(one["config"]["workload"].split("mean ")[1].split(" ")[0])
+    for n in (2, 4):
+        d = run_bench("--gpus", str(n), "--scaling", "strong")
+        assert d["n_gpus"] == n and d["scaling"] == "strong" and d["nonzero_status_points"] == 0
+        nn = float(d["config"]["workload"].split("mean ")[1].split(" ")[0])
+        assert nn == n1, (nn, n1)                       # the halo plan hands every tile all it needs, nothing twice
+        assert d["config"]["points_total"] == one["config"]["points_total"]
+        assert d["config"]["obs_rows_per_rank_with_halo"] < one["config"]["obs_rows_per_rank_with_halo"]
+
+
+def test_weak_scaling_two_ranks():
+    d = run_bench("--gpus", "2")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["nonzero_status_points"] == 0
+    assert d["value"] > 0 and "all-gather" in d["config"]["parallelism"]
