@@ -67,6 +67,9 @@ def run(args, ctx, pkg, dev, rank, world):
     mesh = pkg.Mesh()
     mesh.nctype, mesh.nlon, mesh.nlat, mesh.ihalo, mesh.jhalo, mesh.rank_i, mesh.rank_j = 1, nlon, nlat, 0, 0, pi, pj
     mesh.ngrd_i, mesh.ngrd_j = gi.ctypes.data, gj.ctypes.data
+    # non-square tiles (N = 2, 8 on a square domain): sort with ngrd_j like the lookup does, or the reference's
+    # ij_obsgrd (letkf_obs.f90:1200) loses observations and the tilings would not do the same work
+    mesh.fix_ij_obsgrd = 1
     lay = pkg.HaloLayout()
     lay.nctype, lay.nprocs, lay.prc_num_x, lay.myrank = 1, world, px, rank
     lay.ngrd_i, lay.ngrd_j, lay.ngrdsch_i, lay.ngrdsch_j = gi.ctypes.data, gj.ctypes.data, si.ctypes.data, sj.ctypes.data

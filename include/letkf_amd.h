@@ -346,7 +346,10 @@ typedef struct {
   int32_t nlon, nlat;             /* subdomain size (without halo) */
   int32_t ihalo, jhalo;           /* IHALO, JHALO: ri, rj count the halo */
   int32_t rank_i, rank_j;         /* PRC_2Drank of this rank */
-  int32_t reserved0;
+  int32_t fix_ij_obsgrd;          /* 0: ij_obsgrd as the reference has it -- rj scaled with ngrd_i (letkf_obs.f90:1200), so that
+                                     on subdomains with ngrd_i /= ngrd_j the sort disagrees with the lookup ij_obsgrd_ext
+                                     (:1223, ngrd_j) and grid points lose observations; 1: scale rj with ngrd_j (sort and
+                                     lookup agree on any subdomain shape).  Identical on square subdomains. */
   const int32_t *ngrd_i, *ngrd_j; /* HOST [nctype]: obsgrd(ic)%ngrd_i / ngrd_j (letkf_obs.f90:668-669) */
 } letkf_mesh;
 

@@ -995,7 +995,7 @@ static void orc_ij_obsgrd(const orc_mesh *m, int ic, double ri, double rj, int *
   const double ril = ri - (double)(m->rank_i * m->nlon);
   const double rjl = rj - (double)(m->rank_j * m->nlat);
   int i = (int)ceil((ril - (double)m->ihalo - 0.5) * (double)m->ngrd_i[ic] / (double)m->nlon);
-  int j = (int)ceil((rjl - (double)m->jhalo - 0.5) * (double)m->ngrd_i[ic] / (double)m->nlat);
+  int j = (int)ceil((rjl - (double)m->jhalo - 0.5) * (double)(m->fix_ij_obsgrd ? m->ngrd_j[ic] : m->ngrd_i[ic]) / (double)m->nlat);
   if (i < 1) i = 1;
   if (i > m->ngrd_i[ic]) i = m->ngrd_i[ic];
   if (j < 1) j = 1;

@@ -83,7 +83,7 @@ class QcParams(C.Structure):
 class Mesh(C.Structure):
     """letkf_mesh (section 5); ngrd_i / ngrd_j are HOST int32 arrays"""
     _fields_ = [("nctype", C.c_int32), ("nlon", C.c_int32), ("nlat", C.c_int32), ("ihalo", C.c_int32),
-                ("jhalo", C.c_int32), ("rank_i", C.c_int32), ("rank_j", C.c_int32), ("reserved0", C.c_int32),
+                ("jhalo", C.c_int32), ("rank_i", C.c_int32), ("rank_j", C.c_int32), ("fix_ij_obsgrd", C.c_int32),
                 ("ngrd_i", C.c_void_p), ("ngrd_j", C.c_void_p)]
 
 

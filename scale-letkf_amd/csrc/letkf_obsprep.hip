@@ -106,19 +106,20 @@ __global__ void __launch_bounds__(64) departure_kernel(const letkf_qc_params P, 
 }
 
 struct MeshDev {
-  int nctype, nlon, nlat, ihalo, jhalo, rank_i, rank_j;
+  int nctype, nlon, nlat, ihalo, jhalo, rank_i, rank_j, fix_j;
   const int* ngrd_i;      // device copies
   const int* ngrd_j;
   const long* coff;       // [nctype + 1] cell offsets
 };
 
-// ij_obsgrd, letkf_obs.f90:1186-1203 with the clamps of :768-771; the reference scales rj by ngrd_i (:1200)
+// ij_obsgrd, letkf_obs.f90:1186-1203 with the clamps of :768-771; the reference scales rj by ngrd_i (:1200) -- restated
+// as written unless the caller asks for ngrd_j (letkf_mesh.fix_ij_obsgrd: what ij_obsgrd_ext, :1223, looks up with)
 __device__ __forceinline__ long mesh_cell(const MeshDev& m, int ic, double ri, double rj) {
   const double ril = ri - (double)(m.rank_i * m.nlon);
   const double rjl = rj - (double)(m.rank_j * m.nlat);
   const int gi = m.ngrd_i[ic], gj = m.ngrd_j[ic];
   int i = (int)ceil((ril - (double)m.ihalo - 0.5) * (double)gi / (double)m.nlon);
-  int j = (int)ceil((rjl - (double)m.jhalo - 0.5) * (double)gi / (double)m.nlat);
+  int j = (int)ceil((rjl - (double)m.jhalo - 0.5) * (double)(m.fix_j ? gj : gi) / (double)m.nlat);
   i = i < 1 ? 1 : (i > gi ? gi : i);
   j = j < 1 ? 1 : (j > gj ? gj : j);
   return m.coff[ic] + (long)(j - 1) * gi + (i - 1);
@@ -232,7 +233,7 @@ hipError_t obs_mesh_sort(const letkf_mesh& m, long nobs, const int* ctype, const
   if ((e = hipMemsetAsync(n_cell, 0, sizeof(int) * (size_t)(ncell > 0 ? ncell : 1), st)) != hipSuccess) return e;
   *nsorted = 0;
   if (nobs <= 0) return hipStreamSynchronize(st);
-  MeshDev md{m.nctype, m.nlon, m.nlat, m.ihalo, m.jhalo, m.rank_i, m.rank_j, d_gi, d_gj, d_coff};
+  MeshDev md{m.nctype, m.nlon, m.nlat, m.ihalo, m.jhalo, m.rank_i, m.rank_j, m.fix_ij_obsgrd != 0, d_gi, d_gj, d_coff};
   hipLaunchKernelGGL(mesh_key_kernel, dim3(grid_for(nobs, 256, num_cu)), dim3(256), 0, st, md, nobs, ctype, ri, rj, qc,
                      kin, n_cell);
   if ((e = hipGetLastError()) != hipSuccess) return e;

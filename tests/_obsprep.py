@@ -22,7 +22,7 @@ class QcParams(C.Structure):
 
 class Mesh(C.Structure):
     _fields_ = [("nctype", C.c_int32), ("nlon", C.c_int32), ("nlat", C.c_int32), ("ihalo", C.c_int32),
-                ("jhalo", C.c_int32), ("rank_i", C.c_int32), ("rank_j", C.c_int32), ("reserved0", C.c_int32),
+                ("jhalo", C.c_int32), ("rank_i", C.c_int32), ("rank_j", C.c_int32), ("fix_ij_obsgrd", C.c_int32),
                 ("ngrd_i", C.c_void_p), ("ngrd_j", C.c_void_p)]
 
 
@@ -88,7 +88,8 @@ def make_world(seed, px=2, py=2, nlon=12, nlat=12, k=10, det_run=True, nobs=3000
 
 def mesh_struct(cls, w, rk):
     return fill(cls, nctype=w["nctype"], nlon=w["nlon"], nlat=w["nlat"], ihalo=w["ihalo"], jhalo=w["ihalo"],
-                rank_i=rk["pi"], rank_j=rk["pj"], ngrd_i=w["ngrd_i"].ctypes.data, ngrd_j=w["ngrd_j"].ctypes.data)
+                rank_i=rk["pi"], rank_j=rk["pj"], fix_ij_obsgrd=int(w.get("fix_ij_obsgrd", 0)),
+                ngrd_i=w["ngrd_i"].ctypes.data, ngrd_j=w["ngrd_j"].ctypes.data)
 
 
 def layout_struct(cls, w, myrank):

@@ -76,7 +76,7 @@ def rank_pipeline(w, lev_glob, dx):
 
 
 def tiled_analysis(seed, px, py, nlon_g, nlat_g, nlev, k, nobs, x_glob, zlev, ngrd_cell=(4, 2, 4), nsch=(2, 3, 1),
-                   dx=1000.0, relax=None, det_run=True):
+                   dx=1000.0, relax=None, det_run=True, fix_ij_obsgrd=False):
     """Analysis of the whole (nlon_g x nlat_g x nlev) grid through px x py virtual ranks.  x_glob: numpy
     [nv, nens, nlev, nlat_g, nlon_g] first guess (members, mean slot, det slot).  Returns dict(anal [same shape],
     lists {global point -> (global obs ids, rdiag, rloc)}, nobsl)."""
@@ -88,6 +88,7 @@ def tiled_analysis(seed, px, py, nlon_g, nlat_g, nlev, k, nobs, x_glob, zlev, ng
     ngrd = tuple((nlon // s, nlat // s) for s in ngrd_cell)
     w = make_world(seed, px=px, py=py, nlon=nlon, nlat=nlat, k=k, det_run=det_run, nobs=nobs, ngrd=ngrd,
                    ngrdsch=tuple((s, s) for s in nsch))
+    w["fix_ij_obsgrd"] = int(fix_ij_obsgrd)
     # search radius = what the halo of nsch mesh cells covers (letkf_obs.f90:674-677)
     w["hori_loc"] = np.array([s * cs * dx / DZF * 0.999 for s, cs in zip(nsch, ngrd_cell)])
     lev_glob = np.random.default_rng(seed + 1).uniform(0.0, 12000.0, nobs)

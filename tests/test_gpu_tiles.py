@@ -61,6 +61,25 @@ def test_tiled_analysis_equals_single_domain(px, py, k):
     assert np.abs(a1[0, :k] - (x[0, :k] + x[0, k:k + 1])).max() > 1e-3
 
 
+def test_non_square_tiles_with_the_ij_obsgrd_fix():
+    """letkf_mesh.fix_ij_obsgrd = 1 (rj scaled with ngrd_j in the sort, as the lookup does): 3 x 2 tiles of 8 x 12
+    points give the single domain's lists (as sets: the mesh rows differ from the square case) and analysis."""
+    nlon_g, nlat_g, nlev, nv, nobs, k = 24, 24, 2, 11, 1500, 20
+    zlev = np.array([800.0, 9500.0])
+    x = first_guess(8, nv, k, True, nlev, nlat_g, nlon_g)
+    one = tiled_analysis(79, 1, 1, nlon_g, nlat_g, nlev, k, nobs, x, zlev)
+    til = tiled_analysis(79, 3, 2, nlon_g, nlat_g, nlev, k, nobs, x, zlev, fix_ij_obsgrd=True)
+    for key, (gid1, rd1, rl1) in one["lists"].items():
+        gid2, rd2, rl2 = til["lists"][key]
+        o1, o2 = np.argsort(gid1, kind="stable"), np.argsort(gid2, kind="stable")
+        assert np.array_equal(gid1[o1], gid2[o2]), key
+        assert np.array_equal(rd1[o1], rd2[o2]) and np.array_equal(rl1[o1], rl2[o2]), key
+    members = list(range(k)) + [k + 1]
+    for v in range(nv):
+        scale = max(np.abs(x[v, k]).max(), np.abs(x[v, :k]).max())
+        assert np.abs(one["anal"][v, members] - til["anal"][v, members]).max() <= 1e-10 * scale
+
+
 def test_non_square_tiles_follow_the_reference_quirk():
     nlon_g, nlat_g, nlev, nv, nobs, k = 24, 24, 2, 11, 1500, 20
     zlev = np.array([800.0, 9500.0])
