@@ -531,7 +531,8 @@ __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs
 // cutd_t of :1604-1660 / :1716-1727 (criterion 1: hori_loc * sqrt(largest selected distance) once the limit is hit,
 // else hori_loc * dist_zero_fac; criterion 2 / 3: the smallest selected weight / largest selected error, else 0).
 // ---------------------------------------------------------------------------------------------
-constexpr int kSurvL = 896;                 // survivors of one group buffered per wave (32 B + 8 B key each)
+constexpr int kSurvL = 576;                 // survivors of one group buffered per wave (32 B each): 18 KB, 8 waves per CU
+constexpr int kKeyS = kSurvL / 64;          // ... their selection keys: this many per lane, in registers
 constexpr unsigned long long kNoKey = ~0ull;
 
 struct VertOut {
@@ -576,44 +577,66 @@ __device__ __forceinline__ VertOut vertical_nd(const int vm, const double vloc, 
   return o;
 }
 
-// nmax-th smallest of the nk keys in LDS (kNoKey entries are never reached: want <= number of real keys).  MSB-first,
-// 8 bits per round; the rounds stop as soon as the bin that holds the wanted key holds nothing else -- with ~500
-// double keys that is after 3-4 rounds, not 8 (the top two bytes are sign / exponent and nearly constant).
-// (10-bit digits were measured too: fewer rounds, but clearing and scanning 1024 bins per round cost more.)
-__device__ __forceinline__ void radix_thresh(const unsigned long long* keyl, const int nk, const int nmax,
-                                             unsigned int* hist, unsigned long long& thresh, int& tie_budget) {
-  const int lane = threadIdx.x & 63;
-  unsigned long long prefix = 0ull;
-  int want = nmax;
-  for (int round = 0; round < 8; ++round) {
-    for (int b = lane; b < 256; b += 64) hist[b] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int shift = 56 - 8 * round;
-    for (int e = lane; e < nk; e += 64) {
-      const unsigned long long key = keyl[e];
-      if (key != kNoKey && (round == 0 || (key >> (shift + 8)) == prefix))
-        atomicAdd(&hist[(unsigned int)(key >> shift) & 0xFFu], 1u);
+// wave-wide OR / AND on the vector ALU (the DPP sequence of wave_incl_scan; lane 63 ends up with the total)
+__device__ __forceinline__ unsigned int wave_or_u32(unsigned int v) {
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+  return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+  return ((unsigned long long)wave_or_u32((unsigned int)(v >> 32)) << 32) | wave_or_u32((unsigned int)v);
+}
+
+// nmax-th smallest of the wave's keys held in REGISTERS (slot u of lane l = candidate 64 u + l; kNoKey = none): a binary
+// search over the bit positions, MSB first, counting the candidates of the current class whose next bit is 0 with
+// ballots -- no LDS, no atomics.  Starts at the highest bit in which the keys differ at all (wave OR / AND by DPP) and
+// stops as soon as the class that holds the wanted key holds nothing else: ~10 bit steps for ~500 double keys, against
+// 3-4 LDS histogram rounds with their atomics, clears, fences and scans before (measured: fill phase 105 -> see DESIGN).
+template <int KS>
+__device__ __forceinline__ void bit_thresh(const unsigned long long (&key)[KS], const int ns, const int nreal, int want,
+                                           unsigned long long& thresh, int& tie_budget) {
+  unsigned long long vor = 0ull, vnand = 0ull;                 // OR of the keys, OR of their complements
+#pragma unroll
+  for (int u = 0; u < KS; ++u)
+    if (u * 64 < ns && key[u] != kNoKey) {
+      vor |= key[u];
+      vnand |= ~key[u];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    int cum = 0, bsel = 255;
-    find_bin(hist, want, bsel, cum);
-    want -= cum;
-    prefix = (round == 0) ? (unsigned long long)bsel : ((prefix << 8) | (unsigned long long)bsel);
-    if (round < 7 && hist[bsel] == 1u) {
-      // a single key left in the class: it is the threshold
+  vor = wave_or_u64(vor);
+  const unsigned long long vand = ~wave_or_u64(vnand);
+  const unsigned long long diff = vor ^ vand;
+  if (diff == 0ull) {                                          // all keys equal
+    thresh = vor;
+    tie_budget = want;
+    return;
+  }
+  const int hb = 63 - __clzll((long long)diff);
+  unsigned long long prefix = hb < 63 ? (vand >> (hb + 1)) : 0ull;
+  int inclass = nreal;
+  for (int b = hb; b >= 0; --b) {
+    const unsigned long long t0 = prefix << 1;
+    int cnt0 = 0;
+#pragma unroll
+    for (int u = 0; u < KS; ++u)
+      if (u * 64 < ns) cnt0 += __popcll(__ballot(key[u] != kNoKey && (key[u] >> b) == t0));
+    if (want <= cnt0) {
+      prefix = t0;
+      inclass = cnt0;
+    } else {
+      want -= cnt0;
+      prefix = t0 | 1ull;
+      inclass -= cnt0;
+    }
+    if (inclass == 1 && b > 0) {
       unsigned long long found = 0ull;
-      for (int e = lane; e < nk; e += 64) {
-        const unsigned long long key = keyl[e];
-        if (key != kNoKey && (key >> shift) == prefix) found = key;
-      }
-      // (a key is 0 only for a distance of exactly zero: then `found` stays 0 in every lane, and 0 is the answer)
-      const unsigned long long mk = __ballot(found != 0ull);
-      const int src = mk ? __ffsll((long long)mk) - 1 : 0;
-      const unsigned int flo = __builtin_amdgcn_readlane((unsigned int)found, src);
-      const unsigned int fhi = __builtin_amdgcn_readlane((unsigned int)(found >> 32), src);
-      thresh = ((unsigned long long)fhi << 32) | flo;
+#pragma unroll
+      for (int u = 0; u < KS; ++u)
+        if (u * 64 < ns && key[u] != kNoKey && (key[u] >> b) == prefix) found = key[u];
+      thresh = wave_or_u64(found);                             // (one lane holds it, the others 0)
       tie_budget = 1;
       return;
     }
@@ -627,7 +650,7 @@ struct ColLimArgs {
   double* cutd_ctype;    // [npts][nctype] or null
 };
 
-__global__ void __launch_bounds__(256) letkf_search_columns_limited_kernel(const ColLimArgs L) {
+__global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(const ColLimArgs L) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) double smem_lim[];
   __shared__ unsigned int hist_all[4][256];
@@ -637,10 +660,9 @@ __global__ void __launch_bounds__(256) letkf_search_columns_limited_kernel(const
   const int wv = threadIdx.x >> 6;
   const int nlev = A.nlev;
   const int nl2 = (nlev + 1) & ~1;
-  const int cstride = 5 * kSurvL + nl2;                           // doubles per wave
+  const int cstride = 4 * kSurvL + nl2;                           // doubles per wave
   double* sb = smem_lim + (size_t)wv * cstride;                   // [kSurvL][4]: (row, member), nd_h, v_obs, err
-  unsigned long long* keyl = reinterpret_cast<unsigned long long*>(sb + 4 * kSurvL);   // [kSurvL]
-  int* cntl = reinterpret_cast<int*>(sb + 5 * kSurvL);            // [nlev] entries emitted so far per level
+  int* cntl = reinterpret_cast<int*>(sb + 4 * kSurvL);            // [nlev] entries emitted so far per level
   unsigned int* hist = hist_all[wv];
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   SearchArgs PA;                                                  // for the per-point fall-back
@@ -791,8 +813,12 @@ __global__ void __launch_bounds__(256) letkf_search_columns_limited_kernel(const
           const double lnrain = log(t.rain_base);
           // ---- (1) vertical part: keys (limited group) or straight emission (no limit)
           int acc_n = 0;
-          for (int s0 = 0; s0 < ns; s0 += 64) {
-            const int si = s0 + lane;
+          unsigned long long keyr[kKeyS];
+#pragma unroll
+          for (int u = 0; u < kKeyS; ++u) {
+            keyr[u] = kNoKey;
+            if (u * 64 >= ns) continue;                          // (wave-uniform)
+            const int si = u * 64 + lane;
             VertOut vo{0.0, 0.0, 0.0, false};
             int row = 0, ic = icm;
             if (si < ns) {
@@ -830,7 +856,7 @@ __global__ void __launch_bounds__(256) letkf_search_columns_limited_kernel(const
                 CalOut c{vo.rloc, vo.rdiag, vo.nd};
                 key = key_bits(t.criterion, c);
               }
-              if (si < ns) keyl[si] = key;
+              keyr[u] = key;
             } else {
               if (A.fill && vo.acc) {
                 const long o = out + acc_n + __popcll(mk & lt_mask);
@@ -848,15 +874,12 @@ __global__ void __launch_bounds__(256) letkf_search_columns_limited_kernel(const
           }
           nsel = acc_n;
           if (nmax > 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             nsel = min(acc_n, nmax);
             unsigned long long thresh = kNoKey;                  // every real key is below it
             int tie_budget = 0;
             if (acc_n >= nmax && (acc_n > nmax ? (A.fill || L.cutd_ctype) : L.cutd_ctype != nullptr)) {
               // (2) the nmax-th smallest key: selection threshold, and the cut-off measure once the limit is hit
-              radix_thresh(keyl, ns, nmax, hist, thresh, tie_budget);
+              bit_thresh<kKeyS>(keyr, ns, acc_n, nmax, thresh, tie_budget);
               const double kv = __longlong_as_double((long long)(t.criterion == 2 ? 0x7FFFFFFFFFFFFFFFull - thresh : thresh));
               cutd = (t.criterion == 1) ? t.hori_loc[icm] * sqrt(kv) : kv;
               if (acc_n == nmax) {
@@ -867,11 +890,13 @@ __global__ void __launch_bounds__(256) letkf_search_columns_limited_kernel(const
             if (A.fill) {
               // (3) emission in candidate order
               int emitted = 0;
-              for (int s0 = 0; s0 < ns; s0 += 64) {
-                const int si = s0 + lane;
+#pragma unroll
+              for (int u = 0; u < kKeyS; ++u) {
+                if (u * 64 >= ns) continue;                      // (wave-uniform)
+                const int si = u * 64 + lane;
                 bool take = false, tie = false;
-                if (si < ns) {
-                  const unsigned long long key = keyl[si];
+                {
+                  const unsigned long long key = keyr[u];
                   take = key != kNoKey && key < thresh;
                   tie = key != kNoKey && thresh != kNoKey && key == thresh;
                 }
@@ -949,7 +974,7 @@ hipError_t launch_search_columns_limited(const letkf_search_tables& t, long nij1
                                          int* nobs_ctype, double* cutd_ctype, int num_cu, hipStream_t st) {
   ColLimArgs a{{t, nij1, nlev, rig, rjg, rlev, rz, fill, counts, obs_off, obs_idx, rdiag_l, rloc_l, nobs_ctype},
                cutd_ctype};
-  const size_t lds = (size_t)4 * (5 * kSurvL + ((nlev + 1) & ~1)) * sizeof(double);
+  const size_t lds = (size_t)4 * (4 * kSurvL + ((nlev + 1) & ~1)) * sizeof(double);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_search_columns_limited_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
