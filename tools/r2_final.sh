@@ -21,5 +21,8 @@ tools/r2_prof.sh C3-slab ${TAG}_c3slab | grep "letkf::" | cut -c1-150
 tools/r2_prof.sh C5-slab ${TAG}_c5slab | grep "letkf::" | cut -c1-150
 tools/r2_prof.sh C4-slab ${TAG}_c4slab | grep "letkf::" | cut -c1-150
 tools/r2_prof_args.sh ${TAG}_c2_maxnobs100 --max-nobs 100 | grep "letkf::" | cut -c1-150
+echo "== strong scaling, N = 1 (one tile = the whole domain through the subdomain pipeline)"
+timeout -k 10 300 python bench.py --scaling strong --steps 3 --warmup 1 2>/dev/null | tee $O/bench_c2_strong_n1.json | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C2 strong N=1', 'ms/step', round(d['ms_per_step'],2), 'solves/s', int(d['value']), d['config']['workload'][:120])"
+timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --state-layout member 2>/dev/null | tee $O/bench_c2_member.json | j C2-member-layout
 echo "== bench_largek"; timeout -k 10 500 python bench_largek.py 2>&1 | tail -8
 echo "== cycle"; timeout -k 10 300 python bench_cycle.py 2>&1 | tail -3
