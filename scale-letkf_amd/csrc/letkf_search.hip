@@ -290,7 +290,9 @@ __global__ void __launch_bounds__(256) letkf_search_kernel(const SearchArgs A) {
   extern __shared__ __attribute__((aligned(16))) double cache_all[];       // [4][kCacheCap][4]
   const letkf_search_tables& t = A.t;
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  // (scalar: one column / point per WAVE -- derived from threadIdx alone hipcc takes everything that hangs on it, the
+  // mesh walk, the survivor counts, the select's loop, for divergent and wraps it in exec-mask loops)
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned int* hist = hist_all[wv];
   double* cache = cache_all + (size_t)wv * 4 * kCacheCap;
 
@@ -381,7 +383,9 @@ __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs
   extern __shared__ __attribute__((aligned(16))) double smem_col[];
   const letkf_search_tables& t = A.t;
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  // (scalar: one column / point per WAVE -- derived from threadIdx alone hipcc takes everything that hangs on it, the
+  // mesh walk, the survivor counts, the select's loop, for divergent and wraps it in exec-mask loops)
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nlev = A.nlev;
   const int cstride = 4 * kSurv + 2 * ((nlev + 1) & ~1);         // doubles per wave: survivors + 2 level counter arrays
   double* sb = smem_col + (size_t)wv * cstride;                  // [kSurv][4]: row bits, nd_h, v_obs, err
@@ -594,18 +598,24 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
 // nmax-th smallest of the wave's keys held in REGISTERS (slot u of lane l = candidate 64 u + l; kNoKey = none): a binary
 // search over the bit positions, MSB first, counting the candidates of the current class whose next bit is 0 with
 // ballots -- no LDS, no atomics.  Starts at the highest bit in which the keys differ at all (wave OR / AND by DPP) and
-// stops as soon as the class that holds the wanted key holds nothing else: ~10 bit steps for ~500 double keys, against
-// 3-4 LDS histogram rounds with their atomics, clears, fences and scans before (measured: fill phase 105 -> see DESIGN).
+// stops as soon as the class that holds the wanted key holds nothing else (~18 bit steps for ~200 double keys).
+// The steps run on the HIGH WORDS of the keys as long as those still tell the class apart (32-bit shifts and compares
+// at full rate; the 64-bit forms are quarter rate and made this select 2/3 of the fill phase), on the low words only
+// for what is left -- keys that agree in their upper 32 bits.
 template <int KS>
 __device__ __forceinline__ void bit_thresh(const unsigned long long (&key)[KS], const int ns, const int nreal, int want,
                                            unsigned long long& thresh, int& tie_budget) {
+  unsigned int hi[KS], lo[KS];
   unsigned long long vor = 0ull, vnand = 0ull;                 // OR of the keys, OR of their complements
 #pragma unroll
-  for (int u = 0; u < KS; ++u)
+  for (int u = 0; u < KS; ++u) {
+    hi[u] = (unsigned int)(key[u] >> 32);                      // (kNoKey: all ones -- never equal to a t0, whose LSB is 0,
+    lo[u] = (unsigned int)key[u];                              //  nor to the prefix of a class that a real key defines)
     if (u * 64 < ns && key[u] != kNoKey) {
       vor |= key[u];
       vnand |= ~key[u];
     }
+  }
   vor = wave_or_u64(vor);
   const unsigned long long vand = ~wave_or_u64(vnand);
   const unsigned long long diff = vor ^ vand;
@@ -615,33 +625,76 @@ __device__ __forceinline__ void bit_thresh(const unsigned long long (&key)[KS], 
     return;
   }
   const int hb = 63 - __clzll((long long)diff);
-  unsigned long long prefix = hb < 63 ? (vand >> (hb + 1)) : 0ull;
+  const unsigned int vand_hi = (unsigned int)(vand >> 32), vand_lo = (unsigned int)vand;
   int inclass = nreal;
-  for (int b = hb; b >= 0; --b) {
-    const unsigned long long t0 = prefix << 1;
+  // the one key of a class of one: slot by slot, a ballot finds its lane
+  auto fetch = [&](auto match) {
+    unsigned long long r = 0ull;
+#pragma unroll
+    for (int u = 0; u < KS; ++u)
+      if (u * 64 < ns) {
+        const unsigned long long m = __ballot(match(u));
+        if (m) {
+          const int src = __ffsll((long long)m) - 1;
+          r = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hi[u], src) << 32) |
+              (unsigned int)__builtin_amdgcn_readlane((int)lo[u], src);
+        }
+      }
+    return r;
+  };
+  unsigned int phi = vand_hi;                                  // hb < 32: every key has this high word
+  if (hb >= 32) {
+    const int hbh = hb - 32;
+    phi = hbh < 31 ? vand_hi >> (hbh + 1) : 0u;                // the high bits all keys share
+    for (int b = hbh; b >= 0; --b) {
+      const unsigned int t0 = phi << 1;
+      int cnt0 = 0;
+#pragma unroll
+      for (int u = 0; u < KS; ++u)
+        if (u * 64 < ns) cnt0 += __popcll(__ballot((hi[u] >> b) == t0));
+      if (want <= cnt0) {
+        phi = t0;
+        inclass = cnt0;
+      } else {
+        want -= cnt0;
+        phi = t0 | 1u;
+        inclass -= cnt0;
+      }
+      if (inclass == 1) {
+        const unsigned int pp = phi;
+        const int bb = b;
+        thresh = fetch([&](int u) { return (hi[u] >> bb) == pp; });
+        tie_budget = 1;
+        return;
+      }
+    }
+  }
+  // the class shares its whole high word phi: go on in the low words
+  const int hbl = hb >= 32 ? 31 : hb;
+  unsigned int plo = hbl < 31 ? vand_lo >> (hbl + 1) : 0u;
+  for (int b = hbl; b >= 0; --b) {
+    const unsigned int t0 = plo << 1;
     int cnt0 = 0;
 #pragma unroll
     for (int u = 0; u < KS; ++u)
-      if (u * 64 < ns) cnt0 += __popcll(__ballot(key[u] != kNoKey && (key[u] >> b) == t0));
+      if (u * 64 < ns) cnt0 += __popcll(__ballot(hi[u] == phi && (lo[u] >> b) == t0));
     if (want <= cnt0) {
-      prefix = t0;
+      plo = t0;
       inclass = cnt0;
     } else {
       want -= cnt0;
-      prefix = t0 | 1ull;
+      plo = t0 | 1u;
       inclass -= cnt0;
     }
     if (inclass == 1 && b > 0) {
-      unsigned long long found = 0ull;
-#pragma unroll
-      for (int u = 0; u < KS; ++u)
-        if (u * 64 < ns && key[u] != kNoKey && (key[u] >> b) == prefix) found = key[u];
-      thresh = wave_or_u64(found);                             // (one lane holds it, the others 0)
+      const unsigned int pp = plo, ph = phi;
+      const int bb = b;
+      thresh = fetch([&](int u) { return hi[u] == ph && (lo[u] >> bb) == pp; });
       tie_budget = 1;
       return;
     }
   }
-  thresh = prefix;
+  thresh = ((unsigned long long)phi << 32) | plo;
   tie_budget = want;
 }
 
@@ -657,7 +710,9 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
   const ColArgs& A = L.c;
   const letkf_search_tables& t = A.t;
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  // (scalar: one column / point per WAVE -- derived from threadIdx alone hipcc takes everything that hangs on it, the
+  // mesh walk, the survivor counts, the select's loop, for divergent and wraps it in exec-mask loops)
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nlev = A.nlev;
   const int nl2 = (nlev + 1) & ~1;
   const int cstride = 4 * kSurvL + nl2;                           // doubles per wave

@@ -351,7 +351,7 @@ namespace {
 __device__ __forceinline__ void cols_dot(const double* __restrict__ Cm, const int ldc, const int len, const int ncols,
                                          const double* __restrict__ Rm, const int ldr, const int nbr,
                                          double* __restrict__ P, const int ldp) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
   for (int j = wv; j < ncols; j += nwv) {
     const double* cj = Cm + (size_t)j * ldc;
     double acc[kMaxNb];
@@ -402,7 +402,7 @@ __device__ __forceinline__ int ov_n_of(const PointArgs& A, long pt) {
 __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const StagedArgs S, const int pcq_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const PointArgs& A = S.A;
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
   const int k = A.k, nv = A.nv, nb = nv + 2;
   const double km1 = (double)(k - 1);
   double* lam = smem;                  // k + 2 each (up to k + 1 stored columns)
