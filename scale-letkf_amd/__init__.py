@@ -279,7 +279,7 @@ class Context:
         counts = torch.zeros(npts, dtype=torch.int32, device=rig.device)
         f = self._l.letkf_obs_search_columns_dev
         self._check(f(self._c, C.byref(tables), C.c_int64(nij1), C.c_int32(nlev), _ptr(rig), _ptr(rjg), _ptr(rlev),
-                      _ptr(rz), C.c_int32(0), _ptr(counts), None, None, None, None, _ptr(nobs_ctype), _ptr(cutd_ctype)))
+                      _ptr(rz), C.c_int32(0), _ptr(counts), None, None, None, None, None, None))
         obs_off = torch.zeros(npts + 1, dtype=torch.int64, device=rig.device)
         obs_off[1:] = torch.cumsum(counts.to(torch.int64), 0)
         nnz = int(obs_off[-1].item())
@@ -287,7 +287,8 @@ class Context:
         rdiag = torch.empty(max(nnz, 1), dtype=torch.float64, device=rig.device)
         rloc = torch.empty(max(nnz, 1), dtype=torch.float64, device=rig.device)
         self._check(f(self._c, C.byref(tables), C.c_int64(nij1), C.c_int32(nlev), _ptr(rig), _ptr(rjg), _ptr(rlev),
-                      _ptr(rz), C.c_int32(1), None, _ptr(obs_off), _ptr(obs_idx), _ptr(rdiag), _ptr(rloc), None, None))
+                      _ptr(rz), C.c_int32(1), None, _ptr(obs_off), _ptr(obs_idx), _ptr(rdiag), _ptr(rloc), _ptr(nobs_ctype),
+                      _ptr(cutd_ctype)))    # (diagnostics with the fill pass: the count pass then needs no selection)
         return obs_off, obs_idx[:nnz], rdiag[:nnz], rloc[:nnz]
 
     # ---- (5) set_letkf_obs on the device

@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/letkf_amd.h"
 #include "letkf_device.h"
@@ -581,123 +582,121 @@ __device__ __forceinline__ VertOut vertical_nd(const int vm, const double vloc, 
   return o;
 }
 
-// wave-wide OR / AND on the vector ALU (the DPP sequence of wave_incl_scan; lane 63 ends up with the total)
-__device__ __forceinline__ unsigned int wave_or_u32(unsigned int v) {
-  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
-  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
-  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
-  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
-  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
-  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+// wave-wide minimum / maximum of one unsigned word per lane on the vector ALU (the DPP sequence of wave_incl_scan with
+// the operation's identity shifted in at the row ends; lane 63 ends up with the result)
+__device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
+  v = min(v, (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xF, 0xF, false));
+  v = min(v, (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xF, 0xF, false));
+  v = min(v, (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xF, 0xF, false));
+  v = min(v, (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xF, 0xF, false));
+  v = min(v, (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xA, 0xF, false));
+  v = min(v, (unsigned int)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xC, 0xF, false));
   return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
-  return ((unsigned long long)wave_or_u32((unsigned int)(v >> 32)) << 32) | wave_or_u32((unsigned int)v);
+__device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
+  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));
+  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));
+  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));
+  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));
+  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+  return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// nmax-th smallest of the wave's keys held in REGISTERS (slot u of lane l = candidate 64 u + l; kNoKey = none): a binary
-// search over the bit positions, MSB first, counting the candidates of the current class whose next bit is 0 with
-// ballots -- no LDS, no atomics.  Starts at the highest bit in which the keys differ at all (wave OR / AND by DPP) and
-// stops as soon as the class that holds the wanted key holds nothing else (~18 bit steps for ~200 double keys).
-// The steps run on the HIGH WORDS of the keys as long as those still tell the class apart (32-bit shifts and compares
-// at full rate; the 64-bit forms are quarter rate and made this select 2/3 of the fill phase), on the low words only
-// for what is left -- keys that agree in their upper 32 bits.
+// want-th smallest (1-based, want <= nreal) of the wave's keys held in REGISTERS (slot u of lane l = candidate 64 u + l;
+// kNoKey = none; every real key < 2^63), and how many of the keys equal to it belong to the selection.
+//   rounds: the class [lo, hi) that holds the wanted key is cut into <= 256 equal key ranges, the class members are
+//     histogrammed with LDS atomics (one per candidate) and find_bin's wave scan names the range holding the wanted key --
+//     2-3 dependent wave steps per round; the first class spans the high words actually present (wave min / max), so a
+//     round tells ~8 bits, and ~380 distance keys are down to a handful after one or two rounds;
+//   finish: a class of <= 64 is laid out one key per lane and every lane counts the class keys below / not above its own
+//     (broadcast LDS reads): the wanted key is the one whose two counts straddle `want`.
+// (The first version searched bit by bit, counting with a ballot per slot and bit: ~20 steps of 9 dependent
+// VALU -> SALU round trips, 28 k cycles per select at the 2 waves per SIMD this kernel runs at -- 57 % of the fill pass.)
 template <int KS>
-__device__ __forceinline__ void bit_thresh(const unsigned long long (&key)[KS], const int ns, const int nreal, int want,
-                                           unsigned long long& thresh, int& tie_budget) {
-  unsigned int hi[KS], lo[KS];
-  unsigned long long vor = 0ull, vnand = 0ull;                 // OR of the keys, OR of their complements
+__device__ __forceinline__ void hist_thresh(const unsigned long long (&key)[KS], const int ns, const int nreal, int want,
+                                            unsigned int* hist, unsigned long long& thresh, int& tie_budget) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  unsigned int mn = ~0u, mx = 0u;
 #pragma unroll
   for (int u = 0; u < KS; ++u) {
-    hi[u] = (unsigned int)(key[u] >> 32);                      // (kNoKey: all ones -- never equal to a t0, whose LSB is 0,
-    lo[u] = (unsigned int)key[u];                              //  nor to the prefix of a class that a real key defines)
-    if (u * 64 < ns && key[u] != kNoKey) {
-      vor |= key[u];
-      vnand |= ~key[u];
-    }
+    const unsigned int h = (unsigned int)(key[u] >> 32);
+    mn = min(mn, h);                                             // (kNoKey's high word is the identity of the minimum)
+    mx = max(mx, key[u] != kNoKey ? h : 0u);
   }
-  vor = wave_or_u64(vor);
-  const unsigned long long vand = ~wave_or_u64(vnand);
-  const unsigned long long diff = vor ^ vand;
-  if (diff == 0ull) {                                          // all keys equal
-    thresh = vor;
-    tie_budget = want;
-    return;
-  }
-  const int hb = 63 - __clzll((long long)diff);
-  const unsigned int vand_hi = (unsigned int)(vand >> 32), vand_lo = (unsigned int)vand;
+  unsigned long long lo = (unsigned long long)wave_min_u32(mn) << 32;
+  unsigned long long hi = ((unsigned long long)wave_max_u32(mx) + 1ull) << 32;
   int inclass = nreal;
-  // the one key of a class of one: slot by slot, a ballot finds its lane
-  auto fetch = [&](auto match) {
-    unsigned long long r = 0ull;
-#pragma unroll
-    for (int u = 0; u < KS; ++u)
-      if (u * 64 < ns) {
-        const unsigned long long m = __ballot(match(u));
-        if (m) {
-          const int src = __ffsll((long long)m) - 1;
-          r = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hi[u], src) << 32) |
-              (unsigned int)__builtin_amdgcn_readlane((int)lo[u], src);
-        }
-      }
-    return r;
-  };
-  unsigned int phi = vand_hi;                                  // hb < 32: every key has this high word
-  if (hb >= 32) {
-    const int hbh = hb - 32;
-    phi = hbh < 31 ? vand_hi >> (hbh + 1) : 0u;                // the high bits all keys share
-    for (int b = hbh; b >= 0; --b) {
-      const unsigned int t0 = phi << 1;
-      int cnt0 = 0;
-#pragma unroll
-      for (int u = 0; u < KS; ++u)
-        if (u * 64 < ns) cnt0 += __popcll(__ballot((hi[u] >> b) == t0));
-      if (want <= cnt0) {
-        phi = t0;
-        inclass = cnt0;
-      } else {
-        want -= cnt0;
-        phi = t0 | 1u;
-        inclass -= cnt0;
-      }
-      if (inclass == 1) {
-        const unsigned int pp = phi;
-        const int bb = b;
-        thresh = fetch([&](int u) { return (hi[u] >> bb) == pp; });
-        tie_budget = 1;
-        return;
-      }
-    }
-  }
-  // the class shares its whole high word phi: go on in the low words
-  const int hbl = hb >= 32 ? 31 : hb;
-  unsigned int plo = hbl < 31 ? vand_lo >> (hbl + 1) : 0u;
-  for (int b = hbl; b >= 0; --b) {
-    const unsigned int t0 = plo << 1;
-    int cnt0 = 0;
-#pragma unroll
-    for (int u = 0; u < KS; ++u)
-      if (u * 64 < ns) cnt0 += __popcll(__ballot(hi[u] == phi && (lo[u] >> b) == t0));
-    if (want <= cnt0) {
-      plo = t0;
-      inclass = cnt0;
-    } else {
-      want -= cnt0;
-      plo = t0 | 1u;
-      inclass -= cnt0;
-    }
-    if (inclass == 1 && b > 0) {
-      const unsigned int pp = plo, ph = phi;
-      const int bb = b;
-      thresh = fetch([&](int u) { return hi[u] == ph && (lo[u] >> bb) == pp; });
-      tie_budget = 1;
+  while (inclass > 64) {
+    const unsigned long long span1 = hi - lo - 1ull;
+    if (span1 == 0ull) {                                         // one key value, more than 64 times
+      thresh = lo;
+      tie_budget = want;
       return;
     }
+    const int w = 64 - __clzll((long long)span1);
+    const int sh = w > 8 ? w - 8 : 0;
+    *reinterpret_cast<uint4*>(&hist[4 * lane]) = uint4{0u, 0u, 0u, 0u};
+    wave_lds_sync();
+#pragma unroll
+    for (int u = 0; u < KS; ++u)
+      if (u * 64 < ns && key[u] >= lo && key[u] < hi) atomicAdd(&hist[(unsigned int)((key[u] - lo) >> sh)], 1u);
+    wave_lds_sync();
+    int bsel = 0, before = 0;
+    find_bin(hist, want, bsel, before);
+    const int cb = (int)hist[bsel];
+    wave_lds_sync();
+    want -= before;
+    inclass = __builtin_amdgcn_readfirstlane(cb);
+    lo += (unsigned long long)bsel << sh;
+    const unsigned long long top = lo + (1ull << sh);
+    hi = top < hi ? top : hi;
   }
-  thresh = ((unsigned long long)phi << 32) | plo;
-  tie_budget = want;
+  // finish: the class, one key per lane
+  unsigned long long* cbuf = reinterpret_cast<unsigned long long*>(hist);
+  int base = 0;
+#pragma unroll
+  for (int u = 0; u < KS; ++u)
+    if (u * 64 < ns) {
+      const bool in = key[u] >= lo && key[u] < hi;
+      const unsigned long long m = __ballot(in);
+      if (in) cbuf[base + __popcll(m & lt_mask)] = key[u];
+      base += __popcll(m);
+    }
+  wave_lds_sync();
+  const unsigned long long mine = lane < inclass ? cbuf[lane] : kNoKey;
+  int r_lt = 0, r_le = 0;
+  for (int j = 0; j < inclass; ++j) {
+    const unsigned long long kj = cbuf[j];                      // (one address: a broadcast read)
+    r_lt += kj < mine;
+    r_le += kj <= mine;
+  }
+  const unsigned long long hit = __ballot(lane < inclass && r_lt < want && r_le >= want);
+  const int src = __ffsll((long long)hit) - 1;                  // (hit != 0: want <= inclass)
+  thresh = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(mine >> 32), src) << 32) |
+           (unsigned int)__builtin_amdgcn_readlane((int)mine, src);
+  tie_budget = want - __builtin_amdgcn_readlane(r_lt, src);
+  wave_lds_sync();
 }
 
+#ifdef LETKF_WAVE_PROF
+__device__ unsigned long long g_lim_prof[8];
+#define LP_T() __builtin_readcyclecounter()
+#define LP_ADD(i, v) lpa[i] += (unsigned long long)(v)
+#define LP_DECL() unsigned long long lpa[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define LP_FLUSH() do { if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_lim_prof[i], lpa[i]); } while (0)
+#else
+#define LP_DECL() do {} while (0)
+#define LP_FLUSH() do {} while (0)
+#define LP_T() 0ull
+#define LP_ADD(i, v) do {} while (0)
+#endif
 struct ColLimArgs {
   ColArgs c;
   double* cutd_ctype;    // [npts][nctype] or null
@@ -706,7 +705,7 @@ struct ColLimArgs {
 __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(const ColLimArgs L) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) double smem_lim[];
-  __shared__ unsigned int hist_all[4][256];
+  __shared__ __attribute__((aligned(16))) unsigned int hist_all[4][256];
   const ColArgs& A = L.c;
   const letkf_search_tables& t = A.t;
   const int lane = threadIdx.x & 63;
@@ -727,6 +726,7 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
   PA.rdiag_l = A.rdiag_l;
   PA.rloc_l = A.rloc_l;
 
+  LP_DECL();
   for (long col = (long)blockIdx.x * 4 + wv; col < A.nij1; col += (long)gridDim.x * 4) {
     const double ri = A.rig[col], rj = A.rjg[col];
     for (int l = lane; l < nlev; l += 64) cntl[l] = 0;
@@ -746,6 +746,7 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
       const int icm = t.group_member[gs];                         // master
       const int nmax = t.max_nobs[icm];
       // ---- horizontal part, all members of the group
+      [[maybe_unused]] const unsigned long long lp0 = LP_T();
       int ns = 0;
       bool overflow = false;
       for (int m = gs; m < ge && !overflow; ++m) {
@@ -804,6 +805,8 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      LP_ADD(0, LP_T() - lp0);
+      LP_ADD(6, ns);
       const double cut_default = (t.criterion == 1) ? t.hori_loc[icm] * kDistZeroFac : 0.0;   // :1384-1389
       // the members' vertical parameters, once per group (wave-uniform; up to 4 members are selected per lane by
       // compares -- per-lane table look-ups inside the level loop were a third of the kernel's time)
@@ -818,6 +821,7 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
         varloc_m[mo] = t.varloc[ic];
       }
       const bool many = ge - gs > 4;                              // (not expected: the reference merges two types)
+      const bool count_only = !A.fill && !L.cutd_ctype && nmax > 0;
 
       for (int lev = 0; lev < nlev; ++lev) {
         const long p = col + A.nij1 * (long)lev;
@@ -868,11 +872,13 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
           const double lnrain = log(t.rain_base);
           // ---- (1) vertical part: keys (limited group) or straight emission (no limit)
           int acc_n = 0;
+          [[maybe_unused]] const unsigned long long lp1 = LP_T();
           unsigned long long keyr[kKeyS];
 #pragma unroll
           for (int u = 0; u < kKeyS; ++u) {
             keyr[u] = kNoKey;
             if (u * 64 >= ns) continue;                          // (wave-uniform)
+            if (count_only && acc_n >= nmax) continue;           // (the count is min(accepted, limit): enough seen)
             const int si = u * 64 + lane;
             VertOut vo{0.0, 0.0, 0.0, false};
             int row = 0, ic = icm;
@@ -928,13 +934,15 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
             acc_n += __popcll(mk);
           }
           nsel = acc_n;
+          [[maybe_unused]] const unsigned long long lp2 = LP_T();
+          LP_ADD(1, lp2 - lp1);
           if (nmax > 0) {
             nsel = min(acc_n, nmax);
             unsigned long long thresh = kNoKey;                  // every real key is below it
             int tie_budget = 0;
             if (acc_n >= nmax && (acc_n > nmax ? (A.fill || L.cutd_ctype) : L.cutd_ctype != nullptr)) {
               // (2) the nmax-th smallest key: selection threshold, and the cut-off measure once the limit is hit
-              bit_thresh<kKeyS>(keyr, ns, acc_n, nmax, thresh, tie_budget);
+              hist_thresh<kKeyS>(keyr, ns, acc_n, nmax, hist, thresh, tie_budget);
               const double kv = __longlong_as_double((long long)(t.criterion == 2 ? 0x7FFFFFFFFFFFFFFFull - thresh : thresh));
               cutd = (t.criterion == 1) ? t.hori_loc[icm] * sqrt(kv) : kv;
               if (acc_n == nmax) {
@@ -942,57 +950,75 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
                 tie_budget = 0;
               }
             }
+            [[maybe_unused]] const unsigned long long lp3 = LP_T();
+            LP_ADD(2, lp3 - lp2);
+            LP_ADD(5, acc_n > nmax);
             if (A.fill) {
-              // (3) emission in candidate order
-              int emitted = 0;
+              // (3) emission in candidate order.  The selected candidates' buffer slots are first compacted into a list
+              // (LDS, 16 bit each) in output order; the weights -- an exponential and two divisions each -- are then
+              // computed for full wavefronts of SELECTED rows, not for every slot with a selected lane in it (a limit
+              // of 100 out of ~380 survivors: 2 rounds instead of 6), and the stores are contiguous.
+              unsigned short* list = reinterpret_cast<unsigned short*>(hist);   // [512]
+              int emitted = 0, nl = 0;
+              auto flush = [&]() {
+                wave_lds_sync();
+                for (int r = 0; r < nl; r += 64) {
+                  const int e = r + lane;
+                  if (e < nl) {
+                    const int si = list[e];
+                    const double2 a2 = *reinterpret_cast<const double2*>(&sb[4 * si]);
+                    const double2 b2 = *reinterpret_cast<const double2*>(&sb[4 * si + 2]);
+                    const long packed = __double_as_longlong(a2.x);
+                    const int mo = (int)(packed >> 32);
+                    int vm = vm_m[0];
+                    double vloc = vloc_m[0], varloc = varloc_m[0];
+#pragma unroll
+                    for (int q = 1; q < 4; ++q)
+                      if (mo == q) {
+                        vm = vm_m[q];
+                        vloc = vloc_m[q];
+                        varloc = varloc_m[q];
+                      }
+                    if (many && mo >= 4) {
+                      const int ic = t.group_member[gs + mo];
+                      vm = t.vmode[ic];
+                      vloc = t.vert_loc[ic];
+                      varloc = t.varloc[ic];
+                    }
+                    const double vref = (vloc != 0.0) ? (vm == 1 ? vz : vlnp) : 0.0;
+                    const double vconst = (vm == 3 && vloc != 0.0) ? fabs(lnrain - vref) / vloc : 0.0;
+                    const VertOut vo = vertical_cal(vm, vloc, varloc, vconst, vref, a2.y, b2.x, b2.y);
+                    const long o = out + emitted + e;
+                    A.obs_idx[o] = (int)(packed & 0xFFFFFFFFl);
+                    A.rdiag_l[o] = vo.rdiag;
+                    A.rloc_l[o] = vo.rloc;
+                  }
+                }
+                emitted += nl;
+                nl = 0;
+                wave_lds_sync();
+              };
 #pragma unroll
               for (int u = 0; u < kKeyS; ++u) {
                 if (u * 64 >= ns) continue;                      // (wave-uniform)
-                const int si = u * 64 + lane;
-                bool take = false, tie = false;
-                {
-                  const unsigned long long key = keyr[u];
-                  take = key != kNoKey && key < thresh;
-                  tie = key != kNoKey && thresh != kNoKey && key == thresh;
-                }
+                if (nl > 512 - 64) flush();
+                const unsigned long long key = keyr[u];
+                const bool take = key != kNoKey && key < thresh;
+                const bool tie = key != kNoKey && thresh != kNoKey && key == thresh;
                 const unsigned long long mk = __ballot(take);
                 const unsigned long long tk = __ballot(tie);
                 const int tpos = __popcll(tk & lt_mask);
                 const bool tsel = tie && tpos < tie_budget;
-                if (take || tsel) {
-                  const double2 a2 = *reinterpret_cast<const double2*>(&sb[4 * si]);
-                  const double2 b2 = *reinterpret_cast<const double2*>(&sb[4 * si + 2]);
-                  const long packed = __double_as_longlong(a2.x);
-                  const int mo = (int)(packed >> 32);
-                  int vm = vm_m[0];
-                  double vloc = vloc_m[0], varloc = varloc_m[0];
-#pragma unroll
-                  for (int u = 1; u < 4; ++u)
-                    if (mo == u) {
-                      vm = vm_m[u];
-                      vloc = vloc_m[u];
-                      varloc = varloc_m[u];
-                    }
-                  if (many && mo >= 4) {
-                    const int ic = t.group_member[gs + mo];
-                    vm = t.vmode[ic];
-                    vloc = t.vert_loc[ic];
-                    varloc = t.varloc[ic];
-                  }
-                  const double vref = (vloc != 0.0) ? (vm == 1 ? vz : vlnp) : 0.0;
-                  const double vconst = (vm == 3 && vloc != 0.0) ? fabs(lnrain - vref) / vloc : 0.0;
-                  const VertOut vo = vertical_cal(vm, vloc, varloc, vconst, vref, a2.y, b2.x, b2.y);
-                  const long o = out + emitted + (take ? __popcll(mk & lt_mask) : __popcll(mk) + tpos);
-                  A.obs_idx[o] = (int)(packed & 0xFFFFFFFFl);
-                  A.rdiag_l[o] = vo.rdiag;
-                  A.rloc_l[o] = vo.rloc;
-                }
+                // (the reference's order inside one slot: the strictly better ones, then the ties)
+                if (take || tsel) list[nl + (take ? __popcll(mk & lt_mask) : __popcll(mk) + tpos)] = (unsigned short)(u * 64 + lane);
                 const int nt = min(__popcll(tk), tie_budget);
                 tie_budget -= nt;
-                emitted += __popcll(mk) + nt;
+                nl += __popcll(mk) + nt;
               }
+              flush();
             }
             if (acc_n < nmax) cutd = cut_default;
+            LP_ADD(3, LP_T() - lp3);
           }
         }
         if (lane == 0) {
@@ -1021,6 +1047,7 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  LP_FLUSH();
 }
 
 hipError_t launch_search_columns_limited(const letkf_search_tables& t, long nij1, int nlev, const double* rig,
@@ -1036,7 +1063,17 @@ hipError_t launch_search_columns_limited(const letkf_search_tables& t, long nij1
   const long nwg = (nij1 + 3) / 4;
   const long g = (long)num_cu * 8;
   const int grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
+#ifdef LETKF_WAVE_PROF
+  unsigned long long z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lim_prof), z, sizeof z);
+#endif
   hipLaunchKernelGGL(letkf_search_columns_limited_kernel, dim3(grid), dim3(256), lds, st, a);
+#ifdef LETKF_WAVE_PROF
+  (void)hipStreamSynchronize(st);
+  (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_lim_prof), sizeof z);
+  fprintf(stderr, "LIM_PROF fill=%d grid=%d horiz=%llu vert=%llu select=%llu emit=%llu nsel=%llu sum_ns=%llu\n", fill, grid, z[0], z[1],
+          z[2], z[3], z[5], z[6]);
+#endif
   return hipGetLastError();
 }
 
