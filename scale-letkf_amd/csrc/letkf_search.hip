@@ -11,11 +11,13 @@
 // per-point scratch.  HBM-bound integer/byte work: no MFMA here by design.
 
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdint.h>
 #include <stdio.h>
 
 #include "../../include/letkf_amd.h"
 #include "letkf_device.h"
+#include "letkf_divby_dev.h"
 #include "letkf_search_dev.h"
 
 namespace letkf {
@@ -602,6 +604,15 @@ __device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
   v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
   return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
 }
+// a wave-uniform value, said so: into scalar registers (what hipcc loads through the tables' plain pointers it keeps in
+// vector registers -- and spills to scratch inside the level loop)
+__device__ __forceinline__ int uni(const int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ double uni(const double x) {
+  const long long b = __double_as_longlong(x);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -715,7 +726,7 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
   const int nlev = A.nlev;
   const int nl2 = (nlev + 1) & ~1;
   const int cstride = 4 * kSurvL + nl2;                           // doubles per wave
-  double* sb = smem_lim + (size_t)wv * cstride;                   // [kSurvL][4]: (row, member), nd_h, v_obs, err
+  double* sb = smem_lim + (size_t)wv * cstride;                   // [kSurvL][4]: nd_h, v_obs, row, err
   int* cntl = reinterpret_cast<int*>(sb + 4 * kSurvL);            // [nlev] entries emitted so far per level
   unsigned int* hist = hist_all[wv];
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -745,13 +756,17 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
       const int gs = t.group_start[ig], ge = t.group_start[ig + 1];
       const int icm = t.group_member[gs];                         // master
       const int nmax = t.max_nobs[icm];
-      // ---- horizontal part, all members of the group
+      // ---- horizontal part, all members of the group.  Every member starts a fresh 64-entry slot of the buffer, so
+      // that one slot holds ONE member's survivors and its vertical parameters are wave-uniform in the level loop.
       [[maybe_unused]] const unsigned long long lp0 = LP_T();
       int ns = 0;
-      bool overflow = false;
+      bool overflow = ge - gs > 4;                                // (not expected: the reference merges two types)
+      int mbeg[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX}, mend[4] = {0, 0, 0, 0};
       for (int m = gs; m < ge && !overflow; ++m) {
         const int ic = t.group_member[m];
-        if (t.varloc[ic] < kTiny) continue;                       // local_cal :1843
+        ns = (ns + 63) & ~63;
+        const int ns0 = ns;
+        const bool skip = t.varloc[ic] < kTiny;                   // local_cal :1843
         const int vm = t.vmode[ic];
         const double vloc = t.vert_loc[ic], hloc = t.hori_loc[ic];
         const double dzi = hloc * kDistZeroFac / t.dx, dzj = hloc * kDistZeroFac / t.dy;
@@ -762,7 +777,7 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
         jmin = max(jmin, 1);
         imax = min(imax, t.ngrdext_i[ic]);
         jmax = min(jmax, t.ngrdext_j[ic]);
-        if (imin > imax || jmin > jmax) continue;
+        if (skip || imin > imax) jmax = jmin - 1;                 // (nothing to walk)
         const long acb = t.ac_off[ic];
         const int ld = t.ngrdext_i[ic] + 1;
         for (int j = jmin; j <= jmax && !overflow; ++j) {
@@ -794,34 +809,61 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
             }
             if (ok) {
               const int si = ns + __popcll(mk & lt_mask);
-              const long packed = (long)(unsigned int)row | ((long)(m - gs) << 32);
-              *reinterpret_cast<double2*>(&sb[4 * si]) = double2{__longlong_as_double(packed), nd_h};
-              *reinterpret_cast<double2*>(&sb[4 * si + 2]) = double2{vobs, err};
+              *reinterpret_cast<double2*>(&sb[4 * si]) = double2{nd_h, vobs};
+              *reinterpret_cast<double2*>(&sb[4 * si + 2]) = double2{__longlong_as_double((long)row), err};
             }
             ns += na;
           }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (m - gs == q) {
+            mbeg[q] = ns0;
+            mend[q] = ns;
+          }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wave_lds_sync();
       LP_ADD(0, LP_T() - lp0);
       LP_ADD(6, ns);
       const double cut_default = (t.criterion == 1) ? t.hori_loc[icm] * kDistZeroFac : 0.0;   // :1384-1389
-      // the members' vertical parameters, once per group (wave-uniform; up to 4 members are selected per lane by
-      // compares -- per-lane table look-ups inside the level loop were a third of the kernel's time)
+      // the members' vertical parameters, once per group (wave-uniform)
       int vm_m[4], ic_m[4];
       double vloc_m[4], varloc_m[4];
+      // fast path (distance criterion, at most two members, ordinary vertical scales): the keys are the distances
+      // themselves (vertical_nd), the survivors' level-independent parts stay in registers over the level loop and the
+      // division by the member's vertical scale goes through its reciprocal (letkf_divby_dev.h)
+      bool fast = nmax > 0 && t.criterion == 1 && ge - gs <= 2 && !overflow;
 #pragma unroll
       for (int mo = 0; mo < 4; ++mo) {
         const int ic = t.group_member[min(gs + mo, ge - 1)];
-        ic_m[mo] = ic;
-        vm_m[mo] = t.vmode[ic];
-        vloc_m[mo] = t.vert_loc[ic];
-        varloc_m[mo] = t.varloc[ic];
+        ic_m[mo] = uni(ic);
+        vm_m[mo] = uni(t.vmode[ic]);
+        vloc_m[mo] = uni(t.vert_loc[ic]);
+        varloc_m[mo] = uni(t.varloc[ic]);
+        if (varloc_m[mo] < 1e-290) fast = false;                  // (rloc may underflow to 0 inside the cut-off)
+        if (vloc_m[mo] != 0.0 && !divby::in_range(vloc_m[mo])) fast = false;
       }
-      const bool many = ge - gs > 4;                              // (not expected: the reference merges two types)
       const bool count_only = !A.fill && !L.cutd_ctype && nmax > 0;
+      const int mbeg1 = uni(mbeg[1]);                             // (INT_MAX: one member)
+      double yv_m[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) yv_m[q] = uni(divby::reciprocal(vloc_m[q]));
+      double ndh2_r[kKeyS], vobs_r[kKeyS];
+      if (fast) {
+#pragma unroll
+        for (int u = 0; u < kKeyS; ++u) {
+          ndh2_r[u] = __longlong_as_double(0x7FF0000000000000ll);  // +inf: padding lanes fail the cut-off test
+          vobs_r[u] = 0.0;
+          if (u * 64 >= ns) continue;
+          const int si = u * 64 + lane;
+          const int me = u * 64 >= mbeg1 ? mend[1] : mend[0];
+          if (si < me) {
+            const double2 a2 = *reinterpret_cast<const double2*>(&sb[4 * si]);
+            ndh2_r[u] = a2.x * a2.x;
+            vobs_r[u] = a2.y;
+          }
+        }
+      }
 
       for (int lev = 0; lev < nlev; ++lev) {
         const long p = col + A.nij1 * (long)lev;
@@ -868,47 +910,73 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
             }
           }
         } else {
-          const double vz = A.rz[p], vlnp = log(A.rlev[p]);
-          const double lnrain = log(t.rain_base);
+          const double vz = uni(A.rz[p]), vlnp = uni(log(A.rlev[p]));
+          const double lnrain = uni(log(t.rain_base));
+          double vref_m[4], vconst_m[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            vref_m[q] = (vloc_m[q] != 0.0) ? (vm_m[q] == 1 ? vz : vlnp) : 0.0;
+            vconst_m[q] = 0.0;
+            if (vm_m[q] == 3 && vloc_m[q] != 0.0) vconst_m[q] = uni(fabs(lnrain - vref_m[q]) / vloc_m[q]);
+          }
           // ---- (1) vertical part: keys (limited group) or straight emission (no limit)
           int acc_n = 0;
           [[maybe_unused]] const unsigned long long lp1 = LP_T();
           unsigned long long keyr[kKeyS];
+          if (fast) {
+            // three slots at a time in straight-line code (their dependent chains interleave), wave-uniform skips between
+            static_assert(kKeyS % 3 == 0, "slots are walked in threes");
+#pragma unroll
+            for (int u = 0; u < kKeyS; ++u) keyr[u] = kNoKey;
+#pragma unroll
+            for (int g3 = 0; g3 < kKeyS; g3 += 3) {
+              if (g3 * 64 >= ns) continue;                       // (wave-uniform)
+              if (count_only && acc_n >= nmax) continue;         // (the count is min(accepted, limit): enough seen)
+              unsigned long long am[3];
+#pragma unroll
+              for (int v = 0; v < 3; ++v) {
+                const int u = g3 + v;
+                const bool second = u * 64 >= mbeg1;             // the slot's member (wave-uniform)
+                const int vm = second ? vm_m[1] : vm_m[0];
+                const double vloc = second ? vloc_m[1] : vloc_m[0], yv = second ? yv_m[1] : yv_m[0];
+                const double vref = second ? vref_m[1] : vref_m[0], vconst = second ? vconst_m[1] : vconst_m[0];
+                const double qv = divby::quotient(fabs(vobs_r[u] - vref), vloc, yv);
+                const double nd_v = (vloc == 0.0) ? 0.0 : (vm == 3 ? vconst : qv);      // :1851-1865
+                const double nd = ndh2_r[u] + nd_v * nd_v;                              // :1888
+                const bool acc = !(nd_v > kDistZeroFac) && !(nd > kDistZeroFacSq);      // :1869, :1891
+                keyr[u] = acc ? (unsigned long long)__double_as_longlong(nd) : kNoKey;
+                am[v] = __ballot(acc);
+              }
+              acc_n += __popcll(am[0]) + __popcll(am[1]) + __popcll(am[2]);
+            }
+          } else
 #pragma unroll
           for (int u = 0; u < kKeyS; ++u) {
             keyr[u] = kNoKey;
             if (u * 64 >= ns) continue;                          // (wave-uniform)
             if (count_only && acc_n >= nmax) continue;           // (the count is min(accepted, limit): enough seen)
+            // the slot's member (wave-uniform)
+            int vm = vm_m[0], mo = 0, me = mend[0];
+            double vloc = vloc_m[0], varloc = varloc_m[0], vref = vref_m[0], vconst = vconst_m[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+              if (u * 64 >= mbeg[q]) {
+                mo = q;
+                me = mend[q];
+                vm = vm_m[q];
+                vloc = vloc_m[q];
+                varloc = varloc_m[q];
+                vref = vref_m[q];
+                vconst = vconst_m[q];
+              }
             const int si = u * 64 + lane;
             VertOut vo{0.0, 0.0, 0.0, false};
-            int row = 0, ic = icm;
-            if (si < ns) {
+            int row = 0;
+            if (si < me) {
               const double2 a2 = *reinterpret_cast<const double2*>(&sb[4 * si]);
               const double2 b2 = *reinterpret_cast<const double2*>(&sb[4 * si + 2]);
-              const long packed = __double_as_longlong(a2.x);
-              row = (int)(packed & 0xFFFFFFFFl);
-              const int mo = (int)(packed >> 32);
-              int vm = vm_m[0];
-              double vloc = vloc_m[0], varloc = varloc_m[0];
-              ic = ic_m[0];
-#pragma unroll
-              for (int u = 1; u < 4; ++u)
-                if (mo == u) {
-                  vm = vm_m[u];
-                  vloc = vloc_m[u];
-                  varloc = varloc_m[u];
-                  ic = ic_m[u];
-                }
-              if (many && mo >= 4) {
-                ic = t.group_member[gs + mo];
-                vm = t.vmode[ic];
-                vloc = t.vert_loc[ic];
-                varloc = t.varloc[ic];
-              }
-              const double vref = (vloc != 0.0) ? (vm == 1 ? vz : vlnp) : 0.0;
-              const double vconst = (vm == 3 && vloc != 0.0) ? fabs(lnrain - vref) / vloc : 0.0;
-              vo = (nmax > 0 && t.criterion == 1) ? vertical_nd(vm, vloc, varloc, vconst, vref, a2.y, b2.x, b2.y)
-                                                  : vertical_cal(vm, vloc, varloc, vconst, vref, a2.y, b2.x, b2.y);
+              row = (int)__double_as_longlong(b2.x);
+              vo = vertical_cal(vm, vloc, varloc, vconst, vref, a2.x, a2.y, b2.y);
             }
             const unsigned long long mk = __ballot(vo.acc);
             if (nmax > 0) {
@@ -925,11 +993,9 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
                 A.rdiag_l[o] = vo.rdiag;
                 A.rloc_l[o] = vo.rloc;
               }
-              if (A.nobs_ctype) {
 #pragma unroll
-                for (int mo = 0; mo < 4; ++mo)
-                  if (gs + mo < ge) cm[mo] += __popcll(__ballot(vo.acc && ic == ic_m[mo]));
-              }
+              for (int q = 0; q < 4; ++q)
+                if (mo == q) cm[q] += __popcll(mk);
             }
             acc_n += __popcll(mk);
           }
@@ -958,9 +1024,27 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
               // (LDS, 16 bit each) in output order; the weights -- an exponential and two divisions each -- are then
               // computed for full wavefronts of SELECTED rows, not for every slot with a selected lane in it (a limit
               // of 100 out of ~380 survivors: 2 rounds instead of 6), and the stores are contiguous.
-              unsigned short* list = reinterpret_cast<unsigned short*>(hist);   // [512]
-              int emitted = 0, nl = 0;
-              auto flush = [&]() {
+              unsigned short* list = reinterpret_cast<unsigned short*>(hist);   // [512]: 8 slots' worth per turn
+              int emitted = 0;
+              for (int turn = 0; turn * 512 < ns; ++turn) {
+                int nl = 0;
+#pragma unroll
+                for (int u = 0; u < kKeyS; ++u) {
+                  if (u * 64 >= ns || u / 8 != turn) continue;   // (wave-uniform)
+                  const unsigned long long key = keyr[u];
+                  const bool take = key != kNoKey && key < thresh;
+                  const bool tie = key != kNoKey && thresh != kNoKey && key == thresh;
+                  const unsigned long long mk = __ballot(take);
+                  const unsigned long long tk = __ballot(tie);
+                  const int tpos = __popcll(tk & lt_mask);
+                  const bool tsel = tie && tpos < tie_budget;
+                  // (the order inside one slot: the strictly better ones, then the ties)
+                  if (take || tsel)
+                    list[nl + (take ? __popcll(mk & lt_mask) : __popcll(mk) + tpos)] = (unsigned short)(u * 64 + lane);
+                  const int nt = min(__popcll(tk), tie_budget);
+                  tie_budget -= nt;
+                  nl += __popcll(mk) + nt;
+                }
                 wave_lds_sync();
                 for (int r = 0; r < nl; r += 64) {
                   const int e = r + lane;
@@ -968,54 +1052,27 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
                     const int si = list[e];
                     const double2 a2 = *reinterpret_cast<const double2*>(&sb[4 * si]);
                     const double2 b2 = *reinterpret_cast<const double2*>(&sb[4 * si + 2]);
-                    const long packed = __double_as_longlong(a2.x);
-                    const int mo = (int)(packed >> 32);
                     int vm = vm_m[0];
-                    double vloc = vloc_m[0], varloc = varloc_m[0];
+                    double vloc = vloc_m[0], varloc = varloc_m[0], vref = vref_m[0], vconst = vconst_m[0];
 #pragma unroll
                     for (int q = 1; q < 4; ++q)
-                      if (mo == q) {
+                      if (si >= mbeg[q]) {
                         vm = vm_m[q];
                         vloc = vloc_m[q];
                         varloc = varloc_m[q];
+                        vref = vref_m[q];
+                        vconst = vconst_m[q];
                       }
-                    if (many && mo >= 4) {
-                      const int ic = t.group_member[gs + mo];
-                      vm = t.vmode[ic];
-                      vloc = t.vert_loc[ic];
-                      varloc = t.varloc[ic];
-                    }
-                    const double vref = (vloc != 0.0) ? (vm == 1 ? vz : vlnp) : 0.0;
-                    const double vconst = (vm == 3 && vloc != 0.0) ? fabs(lnrain - vref) / vloc : 0.0;
-                    const VertOut vo = vertical_cal(vm, vloc, varloc, vconst, vref, a2.y, b2.x, b2.y);
+                    const VertOut vo = vertical_cal(vm, vloc, varloc, vconst, vref, a2.x, a2.y, b2.y);
                     const long o = out + emitted + e;
-                    A.obs_idx[o] = (int)(packed & 0xFFFFFFFFl);
+                    A.obs_idx[o] = (int)__double_as_longlong(b2.x);
                     A.rdiag_l[o] = vo.rdiag;
                     A.rloc_l[o] = vo.rloc;
                   }
                 }
                 emitted += nl;
-                nl = 0;
                 wave_lds_sync();
-              };
-#pragma unroll
-              for (int u = 0; u < kKeyS; ++u) {
-                if (u * 64 >= ns) continue;                      // (wave-uniform)
-                if (nl > 512 - 64) flush();
-                const unsigned long long key = keyr[u];
-                const bool take = key != kNoKey && key < thresh;
-                const bool tie = key != kNoKey && thresh != kNoKey && key == thresh;
-                const unsigned long long mk = __ballot(take);
-                const unsigned long long tk = __ballot(tie);
-                const int tpos = __popcll(tk & lt_mask);
-                const bool tsel = tie && tpos < tie_budget;
-                // (the reference's order inside one slot: the strictly better ones, then the ties)
-                if (take || tsel) list[nl + (take ? __popcll(mk & lt_mask) : __popcll(mk) + tpos)] = (unsigned short)(u * 64 + lane);
-                const int nt = min(__popcll(tk), tie_budget);
-                tie_budget -= nt;
-                nl += __popcll(mk) + nt;
               }
-              flush();
             }
             if (acc_n < nmax) cutd = cut_default;
             LP_ADD(3, LP_T() - lp3);
