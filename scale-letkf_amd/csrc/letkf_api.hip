@@ -626,7 +626,7 @@ int letkf_obs_search_columns_dev(letkf_ctx* c, const letkf_search_tables* t, int
   if (fill ? (!obs_off || !obs_idx || !rdiag_l || !rloc_l) : !counts)
     return fail(LETKF_E_INVALID, "missing output array for this phase");
   if ((size_t)4 * (4 * 512 + 2 * ((nlev + 1) & ~1)) * sizeof(double) > c->lds_max ||
-      (size_t)4 * (4 * 576 + ((nlev + 1) & ~1)) * sizeof(double) + 4096 > c->lds_max)
+      (size_t)4 * (4 * 576 + ((nlev + 1) & ~1)) * sizeof(double) + 4608 > c->lds_max)
     return fail(LETKF_E_INVALID, "too many levels for the column kernel's LDS counters");
   bool limited = false;
   if (int rc = tables_limited(c, t, &limited)) return rc;

@@ -166,7 +166,7 @@ __device__ __forceinline__ void find_bin(const unsigned int* hist, const int wan
   const unsigned long long mk = __ballot(here);
   if (mk == 0ull) {            // want exceeds the population (cannot happen for want <= count); keep the old default
     bsel = 255;
-    before = __shfl(incl, 63, 64) - (int)hist[255];
+    before = __builtin_amdgcn_readlane(incl, 63) - __builtin_amdgcn_readfirstlane((int)hist[255]);
     return;
   }
   const int src = __ffsll((long long)mk) - 1;
@@ -613,6 +613,10 @@ __device__ __forceinline__ double uni(const double x) {
   const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b >> 32));
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// number of set bits of a wave mask below this lane (v_mbcnt_lo / _hi: two instructions)
+__device__ __forceinline__ int mbcnt(const unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -630,20 +634,50 @@ __device__ __forceinline__ void wave_lds_sync() {
 // (The first version searched bit by bit, counting with a ballot per slot and bit: ~20 steps of 9 dependent
 // VALU -> SALU round trips, 28 k cycles per select at the 2 waves per SIMD this kernel runs at -- 57 % of the fill pass.)
 template <int KS>
-__device__ __forceinline__ void hist_thresh(const unsigned long long (&key)[KS], const int ns, const int nreal, int want,
-                                            unsigned int* hist, unsigned long long& thresh, int& tie_budget) {
+__device__ __forceinline__ void hist_thresh(const unsigned long long (&key_in)[KS], const int ns, const int nreal, int want,
+                                            unsigned int* hist, unsigned long long& thresh, int& tie_budget,
+                                            const double lin_scale = 0.0) {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  unsigned int mn = ~0u, mx = 0u;
+  unsigned long long key[KS];
 #pragma unroll
-  for (int u = 0; u < KS; ++u) {
-    const unsigned int h = (unsigned int)(key[u] >> 32);
-    mn = min(mn, h);                                             // (kNoKey's high word is the identity of the minimum)
-    mx = max(mx, key[u] != kNoKey ? h : 0u);
-  }
-  unsigned long long lo = (unsigned long long)wave_min_u32(mn) << 32;
-  unsigned long long hi = ((unsigned long long)wave_max_u32(mx) + 1ull) << 32;
+  for (int u = 0; u < KS; ++u) key[u] = key_in[u];
   int inclass = nreal;
+  if (lin_scale > 0.0 && inclass > 64) {
+    // first round by VALUE: the keys are doubles in [0, 256 / lin_scale) (squared distances up to the cut-off), and
+    // floor(key * lin_scale) is a monotone map onto 256 ranges of equal width -- no look at the keys' spread is needed
+    // and a class of ~380 is down to a few; whoever is not in the wanted range drops out of the wave's copy of the keys
+    *reinterpret_cast<uint4*>(&hist[4 * lane]) = uint4{0u, 0u, 0u, 0u};
+    wave_lds_sync();
+    int dig[KS];
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      dig[u] = min((int)(__longlong_as_double((long long)key[u]) * lin_scale), 255);
+      if (u * 64 < ns && key[u] != kNoKey) atomicAdd(&hist[dig[u]], 1u);
+    }
+    wave_lds_sync();
+    int bsel = 0, before = 0;
+    find_bin(hist, want, bsel, before);
+    const int cb = (int)hist[bsel];
+    wave_lds_sync();
+    want -= before;
+    inclass = __builtin_amdgcn_readfirstlane(cb);
+#pragma unroll
+    for (int u = 0; u < KS; ++u)
+      if (dig[u] != bsel) key[u] = kNoKey;
+  }
+  unsigned long long lo = 0ull, hi = 1ull << 63;                 // (every real key)
+  if (inclass > 64) {
+    unsigned int mn = ~0u, mx = 0u;
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      const unsigned int h = (unsigned int)(key[u] >> 32);
+      mn = min(mn, h);                                           // (kNoKey's high word is the identity of the minimum)
+      mx = max(mx, key[u] != kNoKey ? h : 0u);
+    }
+    lo = (unsigned long long)wave_min_u32(mn) << 32;
+    hi = ((unsigned long long)wave_max_u32(mx) + 1ull) << 32;
+  }
   while (inclass > 64) {
     const unsigned long long span1 = hi - lo - 1ull;
     if (span1 == 0ull) {                                         // one key value, more than 64 times
@@ -716,7 +750,7 @@ struct ColLimArgs {
 __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(const ColLimArgs L) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) double smem_lim[];
-  __shared__ __attribute__((aligned(16))) unsigned int hist_all[4][256];
+  __shared__ __attribute__((aligned(16))) unsigned int hist_all[4][kSurvL / 2];   // 256 bins / the emission list
   const ColArgs& A = L.c;
   const letkf_search_tables& t = A.t;
   const int lane = threadIdx.x & 63;
@@ -823,6 +857,8 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
           }
       }
       wave_lds_sync();
+      ns = uni(ns);
+      overflow = uni((int)overflow) != 0;
       LP_ADD(0, LP_T() - lp0);
       LP_ADD(6, ns);
       const double cut_default = (t.criterion == 1) ? t.hori_loc[icm] * kDistZeroFac : 0.0;   // :1384-1389
@@ -1008,7 +1044,7 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
             int tie_budget = 0;
             if (acc_n >= nmax && (acc_n > nmax ? (A.fill || L.cutd_ctype) : L.cutd_ctype != nullptr)) {
               // (2) the nmax-th smallest key: selection threshold, and the cut-off measure once the limit is hit
-              hist_thresh<kKeyS>(keyr, ns, acc_n, nmax, hist, thresh, tie_budget);
+              hist_thresh<kKeyS>(keyr, ns, acc_n, nmax, hist, thresh, tie_budget, fast ? 256.0 / 13.5 : 0.0);
               const double kv = __longlong_as_double((long long)(t.criterion == 2 ? 0x7FFFFFFFFFFFFFFFull - thresh : thresh));
               cutd = (t.criterion == 1) ? t.hori_loc[icm] * sqrt(kv) : kv;
               if (acc_n == nmax) {
@@ -1024,32 +1060,45 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
               // (LDS, 16 bit each) in output order; the weights -- an exponential and two divisions each -- are then
               // computed for full wavefronts of SELECTED rows, not for every slot with a selected lane in it (a limit
               // of 100 out of ~380 survivors: 2 rounds instead of 6), and the stores are contiguous.
-              unsigned short* list = reinterpret_cast<unsigned short*>(hist);   // [512]: 8 slots' worth per turn
-              int emitted = 0;
-              for (int turn = 0; turn * 512 < ns; ++turn) {
-                int nl = 0;
+              unsigned short* list = reinterpret_cast<unsigned short*>(hist);   // [kSurvL]
+              // (all the ballots first -- they do not depend on one another --, then the running positions on the
+              // scalar unit, then the writes: walked slot by slot with the tie budget carried along, the
+              // compare -> ballot -> count -> position chain of each slot waited for the one before)
+              const bool ties = thresh != kNoKey;
+              tie_budget = uni(tie_budget);
+              unsigned long long mk[kKeyS], tk[kKeyS];
 #pragma unroll
-                for (int u = 0; u < kKeyS; ++u) {
-                  if (u * 64 >= ns || u / 8 != turn) continue;   // (wave-uniform)
-                  const unsigned long long key = keyr[u];
-                  const bool take = key != kNoKey && key < thresh;
-                  const bool tie = key != kNoKey && thresh != kNoKey && key == thresh;
-                  const unsigned long long mk = __ballot(take);
-                  const unsigned long long tk = __ballot(tie);
-                  const int tpos = __popcll(tk & lt_mask);
-                  const bool tsel = tie && tpos < tie_budget;
-                  // (the order inside one slot: the strictly better ones, then the ties)
-                  if (take || tsel)
-                    list[nl + (take ? __popcll(mk & lt_mask) : __popcll(mk) + tpos)] = (unsigned short)(u * 64 + lane);
-                  const int nt = min(__popcll(tk), tie_budget);
-                  tie_budget -= nt;
-                  nl += __popcll(mk) + nt;
-                }
+              for (int u = 0; u < kKeyS; ++u) {
+                mk[u] = __ballot(keyr[u] < thresh);              // (kNoKey, the largest pattern, is below nothing)
+                tk[u] = ties ? __ballot(keyr[u] == thresh) : 0ull;
+              }
+              int nl = 0;
+#pragma unroll
+              for (int u = 0; u < kKeyS; ++u) {
+                if (u * 64 >= ns) continue;                      // (wave-uniform)
+                const bool take = keyr[u] < thresh, tie = ties && keyr[u] == thresh;
+                const int nm = __popcll(mk[u]), tpos = mbcnt(tk[u]);
+                // (the order inside one slot: the strictly better ones, then the ties)
+                if (take || (tie && tpos < tie_budget))
+                  list[nl + (take ? mbcnt(mk[u]) : nm + tpos)] = (unsigned short)(u * 64 + lane);
+                const int nt = min((int)__popcll(tk[u]), tie_budget);
+                tie_budget -= nt;
+                nl += nm + nt;
+              }
+              {
                 wave_lds_sync();
-                for (int r = 0; r < nl; r += 64) {
-                  const int e = r + lane;
-                  if (e < nl) {
-                    const int si = list[e];
+                [[maybe_unused]] const unsigned long long lp4 = LP_T();
+                LP_ADD(4, lp4 - lp3);
+                // two wavefronts of selected rows at a time, in straight-line code: every one of them passed the cut-off
+                // tests, so obs_local_cal's remaining arithmetic runs without its early exits and the two chains
+                // (reciprocal-free division, exponential, division) interleave
+                for (int r = 0; r < nl; r += 128) {
+                  double rl[2], rd[2];
+                  int rw[2];
+#pragma unroll
+                  for (int h = 0; h < 2; ++h) {
+                    const int e = r + 64 * h + lane;
+                    const int si = e < nl ? list[e] : 0;
                     const double2 a2 = *reinterpret_cast<const double2*>(&sb[4 * si]);
                     const double2 b2 = *reinterpret_cast<const double2*>(&sb[4 * si + 2]);
                     int vm = vm_m[0];
@@ -1063,14 +1112,24 @@ __global__ void __launch_bounds__(256, 2) letkf_search_columns_limited_kernel(co
                         vref = vref_m[q];
                         vconst = vconst_m[q];
                       }
-                    const VertOut vo = vertical_cal(vm, vloc, varloc, vconst, vref, a2.x, a2.y, b2.y);
-                    const long o = out + emitted + e;
-                    A.obs_idx[o] = (int)__double_as_longlong(b2.x);
-                    A.rdiag_l[o] = vo.rdiag;
-                    A.rloc_l[o] = vo.rloc;
+                    const double qv = fabs(a2.y - vref) / vloc;
+                    const double nd_v = (vloc == 0.0) ? 0.0 : (vm == 3 ? vconst : qv);      // :1851-1865
+                    const double nd = a2.x * a2.x + nd_v * nd_v;                            // :1888
+                    rl[h] = varloc * exp(-0.5 * nd);                                        // :1899
+                    rd[h] = b2.y * b2.y / rl[h];                                            // :1903
+                    rw[h] = (int)__double_as_longlong(b2.x);
+                  }
+#pragma unroll
+                  for (int h = 0; h < 2; ++h) {
+                    const int e = r + 64 * h + lane;
+                    if (e < nl) {
+                      const long o = out + e;
+                      A.obs_idx[o] = rw[h];
+                      A.rdiag_l[o] = rd[h];
+                      A.rloc_l[o] = rl[h];
+                    }
                   }
                 }
-                emitted += nl;
                 wave_lds_sync();
               }
             }
@@ -1130,6 +1189,7 @@ hipError_t launch_search_columns_limited(const letkf_search_tables& t, long nij1
   (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_lim_prof), sizeof z);
   fprintf(stderr, "LIM_PROF fill=%d grid=%d horiz=%llu vert=%llu select=%llu emit=%llu nsel=%llu sum_ns=%llu\n", fill, grid, z[0], z[1],
           z[2], z[3], z[5], z[6]);
+  fprintf(stderr, "LIM_PROF   emit: list=%llu (first turn; the rest is weights + stores)\n", z[4]);
 #endif
   return hipGetLastError();
 }
