@@ -31,6 +31,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warm-runs", choices=["x", "z"], default="z",
+                    help="direction of the eigensolver's warm-start runs: along ij (letkf_das_args.warm_stride = 0) or up "
+                         "the columns (warm_stride = nij1)")
+    ap.add_argument("--warm-run", type=int, default=0, help="run length (letkf_das_args.warm_run; 0 = library default)")
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -184,6 +188,8 @@ def main():
     status = torch.zeros(npts, dtype=torch.int32, device=dev)
     nsweep = torch.zeros(npts, dtype=torch.int32, device=dev)
     relax = dict(rtps=dict(relax_alpha_spread=0.95), rtpp=dict(relax_alpha=0.7), none=dict())[args.relax]
+    nij1 = w["cfg"]["nx"] * w["cfg"]["ny"]                    # points are p = ij + nij1 * lev (gues3d's order)
+    warm = dict(warm_run=args.warm_run, warm_stride=nij1 if (args.warm_runs == "z" and npts % nij1 == 0) else 0)
 
     # N>1: each rank owns a ragged 1/N shard of the rows of its obs table; every step starts with the path's one
     # exchange, the ALLGATHERV of those shards over RCCL (scale-letkf_amd/sharding.py, covered by the gloo test)
@@ -227,10 +233,10 @@ def main():
             w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"] = do_search()
         if args.lists == "fused":
             ctx.das_points(k, nv, None, None, None, None, ens, w["kld"], w["dep"], infl, w["gues"], anal, w["sp"],
-                           w["sm"], w["sv"], status=status, nsweep=nsweep, fused=(t_s, *pts_s), **relax)
+                           w["sm"], w["sv"], status=status, nsweep=nsweep, fused=(t_s, *pts_s), **warm, **relax)
         else:
             ctx.das_points(k, nv, w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"], ens, w["kld"], w["dep"], infl,
-                           w["gues"], anal, w["sp"], w["sm"], w["sv"], status=status, nsweep=nsweep, **relax)
+                           w["gues"], anal, w["sp"], w["sm"], w["sv"], status=status, nsweep=nsweep, **warm, **relax)
 
     def barrier():
         if world > 1:

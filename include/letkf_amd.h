@@ -137,7 +137,12 @@ typedef struct {
   int32_t relax_to_inflated_prior; /* RELAX_TO_INFLATED_PRIOR */
   int32_t iv_p;              /* 0-based index of pressure (iv3d_p) for Q_UPDATE_TOP */
   int32_t iv_q_first, iv_q_last;   /* 0-based inclusive iv3d_q .. iv3d_qg */
-  int32_t reserved0;
+  int32_t warm_stride;       /* 0 / 1: a warm-start run (warm_run below) walks CONSECUTIVE points; S > 1: points p, p + S,
+                                p + 2 S, ... (npts must be a multiple of S).  With gues3d's point order p = ij + nij1 * lev,
+                                S = nij1 makes the runs go up a column -- vertical neighbours, whose local observations
+                                are the same rows with slowly changing weights: a better starting point than the
+                                horizontal neighbour (C2: off-diagonal norm of Q'AQ 0.013 against 0.023).  Same results
+                                to rounding either way.  (This field was reserved0 = 0 up to ABI 4.) */
   double relax_alpha;        /* RELAX_ALPHA (RTPP), 0 = off */
   double relax_alpha_spread; /* RELAX_ALPHA_SPREAD (RTPS), 0 = off; RTPP wins when both set (:457) */
   double q_update_top;       /* Q_UPDATE_TOP, <= 0 = off */

@@ -45,7 +45,7 @@ class CoreBatchArgs(C.Structure):
 class DasArgs(C.Structure):
     _fields_ = [("k", C.c_int32), ("nv", C.c_int32), ("det_run", C.c_int32), ("infl_adaptive", C.c_int32),
                 ("relax_to_inflated_prior", C.c_int32), ("iv_p", C.c_int32), ("iv_q_first", C.c_int32),
-                ("iv_q_last", C.c_int32), ("reserved0", C.c_int32),
+                ("iv_q_last", C.c_int32), ("warm_stride", C.c_int32),
                 ("relax_alpha", C.c_double), ("relax_alpha_spread", C.c_double), ("q_update_top", C.c_double),
                 ("q_sprd_max", C.c_double), ("npts", C.c_int64), ("obs_off", C.c_void_p), ("obs_idx", C.c_void_p),
                 ("rdiag_l", C.c_void_p), ("rloc_l", C.c_void_p), ("ensval", C.c_void_p), ("kld", C.c_int64),
@@ -228,7 +228,7 @@ class Context:
                    beta=None, det_run=False, infl_adaptive=False, relax_to_inflated_prior=False, relax_alpha=0.0,
                    relax_alpha_spread=0.0, q_update_top=0.0, q_sprd_max=0.0, iv_p=4, iv_q_first=5, iv_q_last=10,
                    trans_out=None, transm_out=None, pa_out=None, status=None, nsweep=None, rtps_infl_out=None,
-                   warm_run=0, var_mask=0, fused=None, nobs_out=None):
+                   warm_run=0, var_mask=0, fused=None, nobs_out=None, warm_stride=0):
         """fused = (tables, ri, rj, rlev, rz): obs_local fused into the kernel (obs_off .. rloc_l may be None)"""
         a = DasArgs()
         a.k, a.nv, a.det_run, a.infl_adaptive = k, nv, int(bool(det_run)), int(bool(infl_adaptive))
@@ -244,6 +244,7 @@ class Context:
         a.status, a.nsweep = _ptr(status), _ptr(nsweep)
         a.rtps_infl_out = _ptr(rtps_infl_out)
         a.warm_run = int(warm_run)
+        a.warm_stride = int(warm_stride)
         a.var_mask = int(var_mask)
         if fused is None:
             self._check(self._l.letkf_das_points_dev(self._c, C.byref(a)))

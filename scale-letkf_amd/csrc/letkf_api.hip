@@ -169,7 +169,7 @@ struct EventPair {   // timing events that do not outlive a failed launch
 
 int launch_staged(letkf_ctx* c, letkf::PointArgs& a);
 
-int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
+int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, long warm_stride = 1) {
   a.ldg = p.ldg;
   a.ldy = p.ldy;
   a.tn = p.tn;
@@ -195,7 +195,9 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0) {
     int run_req = warm_run;
     if (const char* e = LETKF_KNOB("LETKF_AMD_RUN_LEN")) run_req = std::atoi(e);   // PROF knob: 1 = all cold
     size_t wbytes = 0;
-    letkf::wave_launch_shape(a.k, a.mode, a.npts, c->num_cu, run_req, &a.run_len, &a.wave_grid, &wbytes);
+    a.warm_stride = warm_stride > 1 ? warm_stride : 1;
+    if (a.npts % a.warm_stride != 0) return fail(LETKF_E_INVALID, "warm_stride does not divide npts");
+    letkf::wave_launch_shape(a.k, a.mode, a.npts, c->num_cu, run_req, a.warm_stride, &a.run_len, &a.wave_grid, &wbytes);
     if (wbytes > c->warm_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));   // old buffer may still be in use
     if (int rc = ensure_bytes(c, &c->warm_ws, &c->warm_ws_bytes, wbytes)) return rc;
     a.warm_ws = reinterpret_cast<double*>(c->warm_ws);
@@ -547,7 +549,7 @@ int das_points_impl(letkf_ctx* c, const letkf_das_args* g, const letkf_search_ta
     a.prz = rz;
     a.nobs_out = nobs_out;
   }
-  return launch(c, a, p, g->warm_run < 0 ? 0 : g->warm_run);
+  return launch(c, a, p, g->warm_run < 0 ? 0 : g->warm_run, g->warm_stride);
 }
 
 }  // namespace

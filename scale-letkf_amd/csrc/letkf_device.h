@@ -63,6 +63,7 @@ struct PointArgs {
   // wave kernel: launch shape and warm-start workspace (wave_launch_shape)
   double* warm_ws;
   int run_len, wave_grid, warm_dbg;
+  long warm_stride;           // >= 1: a run walks points p, p + warm_stride, ... (letkf_das_args.warm_stride)
   unsigned long long* prof;   // profiling build (-DLETKF_WAVE_PROF) only: per-phase s_memtime totals, else null
 };
 
@@ -131,7 +132,8 @@ hipError_t launch_search_columns_limited(const letkf_search_tables& t, long nij1
 hipError_t launch_point_kernel(const PointArgs& a, const LaunchPlan& p, hipStream_t st);
 bool wave_kernel_supports(int k, int nv, int mode);
 int wave_kernel_kr(int k);   // rows of the instantiation that serves k
-void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, int* run_len, int* grid, size_t* ws_bytes);
+void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, long stride, int* run_len, int* grid,
+                       size_t* ws_bytes);
 hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st);
 hipError_t launch_obs_departure(const letkf_qc_params& p, long nobs, const int* elm, const double* dat, const double* err,
                                 double* ensval, long kld, double* val, int* qc, int num_cu, hipStream_t st);

@@ -470,17 +470,22 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
   constexpr bool WARM = true;
   constexpr int PPW = (NW == 1) ? 4 : 1;      // points in flight per workgroup
   const int run_len = WARM ? A.run_len : 1;
-  const long per_wg = (long)PPW * run_len;
-  const long nB = (A.npts + per_wg - 1) / per_wg;
+  // the points as an array [nA][S], p = a S + b: a run walks a at fixed b (S = 1: consecutive points; S = nij1 with
+  // gues3d's point order: up a column), run number = chunk * S + b -- neighbouring runs are neighbouring columns
+  const long S = A.warm_stride, nA = A.npts / S;
+  const long nruns = S * ((nA + run_len - 1) / run_len);
+  const long nB = (nruns + PPW - 1) / PPW;
   // this wave's slot of the warm-start workspace: [KR][NL] doubles, lane-fastest
   double* uws = (WARM && run_len > 1) ? A.warm_ws + ((size_t)blockIdx.x * PPW + wv) * ((size_t)KR * NL) + lane : nullptr;
   PROF_DECL
   for (long B = blockIdx.x; B < nB; B += gridDim.x) {
-   const long run0 = xcd_remap_w(B, nB) * per_wg + (long)wv * run_len;
+   const long rid = xcd_remap_w(B, nB) * PPW + wv;
+   const long rchunk = rid / S, rb = rid - rchunk * S;
+   const long ra0 = (rid < nruns) ? rchunk * run_len : nA;
    bool have_u = false;
    for (int ir = 0; ir < run_len; ++ir) {
-    const long pt = run0 + ir;
-    if (pt >= A.npts) break;
+    if (ra0 + ir >= nA) break;
+    const long pt = (ra0 + ir) * S + rb;
     // Everything built from the lane number is the same for every point of the run, so hipcc hoists it out of this
     // loop -- dozens of LDS addresses -- cannot keep it in registers across the eigensolve, and reloads it from scratch
     // one dword at a time, each reload a round trip in front of its use.  Laundering the lane numbers keeps the address
@@ -1424,7 +1429,8 @@ int wave_kernel_kr(int k) {
 // Launch shape of the wave kernel: run length of the warm-started runs, grid, and the bytes of warm-start workspace
 // (one [KR][64] slot per resident-or-not wave of the grid).  run_req: 0 = library default, 1 = every point cold,
 // n > 1 = runs of n points.
-void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, int* run_len, int* grid, size_t* ws_bytes) {
+void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, long stride, int* run_len, int* grid,
+                       size_t* ws_bytes) {
   const bool one_wave = k <= 62;
   const long ppw = one_wave ? 4 : 1;           // points in flight per workgroup
   int R = 1;
@@ -1437,8 +1443,14 @@ void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, int*
     }
     if (R > 4096) R = 4096;
   }
-  const long per_wg = ppw * R;
-  const long nwg = (npts + per_wg - 1) / per_wg;
+  if (stride < 1) stride = 1;
+  const long nA = npts / stride;
+  // strided runs (up a column): the whole column in one run by default -- one cold start per column, and the wave stays
+  // with one set of observation rows (C2, 60 levels: 401 ms against 426 ms for runs of 30 and 457 ms for runs of 16
+  // along ij)
+  if (mode != 1 && run_req <= 0 && stride > 1) R = (int)(nA < 128 ? nA : 128);
+  if (R > nA) R = (int)(nA > 0 ? nA : 1);      // (a run does not leave its column)
+  const long nwg = (stride * ((nA + R - 1) / R) + ppw - 1) / ppw;
   long g = (long)num_cu * 16;   // 8x oversubscribed: the static block stride balances better (measured 573 ms at 2x, 541 at 16x)
 #ifdef LETKF_WAVE_PROF
   if (const char* e = std::getenv("LETKF_AMD_WAVE_GRID")) g = (long)num_cu * std::atoi(e);   // PROF twin only

@@ -64,7 +64,7 @@ PROGRAM das_driver
                                           INT(npts, c_int64_t), INT(npts, c_int64_t)*nens), 'to_perturbations')
 
   a%k = k; a%nv = nv; a%det_run = det_run; a%infl_adaptive = 0; a%relax_to_inflated_prior = 0
-  a%iv_p = 4; a%iv_q_first = 5; a%iv_q_last = MIN(10, nv - 1); a%reserved0 = 0
+  a%iv_p = 4; a%iv_q_first = 5; a%iv_q_last = MIN(10, nv - 1); a%warm_stride = 0
   a%relax_alpha = 0.0d0; a%relax_alpha_spread = 0.0d0
   IF (relax == 1) a%relax_alpha = alpha
   IF (relax == 2) a%relax_alpha_spread = alpha

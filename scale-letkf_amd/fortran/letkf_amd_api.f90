@@ -12,7 +12,7 @@ MODULE letkf_amd_api
   INTEGER(c_int), PARAMETER :: hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2
 
   TYPE, BIND(C) :: letkf_das_args
-    INTEGER(c_int32_t) :: k, nv, det_run, infl_adaptive, relax_to_inflated_prior, iv_p, iv_q_first, iv_q_last, reserved0
+    INTEGER(c_int32_t) :: k, nv, det_run, infl_adaptive, relax_to_inflated_prior, iv_p, iv_q_first, iv_q_last, warm_stride
     REAL(c_double)     :: relax_alpha, relax_alpha_spread, q_update_top, q_sprd_max
     INTEGER(c_int64_t) :: npts
     TYPE(c_ptr)        :: obs_off, obs_idx, rdiag_l, rloc_l, ensval

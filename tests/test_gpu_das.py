@@ -21,7 +21,7 @@ CONFIGS = {
 }
 
 
-def run_both(k, nv, npts, nobs_tot, n_mean, seed, cfg, want_trans=False, warm_run=0):
+def run_both(k, nv, npts, nobs_tot, n_mean, seed, cfg, want_trans=False, warm_run=0, warm_stride=0):
     from _gpu import ctx, dev
     det = bool(cfg.get("det_run", 0))
     c = das_case(k=k, nv=nv, npts=npts, nobs_tot=nobs_tot, n_mean=n_mean, seed=seed, det_run=det, infl0=1.07)
@@ -47,7 +47,7 @@ def run_both(k, nv, npts, nobs_tot, n_mean, seed, cfg, want_trans=False, warm_ru
                      relax_alpha=cfg.get("relax_alpha", 0.0), relax_alpha_spread=cfg.get("relax_alpha_spread", 0.0),
                      q_update_top=cfg.get("q_update_top", 0.0), q_sprd_max=cfg.get("q_sprd_max", 0.0),
                      iv_p=4, iv_q_first=5, iv_q_last=min(10, nv - 1), trans_out=trans, transm_out=transm,
-                     status=status, warm_run=warm_run)
+                     status=status, warm_run=warm_run, warm_stride=warm_stride)
     torch.cuda.synchronize()
     return c, ref, anal.cpu().numpy(), infl.cpu().numpy(), status.cpu().numpy(), trans, transm
 
@@ -160,6 +160,31 @@ def test_das_points_warm_started_runs(name, k, warm_run):
         if c["beta"][p] == 0.0:
             continue
         assert np.abs(t[p] - ref["trans"][p]).max() <= 1e-11 * np.abs(ref["trans"][p]).max(), p
+
+
+@pytest.mark.parametrize("name", ["rtps_adaptive_det", "rtpp"])
+@pytest.mark.parametrize("k,warm_run,stride", [(50, 0, 7), (50, 4, 6), (20, 3, 14), (33, 0, 42), (62, 2, 21), (100, 0, 6), (64, 5, 3),
+                                               (50, 7, 1)])
+def test_das_points_strided_warm_runs(name, k, warm_run, stride):
+    """letkf_das_args.warm_stride: the runs walk points p, p + S, ... (up a column when S = nij1) -- every point solved
+    exactly once, same parity bar, whatever the run length (0 = whole column; lengths that do not divide the column)."""
+    cfg = CONFIGS[name]
+    npts = 42
+    c, ref, got, infl, status, trans, transm = run_both(k, 11, npts, 600, 120, seed=300 + k + stride, cfg=cfg,
+                                                        want_trans=True, warm_run=warm_run, warm_stride=stride)
+    assert (status == 0).all()
+    compare_anal(c, ref, got, k, 11, bool(cfg.get("det_run", 0)))
+    assert np.abs(infl - ref["infl"]).max() <= 1e-12
+    t = trans.cpu().numpy()
+    for p in range(npts):
+        if c["beta"][p] == 0.0:
+            continue
+        assert np.abs(t[p] - ref["trans"][p]).max() <= 1e-11 * np.abs(ref["trans"][p]).max(), p
+
+
+def test_warm_stride_must_divide_npts():
+    with pytest.raises(RuntimeError, match="warm_stride"):
+        run_both(50, 11, 42, 600, 120, seed=1, cfg=CONFIGS["rtpp"], warm_stride=5)
 
 
 def test_warm_start_cuts_sweeps_on_neighbouring_points():
