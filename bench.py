@@ -31,9 +31,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--warm-runs", choices=["x", "z"], default="z",
+    ap.add_argument("--warm-runs", choices=["auto", "x", "z"], default="auto",
                     help="direction of the eigensolver's warm-start runs: along ij (letkf_das_args.warm_stride = 0) or up "
-                         "the columns (warm_stride = nij1)")
+                         "the columns (warm_stride = nij1); auto = whichever neighbour is closer in localisation "
+                         "scales (mean level spacing / vertical scale against dx / horizontal scale)")
     ap.add_argument("--warm-run", type=int, default=0, help="run length (letkf_das_args.warm_run; 0 = library default)")
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -189,7 +190,12 @@ def main():
     nsweep = torch.zeros(npts, dtype=torch.int32, device=dev)
     relax = dict(rtps=dict(relax_alpha_spread=0.95), rtpp=dict(relax_alpha=0.7), none=dict())[args.relax]
     nij1 = w["cfg"]["nx"] * w["cfg"]["ny"]                    # points are p = ij + nij1 * lev (gues3d's order)
-    warm = dict(warm_run=args.warm_run, warm_stride=nij1 if (args.warm_runs == "z" and npts % nij1 == 0) else 0)
+    zdir = args.warm_runs == "z"
+    if args.warm_runs == "auto":
+        c_ = w["cfg"]
+        zl = bw.level_heights(c_["nz"], c_["ztop"])
+        zdir = c_["nz"] > 1 and float(np.mean(np.diff(zl))) / c_["vloc"] < c_["dx"] / c_["hloc"]
+    warm = dict(warm_run=args.warm_run, warm_stride=nij1 if (zdir and npts % nij1 == 0) else 0)
 
     # N>1: each rank owns a ragged 1/N shard of the rows of its obs table; every step starts with the path's one
     # exchange, the ALLGATHERV of those shards over RCCL (scale-letkf_amd/sharding.py, covered by the gloo test)
@@ -321,6 +327,7 @@ def main():
                                       + (f", MAX_NOBS_PER_GRID={args.max_nobs} x 2 ctypes" if args.max_nobs else ""),
                           "points_per_gpu": npts, "obs_table_rows": int(w["ensval"].shape[0]),
                           "parallelism": f"grid-point shard x{n_gpus}" + ((" + RCCL obs all-gather (" + args.exchange + ")") if world > 1 else "")},
+               "warm_runs": ("columns (warm_stride = nij1)" if warm["warm_stride"] else "along ij"),
                "analysis_wall_s": elapsed / args.steps, "cycle_ms": elapsed / args.steps * 1e3,
                "solve_only_solves_per_s": (npts * world / kern_s) if kern_s > 0 else None,
                "nonzero_status_points": bad,

@@ -28,6 +28,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "letkf_device.h"
 #include "letkf_jacobi_dev.h"
@@ -104,6 +105,16 @@ __device__ __forceinline__ void axpby_inplace(double& x, const double f, const d
       : "v"(f), "v"(g), "v"(y));
 }
 
+#ifdef LETKF_WAVE_PROF
+__device__ unsigned long long g_eig_prof[8];
+#define EP_DECL() unsigned long long epa[4] = {0, 0, 0, 0}; unsigned long long ept0 = __builtin_readcyclecounter()
+#define EP_SYNC(i) do { const unsigned long long t0_ = __builtin_readcyclecounter(); __syncthreads(); epa[i] += __builtin_readcyclecounter() - t0_; } while (0)
+#define EP_FLUSH() do { if (lane == 0) { for (int i = 0; i < 4; ++i) atomicAdd(&g_eig_prof[i], epa[i]); atomicAdd(&g_eig_prof[4], __builtin_readcyclecounter() - ept0); } } while (0)
+#else
+#define EP_DECL() do {} while (0)
+#define EP_SYNC(i) __syncthreads()
+#define EP_FLUSH() do {} while (0)
+#endif
 constexpr int kPF = EIG_PF;   // LDS rows in flight ahead of their use
 constexpr int kPM = EIG_PM;   // mailbox rows in flight
 
@@ -147,6 +158,7 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
   const bool bndL = SB == 2 && sb == 1 && lane == 0;    // slot 64
   const int row0 = part * RP;
 
+  EP_DECL();
   for (long it = blockIdx.x; it < E.npts; it += gridDim.x) {
     const long pt = E.pt0 + it;
     const int m = E.meta[2 * it + 1];
@@ -207,7 +219,7 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
       for (int t = 0; t < ncol && !done; t += 2) {
         // ================= even step: the slot's own two columns.  Their inner product was accumulated while the
         // previous odd step (or the norm refresh) had both columns in its hands: no pass of its own
-        __syncthreads();                                  // (1)
+        EP_SYNC(0);                                       // (1)
         bool notconv, notconv2;
         {
           const double ga = sum_parts<NP>(pe + slot, NS);
@@ -252,7 +264,7 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
             for (int rr = 0; rr < RP; ++rr)
               bbQ[part * RP + rr] = rr < RBR ? breg[rr < RBR ? rr : 0] : blds[(size_t)(rr - RBR) * NT + tid];
           }
-          __syncthreads();                                // (2)
+          EP_SYNC(1);                                     // (2)
         }
         // ================= odd step: upper column of slot s (Q_s) with the lower column of slot s+1 (P_{s+1}).
         // The row loops below carry no branch, so that hipcc can issue the LDS reads of a fence group together (with a
@@ -304,7 +316,7 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
           const int anyv = (__any(notconv || odd_notconv_prev) ? 1 : 0) | (__any(notconv2 || odd_notconv2_prev) ? 2 : 0);
           if (lane == 0) flags[16 * vph + wave] = anyv;
         }
-        __syncthreads();                                  // (3)
+        EP_SYNC(2);                                       // (3)
         {
           // as the left member of the pair (s, s+1), and again as the right member of (s-1, s)
           const double gR = sum_parts<NP>(po + slot, NS);
@@ -414,6 +426,7 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
     (void)pt;
     __syncthreads();
   }
+  EP_FLUSH();
 }
 
 template <int NP, int RP, int RBR, int SB>
@@ -425,7 +438,17 @@ static hipError_t launch_eig_one(const EigArgs& e, int grid, hipStream_t st) {
                                          (int)lds);
     if (err != hipSuccess) return err;
   }
+#ifdef LETKF_WAVE_PROF
+  unsigned long long z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_eig_prof), z, sizeof z);
+#endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NP * SB), lds, st, e);
+#ifdef LETKF_WAVE_PROF
+  (void)hipStreamSynchronize(st);
+  (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_eig_prof), sizeof z);
+  fprintf(stderr, "EIG_PROF <%d,%d,%d,%d> grid=%d wave-cycles total=%llu barrier1=%.1f%% barrier2=%.1f%% barrier3=%.1f%%\n", NP, RP, RBR, SB,
+          grid, z[4], 100.0 * z[0] / (z[4] + 1.0), 100.0 * z[1] / (z[4] + 1.0), 100.0 * z[2] / (z[4] + 1.0));
+#endif
   return hipGetLastError();
 }
 
@@ -439,6 +462,8 @@ int eig_wg_max_order() { return 208; }
 hipError_t launch_eig_wg(const EigArgs& e, int mcap, int num_cu, hipStream_t st) {
   const int grid = (int)(e.npts < 4L * num_cu ? (e.npts > 0 ? e.npts : 1) : 4L * num_cu);
   if (mcap <= 128) return launch_eig_one<4, 32, 32, 1>(e, grid, st);
+  // (an <8, 26, RBR, 2> shape -- 16 waves, a quarter of the LDS rows per lane -- was tried for this range: 128 VGPRs per
+  // lane do not hold the two columns and the prefetch rings, 130-200 B/lane of scratch, C3-slab 171 ms against 107 ms)
   return launch_eig_one<4, 52, EIG_RBR2, 2>(e, grid, st);
 }
 
