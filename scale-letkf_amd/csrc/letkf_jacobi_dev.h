@@ -133,7 +133,12 @@ __device__ __forceinline__ double slot_sum_nw(double v, double* xs, int& ph) {
 // cross waves (three workgroup barriers per step pair).
 // EARLY = false: only the 1e-10 rule (the block Jacobi of letkf_kernels.hip reads "one cycle" as "this block pair
 // was already diagonal" and must not have rotations of 1e-8 pass for that).
-template <int KR, int NW, int RC = 24, bool EARLY = true>
+// INPLACE = true: two half-column arrays instead of three.  The spare array of the copy-free form below costs KR
+// registers; at KR = 100 on two waves that makes 300 for the columns alone, a third of them in AGPRs, and 548 of the
+// 1283 instructions of a step pair were v_accvgpr moves.  In place the even step needs one move per row (the old lower
+// element is an operand of both new ones) and the odd step fetches the right neighbour's column twice (inner product,
+// then update) instead of keeping it: +2 instructions per row, no AGPR traffic.
+template <int KR, int NW, int RC = 24, bool EARLY = true, bool INPLACE = false>
 __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const int max_sweep, double* lds,
                                             int* pairs_out = nullptr, int* conv_out = nullptr) {
   static_assert(KR % 2 == 0, "row halves");
@@ -146,7 +151,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
   int ph = 0;
   const int ncol = (k + 1) & ~1;               // an odd k gets one zero column as an extra (inert) participant
   const int S = ncol >> 1;                     // slots in use
-  double xa[H], xb[H], xf[H];
+  double xa[H], xb[H], xf[INPLACE ? 1 : H];
   // ---- column-per-lane -> row-split: lds[r][col], r in chunks
 #pragma unroll
   for (int r0 = 0; r0 < KR; r0 += RC) {
@@ -220,6 +225,19 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           scB = nscB;
           // the new A goes to the spare array xf, the new B is accumulated in place in xa[] (every FMA adds into the
           // register its result stays in: no copies)
+          if constexpr (INPLACE) {
+            // A stays in xa[], B in xb[]: xa <- xb + cA xa, xb <- xa_old + cB xb, as one instruction sequence per row
+            // (from C++ hipcc renames the whole column per step)
+#pragma unroll
+            for (int rr = 0; rr < H; ++rr) {
+              double t;
+              asm("v_mov_b64 %2, %0\n\t"
+                  "v_fma_f64 %0, %3, %0, %1\n\t"
+                  "v_fma_f64 %1, %4, %1, %2"
+                  : "+v"(xa[rr]), "+v"(xb[rr]), "=&v"(t)
+                  : "v"(cA), "v"(cB));
+            }
+          } else {
 #pragma unroll
           for (int rr = 0; rr < H; ++rr) {
             // three-address form with an early-clobber destination: left to itself the compiler accumulates into
@@ -228,15 +246,33 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
             asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(xf[rr]) : "v"(cA), "v"(xa[rr]), "v"(xb[rr]));
             xa[rr] = fma(cB, xb[rr], xa[rr]);
           }
+          }
         }
         // ---------------- odd step: own B (now in xa[]) with the right slot's A; own A (in xf[]) with the left slot's B
         {
           double p0 = 0.0, p1 = 0.0;
+          if constexpr (INPLACE) {
+#pragma unroll
+            for (int rr = 0; rr < H; ++rr) {
+              // (register-only fences keep the rows in order: without them hipcc fetches all rows of the neighbour
+              // first -- a third column in registers after all)
+              asm volatile("" : "+v"(xa[rr]));
+              const double pr = dpp_shift0<0x130>(xa[rr]);      // A of the right slot
+              if (rr & 1) {
+                p1 = fma(xb[rr], pr, p1);
+                asm volatile("" : "+v"(p1));
+              } else {
+                p0 = fma(xb[rr], pr, p0);
+                asm volatile("" : "+v"(p0));
+              }
+            }
+          } else {
 #pragma unroll
           for (int rr = 0; rr < H; ++rr) {
             xb[rr] = dpp_shift0<0x130>(xf[rr]);                 // A of the right slot
             if (rr & 1) p1 = fma(xa[rr], xb[rr], p1);
             else p0 = fma(xa[rr], xb[rr], p0);
+          }
           }
           const double alAr = dpp_shift0<0x130>(alA), isAr = dpp_shift0<0x130>(isA), scAr = dpp_shift0<0x130>(scA);
           const double ga = slot_sum_nw<NW>(p0 + p1, lds, ph) * (isB * isAr);
@@ -271,11 +307,26 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           // new B into xb[] (on top of the fetched column); then the old B of the LEFT slot is pulled into xa[] --
           // every lane reads its neighbour's xa[rr] and overwrites its own in the same instruction -- and the new A
           // accumulated on top of it: A is back in xa[], B in xb[], xf[] is spare again
+          if constexpr (INPLACE) {
+            // own B (xb) takes the right slot's A on top: xb <- A_r + coefR xb; own A (xa) the left slot's old B:
+            // xa <- B_l + coefL xa -- both neighbours' elements are read before either own element of the row changes
+#pragma unroll
+            for (int rr = 0; rr < H; ++rr) {
+              asm volatile("" : "+v"(xa[rr]), "+v"(xb[rr]));
+              const double pr = dpp_shift0<0x130>(xa[rr]);
+              const double ql = dpp_shift0<0x138>(xb[rr]);
+              // (three-address forms on the element's own register: hipcc's v_fmac accumulates into the FETCHED value's
+              // register and copies the result back, one v_mov_b64 per element)
+              asm("v_fma_f64 %0, %1, %0, %2" : "+v"(xb[rr]) : "v"(coefR), "v"(pr));
+              asm("v_fma_f64 %0, %1, %0, %2" : "+v"(xa[rr]) : "v"(coefL), "v"(ql));
+            }
+          } else {
 #pragma unroll
           for (int rr = 0; rr < H; ++rr) {
             xb[rr] = fma(coefR, xa[rr], xb[rr]);
             xa[rr] = dpp_shift0<0x138>(xa[rr]);
             xa[rr] = fma(coefL, xf[rr], xa[rr]);
+          }
           }
         }
         ++pairs;

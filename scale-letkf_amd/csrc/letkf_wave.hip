@@ -196,6 +196,9 @@ __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const dou
 // early stop of the eigensolver (letkf_jacobi_dev.h): one-wave points, and two-wave points of the 64-column
 // instantiation (both ballots ride one barrier: k = 64 1.00 M against 0.93 M solves/s).  Not the 80- and 100-column
 // ones: at k = 100 the same change costs 8 % (A/B on one box) -- their register allocation is fragile, see the Gram.
+#ifndef LETKF_INPLACE_NW
+#define LETKF_INPLACE_NW(kr, nw) ((nw) == 2 && (kr) > 64)   // two half-column arrays instead of three (letkf_jacobi_dev.h)
+#endif
 #ifndef LETKF_EARLY_NW
 #define LETKF_EARLY_NW(kr, nw) ((nw) == 1 || (kr) <= 64)
 #endif
@@ -952,7 +955,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wa
         }
       }
       PROF_MARK(3)
-      sweeps = jacobi_split<KR, NW, 24, LETKF_EARLY_NW(KR, NW)>(g, k, A.max_sweep, slice, nullptr, &jconv);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
+      sweeps = jacobi_split<KR, NW, 24, LETKF_EARLY_NW(KR, NW), LETKF_INPLACE_NW(KR, NW)>(g, k, A.max_sweep, slice, nullptr, &jconv);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
       // per-lane values that were spilled around the eigensolve come back HERE, in one batch: reloaded lazily, each
       // scratch load sits behind the 50 workspace stores below and its s_waitcnt vmcnt(0) waits for all of them
       asm volatile("" : "+v"(racc), "+v"(rdacc), "+v"(moff));
