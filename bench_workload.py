@@ -45,6 +45,9 @@ CONFIGS = {
                     ztop=18000.0, seed=20240616, halo=True),
     "C2-slab-k100": dict(nx=48, ny=48, nz=12, k=100, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
                          ztop=18000.0, seed=20240618, halo=True),
+    # C2's geometry (60 levels, its observation lattice) at the production ensemble size, on a 48 x 48 piece of the domain
+    "C2-cols-k100": dict(nx=48, ny=48, nz=60, k=100, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2900.0, err=3.0,
+                         ztop=18000.0, seed=20240619, halo=True),
     "C1": dict(nx=40, ny=40, nz=30, k=20, dx=15000.0, hloc=120000.0, vloc=4000.0, spacing=30000.0, err=3.0,
                ztop=18000.0, seed=20240608),
 }

@@ -199,8 +199,11 @@ __device__ __forceinline__ void rows_times_c(const double (&vcol)[KR], const dou
 #ifndef LETKF_INPLACE_NW
 #define LETKF_INPLACE_NW(kr, nw) ((nw) == 2 && (kr) > 64)   // two half-column arrays instead of three (letkf_jacobi_dev.h)
 #endif
+#ifndef LETKF_TWO_PER_SIMD
+#define LETKF_TWO_PER_SIMD(kr, nw) false   // (tried for the in-place instantiations: 256 registers in all, 2 KB/lane of scratch, k = 100 510 k -> 448 k)
+#endif
 #ifndef LETKF_EARLY_NW
-#define LETKF_EARLY_NW(kr, nw) ((nw) == 1 || (kr) <= 64)
+#define LETKF_EARLY_NW(kr, nw) true
 #endif
 #ifndef LETKF_GRAM_DEPTH
 #define LETKF_GRAM_DEPTH 3
@@ -438,7 +441,7 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
 #endif
 
 template <int KR, int NV, bool KKOUT, int NW, bool FUSED>
-__global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? 2 : 1) letkf_wave_kernel(const PointArgs A) {
+__global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER_SIMD(KR, NW)) ? 2 : 1) letkf_wave_kernel(const PointArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NB = NV + 2;
   constexpr int NBP = (NB + 1) & ~1;
