@@ -58,9 +58,10 @@ def main():
     ap.add_argument("--state-layout", default="ref", choices=["ref", "member"],
                     help="ensemble state in HBM: the reference's gues3d(nij1*nlev, nens, nv3d) (point-fastest) or the "
                          "point-major member-fastest layout the ABI's strides also allow (sm = 1)")
-    ap.add_argument("--exchange", default="torch", choices=["torch", "lib"],
+    ap.add_argument("--exchange", default="torch", choices=["torch", "lib", "halo"],
                     help="N > 1: the obs all-gather through torch.distributed (default) or through the library's own "
-                         "letkf_obs_allgatherv_dev on an RCCL communicator this script creates (ncclCommInitRank)")
+                         "letkf_obs_allgatherv_dev on an RCCL communicator this script creates (ncclCommInitRank); "
+                         "halo (--scaling strong only): pairwise sends of just the rows each extended subdomain holds")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(affinity, cgroup quota, 16 = the box's CPU share)")
     args = ap.parse_args()
 
@@ -133,9 +134,11 @@ def main():
                 "config": {"workload": f"{args.workload}: ONE {bw.CONFIGS[args.workload]['nx']}x{bw.CONFIGS[args.workload]['ny']}x"
                                        f"{bw.CONFIGS[args.workload]['nz']} domain as {r['tiles']}, k={k_}, nv={nv_}, mean "
                                        f"{r['n_mean']:.1f} local obs/point, relax={args.relax}; per step and rank: mesh sort, "
-                                       f"obs all-gather ({args.exchange}), halo plan, obs_local, loop body",
+                                       f"obs exchange ({args.exchange}), halo plan, obs_local, loop body",
                            "points_total": r["npts_total"], "obs_rows_global": r["nobs"],
-                           "obs_rows_per_rank_with_halo": r["halo_rows_mean"], "parallelism": f"tiles x{world}"},
+                           "obs_rows_per_rank_with_halo": r["halo_rows_mean"],
+                           "obs_rows_received_per_rank": r["rows_received_mean"], "parallelism": f"tiles x{world}"},
+                "anal_checksum": r["anal_checksum"],
                 "nonzero_status_points": r["bad"], "jacobi_sweeps_mean": r["sweeps_mean"],
                 "roofline": {"bound": "mfma", "achieved": tfl, "peak": 78.6, "unit": "TFLOP/s",
                              "frac": (tfl / 78.6) if tfl else None, "traffic": None, "kernel": ctx.last_path(),

@@ -122,6 +122,10 @@ def run(args, ctx, pkg, dev, rank, world):
         rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
         assert rccl.ncclCommInitRank(C.byref(ncomm), world, uid, rank) == 0
     keep = {}
+    # warm-start runs up the columns where the vertical neighbour is the closer one (bench.py --warm-runs)
+    zl = bw.level_heights(nz, cfg["ztop"])
+    zdir = args.warm_runs == "z" or (args.warm_runs == "auto" and nz > 1 and float(np.mean(np.diff(zl))) / vloc < dx / hloc)
+    wstride = nij1 if zdir else 0
 
     def step():
         # ---- set_letkf_obs: sort, exchange, extended subdomain
@@ -132,17 +136,45 @@ def run(args, ctx, pkg, dev, rank, world):
             dist.all_gather(cells, n_cell.contiguous())
             n_all = torch.stack(cells).contiguous()
             counts = [int(c.sum().item()) for c in cells]
-            if ncomm is not None:
+            if args.exchange == "halo":
+                bufr = None
+            elif ncomm is not None:
                 bufr = torch.empty(sum(counts), ncols, dtype=f64, device=dev)
                 ctx.obs_allgatherv(ncomm.value, rank, counts, send, bufr)
             else:
                 bufr, _ = sharding.allgatherv_rows(send)
         else:
-            n_all, bufr = n_cell[None].contiguous(), send
-        ac, src = ctx.obs_halo_plan(lay, n_all, nacx, bufr.shape[0])
+            n_all, bufr, counts = n_cell[None].contiguous(), send, [send.shape[0]]
+        ntot = sum(counts)
+        ac, src = ctx.obs_halo_plan(lay, n_all, nacx, ntot)
         nt = src.numel()
         tab = torch.empty(nt, ncols, dtype=f64, device=dev)
-        ctx.obs_gather_rows(src, ncols, bufr, ncols, tab, ncols)
+        if bufr is not None:
+            ctx.obs_gather_rows(src, ncols, bufr, ncols, tab, ncols)
+        else:
+            # halo-only exchange: the cell counts (above) are all a rank needs to know WHICH rows of the virtual gathered
+            # table every extended subdomain holds, its own (src) and everybody else's -- so each rank runs the plan once
+            # per destination, sends its own rows of it in plan order, and files what it receives in its own plan's order
+            offs = np.concatenate([[0], np.cumsum(counts)])
+            blocks = []
+            for d in range(world):
+                if d == rank:
+                    src_d = src
+                else:
+                    lay_d = pkg.HaloLayout()
+                    lay_d.nctype, lay_d.nprocs, lay_d.prc_num_x, lay_d.myrank = 1, world, px, d
+                    lay_d.ngrd_i, lay_d.ngrd_j, lay_d.ngrdsch_i, lay_d.ngrdsch_j = (gi.ctypes.data, gj.ctypes.data,
+                                                                                    si.ctypes.data, sj.ctypes.data)
+                    _, src_d = ctx.obs_halo_plan(lay_d, n_all, nacx, ntot)
+                own = src_d[(src_d >= int(offs[rank])) & (src_d < int(offs[rank + 1]))].long() - int(offs[rank])
+                blocks.append(send[own].contiguous())
+            src_rank = torch.bucketize(src.long(), torch.as_tensor(offs[1:], device=dev), right=True)
+            rc = torch.bincount(src_rank, minlength=world).tolist()
+            got = sharding.exchange_rows(blocks, rc)
+            for q in range(world):
+                if rc[q]:
+                    tab[src_rank == q] = got[q]
+            keep["rows_received"] = int(sum(rc) - rc[rank])
         ens = tab[:, :kld].contiguous()
         dep = tab[:, kld].contiguous()
         t = pkg.SearchTables()
@@ -156,8 +188,10 @@ def run(args, ctx, pkg, dev, rank, world):
         # ---- das_letkf: obs_local for the tile's points, then the loop body
         off, idx, rd, rl = ctx.obs_search_columns(t, nij1, nz, rig, rjg, prl, prz)
         ctx.das_points(k, nv, off, idx, rd, rl, ens, kld, dep, infl, gues, anal, 1, npts, npts * nens, status=status,
-                       nsweep=nsweep, **relax)
+                       nsweep=nsweep, warm_stride=wstride, **relax)
         keep.update(k2=k2, nt=nt, nnz=int(off[-1].item()))
+        if "rows_received" not in keep:
+            keep["rows_received"] = int(ntot - counts[rank]) if world > 1 else 0
 
     def barrier():
         if world > 1:
@@ -175,8 +209,10 @@ def run(args, ctx, pkg, dev, rank, world):
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms, nlaunch = ctx.timing_read(reset=True)
+    csum = float(anal.view(nv, nens, npts)[:, :k].sum().item())          # (slot k, the mean, is not written by the loop)
     stat = torch.tensor([elapsed, float(keep["nnz"]), float(keep["nt"]), float((status != 0).sum().item()),
-                         float(nsweep.double().sum().item()), kern_ms], dtype=f64, device=dev)
+                         float(nsweep.double().sum().item()), kern_ms, float(keep["rows_received"]), csum], dtype=f64,
+                        device=dev)
     mx = stat.clone()
     if world > 1:
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -186,4 +222,5 @@ def run(args, ctx, pkg, dev, rank, world):
     n_mean = float(stat[1].item()) / ntot
     return dict(elapsed=elapsed, npts_total=ntot, n_mean=n_mean, halo_rows_mean=float(stat[2].item()) / world,
                 bad=int(stat[3].item()), sweeps_mean=float(stat[4].item()) / ntot, kern_ms=float(mx[5].item()),
-                nlaunch=nlaunch, k=k, nv=nv, tiles=f"{px}x{py} tiles of {nlon}x{nlat}x{nz}", nobs=nobs)
+                nlaunch=nlaunch, k=k, nv=nv, tiles=f"{px}x{py} tiles of {nlon}x{nlat}x{nz}", nobs=nobs,
+                rows_received_mean=float(stat[6].item()) / world, anal_checksum=float(stat[7].item()))

@@ -65,3 +65,28 @@ def halo_rows(ri, rj, tile, halo_i, halo_j):
     i0, i1, j0, j1 = tile
     ok = (ri >= i0 - halo_i) & (ri < i1 + halo_i) & (rj >= j0 - halo_j) & (rj < j1 + halo_j)
     return ok.nonzero(as_tuple=False).squeeze(1)
+
+
+def exchange_rows(send_blocks, recv_counts, group=None):
+    """Pairwise exchange of row blocks: rank r hands send_blocks[q] to rank q and receives recv_counts[q] rows from it
+    (its own block is copied).  The halo-only alternative to the ALLGATHERV above: every rank gets just the rows of its
+    extended subdomain, from the ranks that own them -- on a fully connected xGMI node the pairs use different links at
+    the same time.  One batch of point-to-point operations (ncclSend / ncclRecv grouped by torch on the GPU box)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    proto = send_blocks[rank]
+    tail = tuple(proto.shape[1:])
+    recv = [proto.new_empty((int(recv_counts[q]),) + tail) for q in range(world)]
+    ops = []
+    for q in range(world):
+        if q == rank:
+            recv[q].copy_(send_blocks[q])
+            continue
+        if send_blocks[q].shape[0] > 0:
+            ops.append(dist.P2POp(dist.isend, send_blocks[q].contiguous(), q, group))
+        if recv[q].shape[0] > 0:
+            ops.append(dist.P2POp(dist.irecv, recv[q], q, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return recv

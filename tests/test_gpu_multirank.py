@@ -41,3 +41,15 @@ def test_weak_scaling_two_ranks():
     d = run_bench("--gpus", "2")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["nonzero_status_points"] == 0
     assert d["value"] > 0 and "all-gather" in d["config"]["parallelism"]
+
+
+def test_halo_only_exchange_gives_the_all_gather_analysis():
+    """--exchange halo: every rank receives only the rows of its extended subdomain (pairwise sends, sharding.exchange_rows)
+    and must end up with the very table -- hence the very analysis -- the ALLGATHERV + halo plan gives."""
+    for n in (2, 4):
+        a = run_bench("--gpus", str(n), "--scaling", "strong")
+        h = run_bench("--gpus", str(n), "--scaling", "strong", "--exchange", "halo")
+        assert h["nonzero_status_points"] == 0
+        assert h["config"]["obs_rows_per_rank_with_halo"] == a["config"]["obs_rows_per_rank_with_halo"]
+        assert h["config"]["obs_rows_received_per_rank"] < a["config"]["obs_rows_received_per_rank"]
+        assert abs(h["anal_checksum"] - a["anal_checksum"]) <= 1e-12 * abs(a["anal_checksum"]), (h["anal_checksum"], a["anal_checksum"])

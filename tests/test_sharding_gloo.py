@@ -59,6 +59,13 @@ def _worker(rank, world, port, q):
         rj = torch.tensor([1.0, 1.0, 6.0, 6.5])
         keep = sh.halo_rows(ri, rj, tiles[rank], 0.5, 0.5)
         ok = ok and keep.numel() >= 1
+        # pairwise exchange of ragged blocks (the halo-only alternative): rank r sends 2 + r + 3q rows to rank q, none to
+        # itself when r == 1; every received row must be the sender's
+        def block(src, dst):
+            n = 0 if (src == dst == 1) else 2 + src + 3 * dst
+            return (torch.arange(n * 4, dtype=torch.float64).reshape(n, 4) + 1000.0 * src + 100.0 * dst)
+        got = sh.exchange_rows([block(rank, d) for d in range(world)], [block(s, rank).shape[0] for s in range(world)])
+        ok = ok and all(torch.equal(got[s], block(s, rank)) for s in range(world))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
