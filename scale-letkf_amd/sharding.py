@@ -90,3 +90,49 @@ def exchange_rows(send_blocks, recv_counts, group=None):
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return recv
+
+
+def nij1_of(nlon, nlat, rank, world):
+    """points of a subdomain dealt to ensemble-rank `rank` (grd_to_buf: point ij goes to rank ij mod world)."""
+    return (nlon * nlat - rank + world - 1) // world
+
+
+def scatter_members_alltoall(ctx, nlev, nlon, nlat, nv3d, mstart, mcount, v3dg, x, nens, group=None):
+    """scatter_grd_mpi_alltoall (scale/common/common_mpi_scale.f90:1279-1335): ranks 0 .. mcount-1 each hold ONE member's
+    field v3dg(nlev,nlon,nlat,nv3d) (member mstart + rank; v3dg may be None on the others); afterwards every rank has,
+    for ITS share of the grid points, the members mstart .. mstart+mcount-1 in slots of x = gues3d(nij1,nlev,nens,nv3d).
+    The dealing of points into per-destination blocks and the filing into the member slot are the library's
+    letkf_member_points_dev (the reference's grd_to_buf and its copy loop); the exchange is one batch of pairwise sends
+    (MPI_ALLTOALL(V) of nij1max x nlevall blocks there; true counts here)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nij1 = nij1_of(nlon, nlat, rank, world)
+    dev = x.device
+    blocks = []
+    for d in range(world):
+        nd = nij1_of(nlon, nlat, d, world)
+        if rank < mcount:
+            b = torch.empty(nv3d * nlev * nd, dtype=x.dtype, device=dev)
+            ctx.member_points(0, nlev, nlon, nlat, nv3d, world, d, 0, v3dg, b, nd, 1, 0, nd * nlev)
+        else:
+            b = torch.empty(0, dtype=x.dtype, device=dev)
+        blocks.append(b)
+    rc = [nv3d * nlev * nij1 if s < mcount else 0 for s in range(world)]
+    got = exchange_rows(blocks, rc, group)
+    xv = x.view(nv3d, nens, nlev * nij1)
+    for s in range(mcount):
+        xv[:, mstart + s, :] = got[s].view(nv3d, nlev * nij1)
+
+
+def gather_members_alltoall(ctx, nlev, nlon, nlat, nv3d, mstart, mcount, x, nens, v3dg, group=None):
+    """gather_grd_mpi_alltoall (:1340-1396), the way back: member mstart + r of every rank's x goes to rank r, which
+    assembles the whole field v3dg (ranks >= mcount receive nothing)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nij1 = nij1_of(nlon, nlat, rank, world)
+    xv = x.view(nv3d, nens, nlev * nij1)
+    blocks = [(xv[:, mstart + d, :].contiguous().view(-1) if d < mcount else x.new_empty(0)) for d in range(world)]
+    rc = [nv3d * nlev * nij1_of(nlon, nlat, s, world) if rank < mcount else 0 for s in range(world)]
+    got = exchange_rows(blocks, rc, group)
+    if rank < mcount:
+        for s in range(world):
+            ns = nij1_of(nlon, nlat, s, world)
+            ctx.member_points(1, nlev, nlon, nlat, nv3d, world, s, 0, v3dg, got[s], ns, 1, 0, ns * nlev)
