@@ -106,8 +106,9 @@ int letkf_core_batch_dev(letkf_ctx *ctx, const letkf_core_batch_args *args);
 
 /*---------------------------------------------------------------------------
  * (2) Coarse boundary: the das_letkf main loop body for a batch of grid points,
- *     scale/letkf/letkf_tools.f90:313-527 (single variable-localisation class,
- *     nv2d = 0: the namelist defaults).  For every point:
+ *     scale/letkf/letkf_tools.f90:313-527 (one variable-localisation class per
+ *     call, see var_mask; 2-D variables, :530-659, are further variables of a
+ *     level-1 call -- INTEGRATION.md "2-D variables").  For every point:
  *     local-obs gather by index -> letkf_core -> RTPP/RTPS relaxation (:457-469)
  *     -> total weight with beta (:472-477) -> analysis of the k members and of
  *     the deterministic member (:480-497) -> q-spread clamp (:500-513).

@@ -749,6 +749,133 @@ int orc_das_letkf_points_diag(const orc_das_params *p, int64_t npts, const int64
   return worst;
 }
 
+/* The loop body at ilev = 1 WITH 2-D variables, scale/letkf/letkf_tools.f90:313-686, all variable-localisation
+ * classes of a point in one pass as the reference has it: the 3-D loop (:366-527) and the 2-D loop (:530-659) share
+ * trans_done(:) / trans(:,:,n2nc) / transm / transmd / pa, so a 2-D variable whose class was already solved for a 3-D
+ * variable re-uses those weights and copies its adaptive inflation from work3d(ij,ilev,n2n) (:549-554), otherwise from
+ * work2d(ij,n2n-nv3d) (:555-562) or it solves for itself with work2d(ij,n) (:566-601).  The 2-D variables know no
+ * Q_UPDATE_TOP skip and no spread clamp.  (The reference is compiled with nv2d = 0, scale/common/common_scale.f90:54.)
+ * Inputs: n2nc / n2n [nv3d + nv2d] = var_local_n2nc / var_local_n2n, 1-based as in the reference; the local lists of
+ * class c (what obs_local returns for a variable of that class) are the CSR slice obs_off[c*(nij1+1) + ij] ..
+ * [.. + ij + 1] of obs_idx / rdiag_l / rloc_l; work3d [nij1*nv3d] is the ilev = 1 slice, work2d [nij1*nv2d];
+ * gues3 / anal3 element (ij, m, n) at ij*sp3 + m*sm3 + n*sv3 (again the ilev = 1 slice), gues2 / anal2 likewise. */
+int orc_das_letkf_level1_2d(const orc_das_params *p, int nv2d, const int32_t *n2nc, const int32_t *n2n, int nclass,
+                            int64_t nij1, const int64_t *obs_off, const int32_t *obs_idx, const double *rdiag_l,
+                            const double *rloc_l, const double *ensval, int64_t kld, const double *dep,
+                            const double *beta_a, double *work3d, double *work2d, const double *gues3, double *anal3,
+                            int64_t sp3, int64_t sm3, int64_t sv3, const double *gues2, double *anal2, int64_t sp2,
+                            int64_t sm2, int64_t sv2) {
+  const int k = p->k, nv3d = p->nv;
+  const size_t kk = (size_t)k * (size_t)k;
+  int64_t nmax = 1;
+  for (int c = 0; c < nclass; ++c)
+    for (int64_t ij = 0; ij < nij1; ++ij) {
+      const int64_t n = obs_off[(int64_t)c * (nij1 + 1) + ij + 1] - obs_off[(int64_t)c * (nij1 + 1) + ij];
+      if (n > nmax) nmax = n;
+    }
+  double *hdxf = (double *)malloc(sizeof(double) * (size_t)nmax * (size_t)k);
+  double *rd = (double *)malloc(sizeof(double) * (size_t)nmax * 4);
+  double *rl = rd + nmax, *dp = rl + nmax, *dpd = dp + nmax;
+  double *trans = (double *)malloc(sizeof(double) * ((2 * kk + 2 * (size_t)k) * (size_t)nclass + kk));   /* :297-302 */
+  double *pa = trans + kk * nclass, *transm = pa + kk * nclass, *transmd = transm + (size_t)k * nclass;
+  double *wrlx = transmd + (size_t)k * nclass;
+  int *trans_done = (int *)malloc(sizeof(int) * (size_t)nclass);
+  int worst = 0;
+  for (int64_t ij = 0; ij < nij1; ++ij) {
+    for (int c = 0; c < nclass; ++c) trans_done[c] = 0;                  /* :321 */
+    const double beta = beta_a ? beta_a[ij] : 1.0;                       /* :325 */
+    const double *g3 = gues3 + ij * sp3, *g2 = gues2 + ij * sp2;
+    double *a3 = anal3 + ij * sp3, *a2 = anal2 + ij * sp2;
+    if (beta == 0.0) {                                                   /* :333-359 */
+      for (int n = 0; n < nv3d; ++n) {
+        for (int m = 0; m < k; ++m) a3[m * sm3 + n * sv3] = g3[k * sm3 + n * sv3] + g3[m * sm3 + n * sv3];
+        if (p->det_run) a3[(k + 1) * sm3 + n * sv3] = g3[(k + 1) * sm3 + n * sv3];
+      }
+      for (int n = 0; n < nv2d; ++n) {
+        for (int m = 0; m < k; ++m) a2[m * sm2 + n * sv2] = g2[k * sm2 + n * sv2] + g2[m * sm2 + n * sv2];
+        if (p->det_run) a2[(k + 1) * sm2 + n * sv2] = g2[(k + 1) * sm2 + n * sv2];
+      }
+      continue;
+    }
+    for (int nn = 0; nn < nv3d + nv2d; ++nn) {                           /* :366 DO n=1,nv3d ; :532 DO n=1,nv2d */
+      const int is2d = nn >= nv3d, n = is2d ? nn - nv3d : nn;
+      const int cls = n2nc[nn] - 1, rep = n2n[nn] - 1;                   /* :368-369, :534-535 */
+      const double *g = is2d ? g2 : g3;
+      double *a = is2d ? a2 : a3;
+      const int64_t sm = is2d ? sm2 : sm3, sv = is2d ? sv2 : sv3;
+      double *work = is2d ? work2d + ij + nij1 * n : work3d + ij + nij1 * n;
+      if (!is2d && p->q_update_top > 0.0 && g3[k * sm3 + p->iv_p * sv3] < p->q_update_top && n >= p->iv_q_first &&
+          n <= p->iv_q_last) {                                           /* :371-385 */
+        for (int m = 0; m < k; ++m) a[m * sm + n * sv] = g[k * sm + n * sv] + g[m * sm + n * sv];
+        if (p->det_run) a[(k + 1) * sm + n * sv] = g[(k + 1) * sm + n * sv];
+        continue;
+      }
+      const double parm = p->relax_to_inflated_prior ? *work : 1.0;      /* :387-391, :537-541 */
+      double *tr = trans + kk * cls, *tm = transm + (size_t)k * cls, *tmd = transmd + (size_t)k * cls, *pc = pa + kk * cls;
+      if (trans_done[cls]) {                                             /* :394-406, :544-568 */
+        if (p->infl_adaptive) *work = (rep < nv3d) ? work3d[ij + nij1 * rep] : work2d[ij + nij1 * (rep - nv3d)];
+      } else {                                                           /* :409-439, :569-607 */
+        const int64_t o = obs_off[(int64_t)cls * (nij1 + 1) + ij];
+        const int nobsl = (int)(obs_off[(int64_t)cls * (nij1 + 1) + ij + 1] - o);
+        for (int i = 0; i < nobsl; ++i) {
+          const double *row = ensval + (int64_t)obs_idx[o + i] * kld;
+          for (int m = 0; m < k; ++m) CM(hdxf, nobsl > 0 ? nobsl : 1, i, m) = row[m];
+          rd[i] = rdiag_l[o + i];
+          rl[i] = rloc_l[o + i];
+          dp[i] = dep[obs_idx[o + i]];
+          if (p->det_run) dpd[i] = row[k];
+        }
+        int one = 1, iu = p->infl_adaptive;
+        const int rc = orc_letkf_core(k, nobsl > 0 ? nobsl : 1, nobsl, hdxf, rd, rl, dp, work, tr, tm,
+                                      (p->relax_alpha_spread != 0.0) ? pc : NULL, &one, &iu,
+                                      p->det_run ? dpd : NULL, p->det_run ? tmd : NULL);
+        if (rc > worst) worst = rc;
+        trans_done[cls] = 1;
+      }
+      if (p->relax_alpha != 0.0) {                                       /* :457-469, :617-629 */
+        orc_weight_rtpp(k, p->relax_alpha, tr, parm, wrlx);
+      } else if (p->relax_alpha_spread != 0.0) {
+        double xb[k], tmpinfl;
+        for (int m = 0; m < k; ++m) xb[m] = g[m * sm + n * sv];
+        orc_weight_rtps(k, p->relax_alpha_spread, tr, pc, xb, parm, wrlx, &tmpinfl);
+      } else {
+        memcpy(wrlx, tr, sizeof(double) * kk);
+      }
+      for (int m = 0; m < k; ++m) {                                      /* :472-477, :632-637 */
+        for (int q = 0; q < k; ++q) CM(wrlx, k, q, m) = (CM(wrlx, k, q, m) + tm[q]) * beta;
+        CM(wrlx, k, m, m) += (1.0 - beta);
+      }
+      for (int m = 0; m < k; ++m) {                                      /* :480-486, :640-646 */
+        double t = g[k * sm + n * sv];
+        for (int q = 0; q < k; ++q) t = t + g[q * sm + n * sv] * CM(wrlx, k, q, m);
+        a[m * sm + n * sv] = t;
+      }
+      if (p->det_run) {                                                  /* :489-497, :649-657 */
+        double t = 0.0;
+        for (int q = 0; q < k; ++q) t = t + g[q * sm + n * sv] * tmd[q];
+        a[(k + 1) * sm + n * sv] = g[(k + 1) * sm + n * sv] + t * beta;
+      }
+      if (!is2d && p->q_sprd_max > 0.0 && n == p->iv_q_first) {          /* :500-513 (3-D only) */
+        double q_mean = 0.0, q_sprd = 0.0, q_anal[k];
+        for (int m = 0; m < k; ++m) q_mean += a[m * sm + n * sv];
+        q_mean /= (double)k;
+        for (int m = 0; m < k; ++m) {
+          q_anal[m] = a[m * sm + n * sv] - q_mean;
+          q_sprd += q_anal[m] * q_anal[m];
+        }
+        q_sprd = sqrt(q_sprd / (double)(k - 1)) / q_mean;
+        if (q_sprd > p->q_sprd_max)
+          for (int m = 0; m < k; ++m) a[m * sm + n * sv] = q_mean + q_anal[m] * p->q_sprd_max / q_sprd;
+      }
+    }
+  }
+  free(hdxf);
+  free(rd);
+  free(trans);
+  free(trans_done);
+  return worst;
+}
+
 /* common/common_sort.f90:341-369 / :404-432 -- selection semantics only: after the call the first K entries of x
  * index the K smallest (largest) keys.  The reference's pivot rules (sample_second_min_arg :224, median_of_three_arg
  * :168) only decide the ORDER inside the two halves, which its callers never rely on

@@ -144,3 +144,24 @@ def das_points(params, obs_off, obs_idx, rdiag_l, rloc_l, ensval, dep, beta, inf
         _dp(dep), _dp(beta), _dp(infl), _dp(gues), _dp(anal), C.c_int64(sp), C.c_int64(sm), C.c_int64(sv),
         _dp(trans), _dp(transm), _dp(pa), status.ctypes.data_as(C.POINTER(C.c_int32)), _dp(rtps))
     return dict(anal=anal, infl=infl, trans=trans, transm=transm, pa=pa, status=status, rc=rc, rtps=rtps)
+
+
+def das_level1_2d(params, nv2d, n2nc, n2n, nclass, nij1, obs_off, obs_idx, rdiag_l, rloc_l, ensval, dep, beta,
+                  work3d, work2d, gues3, s3, gues2, s2):
+    """orc_das_letkf_level1_2d (scale/letkf/letkf_tools.f90:313-686): obs_off [nclass][nij1+1] into the concatenated
+    per-class lists; s3 / s2 = (sp, sm, sv).  Returns dict(anal3, anal2, work3d, work2d, rc)."""
+    anal3, anal2 = np.full_like(gues3, np.nan), np.full_like(gues2, np.nan)
+    w3, w2 = np.array(work3d, dtype=np.float64, copy=True), np.array(work2d, dtype=np.float64, copy=True)
+    obs_off = np.ascontiguousarray(obs_off, dtype=np.int64).reshape(-1)
+    obs_idx = np.ascontiguousarray(obs_idx, dtype=np.int32)
+    n2nc = np.ascontiguousarray(n2nc, dtype=np.int32)
+    n2n = np.ascontiguousarray(n2n, dtype=np.int32)
+    f = oracle().orc_das_letkf_level1_2d
+    f.restype = C.c_int
+    rc = f(C.byref(params), C.c_int(nv2d), n2nc.ctypes.data_as(C.POINTER(C.c_int32)),
+           n2n.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int(nclass), C.c_int64(nij1),
+           obs_off.ctypes.data_as(C.POINTER(C.c_int64)), obs_idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(rdiag_l),
+           _dp(rloc_l), _dp(ensval), C.c_int64(ensval.shape[1]), _dp(dep), _dp(beta), _dp(w3), _dp(w2), _dp(gues3),
+           _dp(anal3), C.c_int64(s3[0]), C.c_int64(s3[1]), C.c_int64(s3[2]), _dp(gues2), _dp(anal2), C.c_int64(s2[0]),
+           C.c_int64(s2[1]), C.c_int64(s2[2]))
+    return dict(anal3=anal3, anal2=anal2, work3d=w3, work2d=w2, rc=rc)
