@@ -101,7 +101,7 @@ def main():
     st = torch.zeros(npts, dtype=torch.int32, device=dev)
     stages["loop_body(letkf_core+transform)"], _ = timed(
         lambda: ctx.das_points(k, nv, off, idx, rd, rl, ens_sorted, kld, dep_sorted, infl, gues, anal, sp, sm, sv,
-                               status=st, relax_alpha_spread=0.95))
+                               status=st, relax_alpha_spread=0.95, warm_stride=nij))   # warm-start runs up the columns, as bench.py
     assert int(st.abs().max()) == 0
     del off, idx, rd, rl, lists
     add = torch.randn_like(gues)
