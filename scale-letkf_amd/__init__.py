@@ -27,10 +27,12 @@ def build(force=False):
     """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))]
     srcs.append(os.path.join(HERE, "..", "include", "letkf_amd.h"))
+    if os.environ.get("LETKF_AMD_LIB") and os.path.exists(LIB_PATH) and not force:
+        return LIB_PATH                      # an A/B or profiling twin: taken as it is, whatever its age
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
-    if stale:
-        subprocess.check_call(["make", "-j4", "-C", HERE] + (["-B"] if force else []))
+    if stale:                                # (make's chatter to stderr: stdout belongs to the caller's JSON line)
+        subprocess.check_call(["make", "-j4", "-C", HERE] + (["-B"] if force else []), stdout=2)
     return LIB_PATH
 
 

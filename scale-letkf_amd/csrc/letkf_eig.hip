@@ -34,18 +34,20 @@
 #include "letkf_jacobi_dev.h"
 
 #ifndef EIG_RBR2
-#define EIG_RBR2 16
+#define EIG_RBR2 42
 #endif
 #ifndef EIG_PF
-#define EIG_PF 4
+#define EIG_PF 2
 #endif
 #ifndef EIG_PM
-#define EIG_PM 4
+#define EIG_PM 2
 #endif
 
 namespace letkf {
 
 namespace {
+
+typedef __attribute__((address_space(3))) double lds_double;
 
 using jacobi_dev::dpp_shift0;
 using jacobi_dev::fast_rcp1;
@@ -53,7 +55,7 @@ using jacobi_dev::fast_rsqrt;
 using jacobi_dev::fast_rsqrt1;
 
 struct Rot {
-  double c, s, tg;   // cosine, sine, t * gamma
+  double tt, c, tg;   // tangent, cosine, t * gamma
   bool notconv;      // |cos| > 1e-10
   bool notconv2;     // |cos| > 1e-8 or |t| > 1e-6: the early-stop rule of letkf_jacobi_dev.h (kEarlyTol2W, kEarlyT2W)
 };
@@ -71,8 +73,8 @@ __device__ __forceinline__ Rot make_rot(const double a, const double b, const do
   tt = rot ? tt : 0.0;
   r.notconv2 = enable && (g2 > jacobi_dev::kEarlyTol2W * ab || tt * tt > jacobi_dev::kEarlyT2W);
   const double w = fma(tt, tt, 1.0);
+  r.tt = tt;
   r.c = fast_rsqrt(w);
-  r.s = r.c * tt;
   r.tg = tt * ga;
   return r;
 }
@@ -86,23 +88,21 @@ __device__ __forceinline__ Rot make_rot(const double a, const double b, const do
 // the lower column into a fresh register (the old one is still an operand of the upper column's update), i.e. it
 // renames the whole column per step, and the copies / live ranges that follow cost ~90 spilled registers at 52 rows
 // per lane (found with -Rpass-analysis and in the ISA).
-//   even step:  a <- c b + s a ;  b <- c a - s b
-__device__ __forceinline__ void rot_inplace(double& a, double& b, const double c, const double s) {
+// The rotations are the SCALED ("fast") ones of letkf_jacobi_dev.h: a column is kept as stored * is (is = the product
+// of the cosines since the last refresh, sc = 1 / is carried along), so a rotated column is H + coef * G -- one FMA per
+// element instead of a multiply and an FMA.
+//   even step:  a <- b + cA a ;  b <- a_old + cB b
+__device__ __forceinline__ void rot_inplace(double& a, double& b, const double cA, const double cB) {
   double t;
   asm("v_mov_b64 %2, %0\n\t"
-      "v_mul_f64 %0, %4, %0\n\t"
-      "v_fmac_f64 %0, %3, %1\n\t"
-      "v_mul_f64 %1, -%4, %1\n\t"
-      "v_fmac_f64 %1, %3, %2"
+      "v_fma_f64 %0, %3, %0, %1\n\t"
+      "v_fma_f64 %1, %4, %1, %2"
       : "+v"(a), "+v"(b), "=&v"(t)
-      : "v"(c), "v"(s));
+      : "v"(cA), "v"(cB));
 }
-//   odd step:   x <- f x + g y
-__device__ __forceinline__ void axpby_inplace(double& x, const double f, const double g, const double y) {
-  asm("v_mul_f64 %0, %1, %0\n\t"
-      "v_fmac_f64 %0, %2, %3"
-      : "+v"(x)
-      : "v"(f), "v"(g), "v"(y));
+//   odd step:   x <- y + f x   (on the element's own register: hipcc's v_fmac accumulates into y's register and copies back)
+__device__ __forceinline__ void xpay_inplace(double& x, const double f, const double y) {
+  asm("v_fma_f64 %0, %1, %0, %2" : "+v"(x) : "v"(f), "v"(y));
 }
 
 #ifdef LETKF_WAVE_PROF
@@ -130,7 +130,7 @@ __device__ __forceinline__ double sum_parts(const double* p, const int stride) {
 
 size_t eig_wg_lds_bytes(int NP, int RP, int RBR, int SB) {
   const size_t NT = 64 * (size_t)NP * SB, NS = 64 * (size_t)SB;
-  return 8 * ((size_t)(RP - RBR) * NT + 2 * (size_t)NP * NS + 2 * NS + 2 * (size_t)NP * RP) + 2 * 16 * sizeof(int) + 64;
+  return 8 * ((size_t)(RP - RBR) * NT + 2 * (size_t)NP * NS + 8 * NS + 2 * (size_t)NP * RP) + 2 * 16 * sizeof(int) + 64;
 }
 
 // NP row parts x SB slot-blocks = NP * SB waves per matrix; 2 waves per SIMD (256 VGPRs per lane) either way:
@@ -144,8 +144,9 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
   double* blds = sm;                       // [RBL][NT]   rows RBR.. of the upper columns
   double* pe = blds + (size_t)RBL * NT;    // [8][NS]     partial inner products, even steps (and the norm refresh)
   double* po = pe + kParts * NS;           // [8][NS]     ... odd steps
-  double* pn = po + kParts * NS;           // [NS][2]     squared norms (lower, upper) of every slot after its even step
-  double* bbP = pn + 2 * NS;               // [8][RP]     mailbox: lower column of slot 64 (for slot 63)
+  double* pn = po + kParts * NS;           // [NS][4]     squared norms and scales (lower, upper) of every slot after its even step
+  double* st = pn + 4 * NS;                // [NS][4]     the slots' norms and scales BETWEEN step pairs (see the even step)
+  double* bbP = st + 4 * NS;               // [8][RP]     mailbox: lower column of slot 64 (for slot 63)
   double* bbQ = bbP + kParts * RP;         // [8][RP]     mailbox: upper column of slot 63 (for slot 64)
   int* flags = reinterpret_cast<int*>(bbQ + kParts * RP);   // [2][16] convergence votes of the waves
 
@@ -153,10 +154,21 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the branches on part / sb below are wave-uniform)
   const int part = wave / SB, sb = wave % SB;
   const int slot = sb * 64 + lane;
-  const int tidm1 = tid > 0 ? tid - 1 : 0;
   const bool bndR = SB == 2 && sb == 0 && lane == 63;   // slot 63: its right neighbour sits in the other slot-block
   const bool bndL = SB == 2 && sb == 1 && lane == 0;    // slot 64
   const int row0 = part * RP;
+  // LDS rows of a thread are NT * 8 bytes apart and a DS instruction reaches 64 KB from its address register: left to
+  // itself hipcc gives every row beyond that its own (hoisted) address register -- 20 VGPRs at 36 rows.  One laundered
+  // base per KROW rows instead, every access an immediate offset from one of them.
+  constexpr int KROW = 65536 / (NT * 8), NBASE = RBL > 0 ? (RBL + KROW - 1) / KROW : 1;
+  lds_double* bt[NBASE];   // the thread's own rows
+#pragma unroll
+  for (int i = 0; i < NBASE; ++i) {
+    unsigned o = (unsigned)(uintptr_t)(lds_double*)(blds + (size_t)i * KROW * NT + tid);
+    asm volatile("" : "+v"(o));
+    bt[i] = (lds_double*)(uintptr_t)o;
+  }
+#define BT(r) bt[(r) / KROW][((r) % KROW) * NT]
 
   EP_DECL();
   for (long it = blockIdx.x; it < E.npts; it += gridDim.x) {
@@ -186,23 +198,47 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
         a[rr] = (oka && row < m) ? va : 0.0;
         const double vbz = (okb && row < m) ? vb : 0.0;
         if (rr < RBR) breg[rr] = vbz;
-        else blds[(size_t)(rr - RBR) * NT + tid] = vbz;
+        else BT(rr - RBR) = vbz;
         EIG_ROW_FENCE(rr);
       }
     }
-    double alA = 0.0, alB = 0.0;
+    // A slot's squared norms (alA, alB) and scales (column = stored * is) are the same in all its row parts, change only
+    // in the two short scalar phases of a step pair and are needed nowhere else: they LIVE IN LDS (st between step pairs,
+    // pn between the even and the odd step, written by part 0) instead of in eight registers across the row loops --
+    // four more rows of the upper column in registers.
+    if (part == 0) {
+      st[4 * slot] = 0.0;
+      st[4 * slot + 1] = 0.0;
+      st[4 * slot + 2] = 1.0;
+      st[4 * slot + 3] = 1.0;
+    }
     int quiet = 0, quiet2 = 0, pairs = 0, sweep = 0;
     bool done = false, odd_notconv_prev = false, odd_notconv2_prev = false;
     int vph = 0;
+    // Lanes of unused slots hold zero columns and are SWITCHED OFF inside the row loops (never around a barrier): the
+    // scaled rotations below write x <- y + f x, so a fetched neighbour can no longer be multiplied away, but a DPP
+    // read from a disabled lane returns 0 (bound_ctrl) and their LDS rows stay the zeros of the load -- "no partner".
+    const bool act = slot < S;
     __syncthreads();
 
     for (; sweep < E.max_sweep && !done; ++sweep) {
-      // ---- refresh the squared norms (they are carried by the rotation identities inside a sweep)
+      // ---- refresh: fold the scales back into the columns, recompute the squared norms (inside a sweep they are
+      // carried by the rotation identities)
       {
+        if (sweep > 0) __syncthreads();                   // (st was written by part 0 in the last odd step)
+        const double isA = st[4 * slot + 2], isB = st[4 * slot + 3];
         double sa = 0.0, sbq = 0.0, sab = 0.0;
 #pragma unroll
         for (int rr = 0; rr < RP; ++rr) {
-          const double vb = rr < RBR ? breg[rr < RBR ? rr : 0] : blds[(size_t)(rr - RBR) * NT + tid];
+          a[rr] *= isA;
+          double vb;
+          if (rr < RBR) {
+            breg[rr < RBR ? rr : 0] *= isB;
+            vb = breg[rr < RBR ? rr : 0];
+          } else {
+            vb = BT(rr - RBR) * isB;
+            BT(rr - RBR) = vb;
+          }
           sa = fma(a[rr], a[rr], sa);
           sbq = fma(vb, vb, sbq);
           sab = fma(a[rr], vb, sab);
@@ -211,8 +247,12 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
         pe[part * NS + slot] = sa;
         po[part * NS + slot] = sbq;
         __syncthreads();
-        alA = sum_parts<NP>(pe + slot, NS);
-        alB = sum_parts<NP>(po + slot, NS);
+        if (part == 0) {
+          st[4 * slot] = sum_parts<NP>(pe + slot, NS);
+          st[4 * slot + 1] = sum_parts<NP>(po + slot, NS);
+          st[4 * slot + 2] = 1.0;
+          st[4 * slot + 3] = 1.0;
+        }
         __syncthreads();
         pe[part * NS + slot] = sab;                       // the first even step's inner product (see the odd step)
       }
@@ -222,39 +262,46 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
         EP_SYNC(0);                                       // (1)
         bool notconv, notconv2;
         {
-          const double ga = sum_parts<NP>(pe + slot, NS);
+          const double alA = st[4 * slot], alB = st[4 * slot + 1], isA = st[4 * slot + 2], isB = st[4 * slot + 3];
+          const double ga = sum_parts<NP>(pe + slot, NS) * (isA * isB);
           const Rot r = make_rot(alA, alB, ga, true);
           notconv = r.notconv;
           notconv2 = r.notconv2;
-          // rotate and swap: position 2s takes c B + s A, position 2s+1 takes c A - s B
-          const double nA = alB + r.tg, nB = alA - r.tg;
-          alA = nA;
-          alB = nB;
+          // rotate and swap: position 2s takes c (B + t A), position 2s+1 takes c (A - t B)
+          // (coefficients t isA / isB and -t isB / isA through ONE reciprocal; carrying 1 / is along as the register
+          // kernels do costs four more registers per lane, which this kernel does not have)
+          const double rab = r.tt * jacobi_dev::fast_rcp(isA * isB);
+          const double cA = (isA * isA) * rab, cB = -(isB * isB) * rab;
+          if (part == 0) {
+            pn[4 * slot] = alB + r.tg;
+            pn[4 * slot + 1] = alA - r.tg;
+            pn[4 * slot + 2] = isB * r.c;
+            pn[4 * slot + 3] = isA * r.c;
+          }
           // LDS rows: the loads run kPF rows ahead of their use, written out in the source -- hipcc cannot move a row's
           // read above the previous row's write (every row has its own address register: no alias information), and
           // left alone it emits read, s_waitcnt lgkmcnt(0), use for every single row
-          double pf[kPF];
+          if (act) {
+            double pf[kPF];
 #pragma unroll
-          for (int u = 0; u < kPF; ++u)
-            if (RBR + u < RP) pf[u] = blds[(size_t)u * NT + tid];
+            for (int u = 0; u < kPF; ++u)
+              if (RBR + u < RP) pf[u] = BT(u);
 #pragma unroll
-          for (int rr = 0; rr < RP; ++rr) {
-            if (rr < RBR) {
-              rot_inplace(a[rr], breg[rr < RBR ? rr : 0], r.c, r.s);
-            } else {
-              double vb = pf[(rr - RBR) % kPF];
-              if (rr + kPF < RP) pf[(rr - RBR) % kPF] = blds[(size_t)(rr + kPF - RBR) * NT + tid];
-              rot_inplace(a[rr], vb, r.c, r.s);
-              blds[(size_t)(rr - RBR) * NT + tid] = vb;
+            for (int rr = 0; rr < RP; ++rr) {
+              if (rr < RBR) {
+                rot_inplace(a[rr], breg[rr < RBR ? rr : 0], cA, cB);
+              } else {
+                double vb = pf[(rr - RBR) % kPF];
+                if (rr + kPF < RP) pf[(rr - RBR) % kPF] = BT(rr + kPF - RBR);
+                rot_inplace(a[rr], vb, cA, cB);
+                BT(rr - RBR) = vb;
+              }
             }
-          }
-          if (part == 0) {
-            pn[2 * slot] = alA;
-            pn[2 * slot + 1] = alB;
           }
         }
         if constexpr (SB == 2) {
-          // mailbox for the slot pair (63, 64) that straddles the two slot-blocks
+          // mailbox for the slot pair (63, 64) that straddles the two slot-blocks (written by an unused slot 64 as
+          // well: its zeros are slot 63's "no partner")
           if (bndL) {
 #pragma unroll
             for (int rr = 0; rr < RP; ++rr) bbP[part * RP + rr] = a[rr];
@@ -262,7 +309,7 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
           if (bndR) {
 #pragma unroll
             for (int rr = 0; rr < RP; ++rr)
-              bbQ[part * RP + rr] = rr < RBR ? breg[rr < RBR ? rr : 0] : blds[(size_t)(rr - RBR) * NT + tid];
+              bbQ[part * RP + rr] = rr < RBR ? breg[rr < RBR ? rr : 0] : BT(rr - RBR);
           }
           EP_SYNC(1);                                     // (2)
         }
@@ -272,42 +319,47 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
         // LDS latencies per step pair, 2/3 of the kernel's time).  The slot pair that straddles the slot-blocks gets
         // its partner through an UNCONDITIONAL term: every wave reads its mailbox row (one address for the whole wave)
         // and multiplies it by a coefficient that is zero in all lanes but the one concerned.
-        const double* mbx = (SB == 2 && sb == 1) ? bbQ + part * RP : bbP + part * RP;   // (wave-uniform)
+        // (wave-uniform; read two rows at a time: one address for the whole wave, so what a read costs is the instruction)
+        const double2* mbx2 = reinterpret_cast<const double2*>((SB == 2 && sb == 1) ? bbQ + part * RP : bbP + part * RP);
+        static_assert(SB == 1 || RP % 2 == 0, "mailbox rows are read in pairs");
         const double selP = bndR ? 1.0 : 0.0;
         {
           double p0 = 0.0, p1 = 0.0;
-          double pf[kPF], pm[kPM];
+          if (act) {
+            double pf[kPF];
+            double2 pm[kPM];
 #pragma unroll
-          for (int u = 0; u < kPF; ++u)
-            if (RBR + u < RP) pf[u] = blds[(size_t)u * NT + tid];
-          if constexpr (SB == 2) {
+            for (int u = 0; u < kPF; ++u)
+              if (RBR + u < RP) pf[u] = BT(u);
+            if constexpr (SB == 2) {
 #pragma unroll
-            for (int u = 0; u < kPM; ++u)
-              if (u < RP) pm[u] = mbx[u];
-          }
-#pragma unroll
-          for (int rr = 0; rr < RP; ++rr) {
-            // (register-only fences: without them hipcc fetches ALL rows of the neighbour first -- a third column in
-            // registers; volatile asm statements keep their order, so each row's fetch waits for the previous row's FMA)
-            asm volatile("" : "+v"(a[rr]));
-            double pr = dpp_shift0<0x130>(a[rr]);          // lane + 1 (0 for lane 63)
-            if constexpr (SB == 2) {                        // slot 63: its partner's column is in the mailbox
-              pr = fma(selP, pm[rr % kPM], pr);
-              if (rr + kPM < RP) pm[rr % kPM] = mbx[rr + kPM];
+              for (int u = 0; u < kPM; ++u)
+                if (2 * u < RP) pm[u] = mbx2[u];
             }
-            double q;
-            if (rr < RBR) {
-              q = breg[rr < RBR ? rr : 0];
-            } else {
-              q = pf[(rr - RBR) % kPF];
-              if (rr + kPF < RP) pf[(rr - RBR) % kPF] = blds[(size_t)(rr + kPF - RBR) * NT + tid];
-            }
-            if (rr & 1) {
-              p1 = fma(q, pr, p1);
-              asm volatile("" : "+v"(p1));
-            } else {
-              p0 = fma(q, pr, p0);
-              asm volatile("" : "+v"(p0));
+#pragma unroll
+            for (int rr = 0; rr < RP; ++rr) {
+              // (register-only fences: without them hipcc fetches ALL rows of the neighbour first -- a third column in
+              // registers; volatile asm statements keep their order, so each row's fetch waits for the previous row's FMA)
+              asm volatile("" : "+v"(a[rr]));
+              double pr = dpp_shift0<0x130>(a[rr]);          // lane + 1 (0 for lane 63 and for a switched-off lane)
+              if constexpr (SB == 2) {                        // slot 63: its partner's column is in the mailbox
+                pr = fma(selP, (rr & 1) ? pm[(rr / 2) % kPM].y : pm[(rr / 2) % kPM].x, pr);
+                if ((rr & 1) && rr / 2 + kPM < RP / 2) pm[(rr / 2) % kPM] = mbx2[rr / 2 + kPM];
+              }
+              double q;
+              if (rr < RBR) {
+                q = breg[rr < RBR ? rr : 0];
+              } else {
+                q = pf[(rr - RBR) % kPF];
+                if (rr + kPF < RP) pf[(rr - RBR) % kPF] = BT(rr + kPF - RBR);
+              }
+              if (rr & 1) {
+                p1 = fma(q, pr, p1);
+                asm volatile("" : "+v"(p1));
+              } else {
+                p0 = fma(q, pr, p0);
+                asm volatile("" : "+v"(p0));
+              }
             }
           }
           const double podd = p0 + p1;
@@ -319,76 +371,82 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
         EP_SYNC(2);                                       // (3)
         {
           // as the left member of the pair (s, s+1), and again as the right member of (s-1, s)
-          const double gR = sum_parts<NP>(po + slot, NS);
-          const double gL = sum_parts<NP>(po + (slot > 0 ? slot - 1 : 0), NS);
-          const double nPr = pn[2 * (slot + 1 < NS ? slot + 1 : slot)];       // |P_{s+1}|^2
-          const double nQl = pn[2 * (slot > 0 ? slot - 1 : 0) + 1];           // |Q_{s-1}|^2
+          const int sr = slot + 1 < NS ? slot + 1 : slot, sl = slot > 0 ? slot - 1 : 0;
+          const double alA = pn[4 * slot], alB = pn[4 * slot + 1], isA = pn[4 * slot + 2], isB = pn[4 * slot + 3];
+          const double nPr = pn[4 * sr], isPr = pn[4 * sr + 2];                // |P_{s+1}|^2 and its scale
+          const double nQl = pn[4 * sl + 1], isQl = pn[4 * sl + 3];            // |Q_{s-1}|^2 and its scale
+          const double gR = sum_parts<NP>(po + slot, NS) * (isB * isPr);
+          const double gL = sum_parts<NP>(po + sl, NS) * (isQl * isA);
+          const double scPr = jacobi_dev::fast_rcp(isPr), scQl = jacobi_dev::fast_rcp(isQl);
           const Rot rR = make_rot(alB, nPr, gR, hasR);     // lower = Q_s, upper = P_{s+1}
           const Rot rL = make_rot(nQl, alA, gL, hasL);     // lower = Q_{s-1}, upper = P_s
           odd_notconv_prev = rR.notconv;
           odd_notconv2_prev = rR.notconv2;
-          // new upper column of slot s (position 2s+1) = c P_{s+1} + s Q_s ; new lower column (position 2s) = c Q_{s-1} - s P_s
-          const double cp = hasR ? rR.c : 0.0, cq = hasR ? rR.s : 1.0;
-          const double cql = hasL ? rL.c : 0.0, ca = hasL ? -rL.s : 1.0;
-          if (hasR) alB = nPr + rR.tg;
-          if (hasL) alA = nQl - rL.tg;
+          // new upper column of slot s (position 2s+1) = c (P_{s+1} + t Q_s); new lower column (position 2s) = c (Q_{s-1} - t P_s)
+          const double coefR = hasR ? rR.tt * (isB * scPr) : 1.0;
+          const double coefL = hasL ? -rL.tt * (isA * scQl) : 1.0;
+          if (part == 0) {
+            st[4 * slot] = hasL ? nQl - rL.tg : alA;
+            st[4 * slot + 1] = hasR ? nPr + rR.tg : alB;
+            st[4 * slot + 2] = hasL ? isQl * rL.c : isA;
+            st[4 * slot + 3] = hasR ? isPr * rR.c : isB;
+          }
           int anyf = 0;
 #pragma unroll
           for (int w = 0; w < NP * SB; ++w) anyf |= flags[16 * vph + w];
+          anyf = __builtin_amdgcn_readfirstlane(anyf);     // (the same words in every lane: quiet / done live in SGPRs)
           vph ^= 1;
           double fe0 = 0.0, fe1 = 0.0;
-          double pfq[kPF], pfl[kPF], pm[kPM];
+          if (act) {
+            double pfq[kPF];
+            double2 pm[kPM];
 #pragma unroll
-          for (int u = 0; u < kPF; ++u)
-            if (RBR + u < RP) {
-              pfq[u] = blds[(size_t)u * NT + tid];
-              pfl[u] = blds[(size_t)u * NT + tidm1];
-            }
-          if constexpr (SB == 2) {
-#pragma unroll
-            for (int u = 0; u < kPM; ++u)
-              if (u < RP) pm[u] = mbx[u];
-          }
-#pragma unroll
-          for (int rr = 0; rr < RP; ++rr) {
-            // the neighbour's rows are fetched a second time (once for the inner product, once here); laundering a[rr]
-            // keeps hipcc from merging the two fetches across the barrier, and orders this row behind the previous one
-            asm volatile("" : "+v"(a[rr]));
-            double pr = dpp_shift0<0x130>(a[rr]);
-            double q, ql;
-            if (rr < RBR) {
-              q = breg[rr < RBR ? rr : 0];
-              ql = dpp_shift0<0x138>(q);                   // lane - 1 (0 for lane 0)
-            } else {
-              q = pfq[(rr - RBR) % kPF];
-              ql = pfl[(rr - RBR) % kPF];
-              if (rr + kPF < RP) {
-                pfq[(rr - RBR) % kPF] = blds[(size_t)(rr + kPF - RBR) * NT + tid];
-                pfl[(rr - RBR) % kPF] = blds[(size_t)(rr + kPF - RBR) * NT + tidm1];
-              }
-            }
+            for (int u = 0; u < kPF; ++u)
+              if (RBR + u < RP) pfq[u] = BT(u);
             if constexpr (SB == 2) {
-              const double mb = pm[rr % kPM];
-              if (rr + kPM < RP) pm[rr % kPM] = mbx[rr + kPM];
-              pr = fma(selP, mb, pr);                      // slot 63 <- lower column of slot 64
-              ql = bndL ? mb : ql;                         // slot 64 <- upper column of slot 63
+#pragma unroll
+              for (int u = 0; u < kPM; ++u)
+                if (2 * u < RP) pm[u] = mbx2[u];
             }
-            if (rr < RBR) {
-              axpby_inplace(breg[rr < RBR ? rr : 0], cq, cp, pr);
-            } else {
-              axpby_inplace(q, cq, cp, pr);
-              blds[(size_t)(rr - RBR) * NT + tid] = q;
-            }
-            axpby_inplace(a[rr], ca, cql, ql);
-            // both new columns of the slot are in registers here: the next even step's inner product, for free
-            {
-              const double qn = rr < RBR ? breg[rr < RBR ? rr : 0] : q;
-              if (rr & 1) {
-                fe1 = fma(a[rr], qn, fe1);
-                asm volatile("" : "+v"(fe1));              // (keeps the rows in order: see the odd step's inner product)
+#pragma unroll
+            for (int rr = 0; rr < RP; ++rr) {
+              // the neighbour's rows are fetched a second time (once for the inner product, once here); laundering a[rr]
+              // keeps hipcc from merging the two fetches across the barrier, and orders this row behind the previous one
+              asm volatile("" : "+v"(a[rr]));
+              double pr = dpp_shift0<0x130>(a[rr]);
+              // (the left neighbour's element comes from the lane next door for the LDS rows too -- it has just loaded it:
+              // two vector moves instead of a second LDS read; the LDS pipe is this kernel's bottleneck)
+              double q;
+              if (rr < RBR) {
+                q = breg[rr < RBR ? rr : 0];
               } else {
-                fe0 = fma(a[rr], qn, fe0);
-                asm volatile("" : "+v"(fe0));
+                q = pfq[(rr - RBR) % kPF];
+                if (rr + kPF < RP) pfq[(rr - RBR) % kPF] = BT(rr + kPF - RBR);
+              }
+              double ql = dpp_shift0<0x138>(q);              // lane - 1 (0 for lane 0)
+              if constexpr (SB == 2) {
+                const double mb = (rr & 1) ? pm[(rr / 2) % kPM].y : pm[(rr / 2) % kPM].x;
+                if ((rr & 1) && rr / 2 + kPM < RP / 2) pm[(rr / 2) % kPM] = mbx2[rr / 2 + kPM];
+                pr = fma(selP, mb, pr);                      // slot 63 <- lower column of slot 64
+                ql = bndL ? mb : ql;                         // slot 64 <- upper column of slot 63 (a lane mask, no register)
+              }
+              if (rr < RBR) {
+                xpay_inplace(breg[rr < RBR ? rr : 0], coefR, pr);
+              } else {
+                xpay_inplace(q, coefR, pr);
+                BT(rr - RBR) = q;
+              }
+              xpay_inplace(a[rr], coefL, ql);
+              // both new columns of the slot are in registers here: the next even step's inner product, for free
+              {
+                const double qn = rr < RBR ? breg[rr < RBR ? rr : 0] : q;
+                if (rr & 1) {
+                  fe1 = fma(a[rr], qn, fe1);
+                  asm volatile("" : "+v"(fe1));              // (keeps the rows in order: see the odd step's inner product)
+                } else {
+                  fe0 = fma(a[rr], qn, fe0);
+                  asm volatile("" : "+v"(fe0));
+                }
               }
             }
           }
@@ -398,24 +456,20 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
           quiet2 = (anyf & 2) ? 0 : quiet2 + 1;
           done = quiet >= S + 1 || quiet2 >= S + 1;
         }
-        if constexpr (SB == 2) {
-          // the LDS rows of slot 63's upper column were just rewritten by its own wave while slot 64 (other wave) read
-          // the mailbox copy: nothing to wait for.  But the rows of the left neighbour read at thread - 1 cross the wave
-          // boundary only for slot 64, which uses the mailbox instead.
-        }
       }
     }
     __syncthreads();
-    // ---- store: columns back in place (lambda_j v_j, permuted order)
+    // ---- store: columns back in place (lambda_j v_j, permuted order), scales folded in
     {
       const int ca = 2 * slot, cb = 2 * slot + 1;
+      const double isA = st[4 * slot + 2], isB = st[4 * slot + 3];
 #pragma unroll
       for (int rr = 0; rr < RP; ++rr) {
         const int row = row0 + rr;
-        const double vb = rr < RBR ? breg[rr < RBR ? rr : 0] : blds[(size_t)(rr - RBR) * NT + tid];
+        const double vb = (rr < RBR ? breg[rr < RBR ? rr : 0] : BT(rr - RBR)) * isB;
         if (row < m) {                                     // all ncol columns: the zero column that pads an odd order
-          if (ca < ncol) G[(size_t)ca * ldg + row] = a[rr];   // may sit anywhere among them after the swaps (the slab
-          if (cb < ncol) G[(size_t)cb * ldg + row] = vb;      // has room for m + 1 columns)
+          if (ca < ncol) G[(size_t)ca * ldg + row] = a[rr] * isA;   // may sit anywhere among them after the swaps (the slab
+          if (cb < ncol) G[(size_t)cb * ldg + row] = vb;            // has room for m + 1 columns)
         }
       }
     }
@@ -453,7 +507,7 @@ static hipError_t launch_eig_one(const EigArgs& e, int grid, hipStream_t st) {
 }
 
 #ifndef EIG_RBR2
-#define EIG_RBR2 16
+#define EIG_RBR2 42
 #endif
 int eig_wg_max_order() { return 208; }
 
@@ -464,7 +518,11 @@ hipError_t launch_eig_wg(const EigArgs& e, int mcap, int num_cu, hipStream_t st)
   if (mcap <= 128) return launch_eig_one<4, 32, 32, 1>(e, grid, st);
   // (an <8, 26, RBR, 2> shape -- 16 waves, a quarter of the LDS rows per lane -- was tried for this range: 128 VGPRs per
   // lane do not hold the two columns and the prefetch rings, 130-200 B/lane of scratch, C3-slab 171 ms against 107 ms)
+#ifdef EIG_SHAPE6
+  return launch_eig_one<6, 35, EIG_SHAPE6, 2>(e, grid, st);   // 12 waves = 3 per SIMD (168 VGPRs), EIG_SHAPE6 of the 35 rows of B in registers
+#else
   return launch_eig_one<4, 52, EIG_RBR2, 2>(e, grid, st);
+#endif
 }
 
 }  // namespace letkf
