@@ -34,7 +34,7 @@
 #include "letkf_jacobi_dev.h"
 
 #ifndef EIG_RBR2
-#define EIG_RBR2 42
+#define EIG_RBR2 50
 #endif
 #ifndef EIG_PF
 #define EIG_PF 2
@@ -83,6 +83,12 @@ __device__ __forceinline__ Rot make_rot(const double a, const double b, const do
 // lane that spills the columns themselves); a compiler-level fence every 8 rows keeps the loads near their use (8 in flight)
 #define EIG_ROW_FENCE(rr) \
   if (((rr) & 7) == 7) asm volatile("" ::: "memory")
+// the single-lane mailbox loops: rows in pairs, EIG_FIX_ROWS rows of loads in flight
+#ifndef EIG_FIX_ROWS
+#define EIG_FIX_ROWS 8
+#endif
+#define EIG_FIX_FENCE(rr) \
+  if (((rr) + 2) % EIG_FIX_ROWS == 0) asm volatile("" ::: "memory")
 
 // The two row updates, written as instruction sequences that work IN PLACE.  From C++ hipcc puts every new element of
 // the lower column into a fresh register (the old one is still an operand of the upper column's update), i.e. it
@@ -116,7 +122,6 @@ __device__ unsigned long long g_eig_prof[8];
 #define EP_FLUSH() do {} while (0)
 #endif
 constexpr int kPF = EIG_PF;   // LDS rows in flight ahead of their use
-constexpr int kPM = EIG_PM;   // mailbox rows in flight
 
 template <int NP>
 __device__ __forceinline__ double sum_parts(const double* p, const int stride) {
@@ -160,6 +165,7 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
   // LDS rows of a thread are NT * 8 bytes apart and a DS instruction reaches 64 KB from its address register: left to
   // itself hipcc gives every row beyond that its own (hoisted) address register -- 20 VGPRs at 36 rows.  One laundered
   // base per KROW rows instead, every access an immediate offset from one of them.
+  static_assert(SB == 1 || RP % 2 == 0, "mailbox rows are read in pairs");
   constexpr int KROW = 65536 / (NT * 8), NBASE = RBL > 0 ? (RBL + KROW - 1) / KROW : 1;
   lds_double* bt[NBASE];   // the thread's own rows
 #pragma unroll
@@ -315,37 +321,24 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
         }
         // ================= odd step: upper column of slot s (Q_s) with the lower column of slot s+1 (P_{s+1}).
         // The row loops below carry no branch, so that hipcc can issue the LDS reads of a fence group together (with a
-        // conditional mailbox read per row every LDS read was followed by its own s_waitcnt lgkmcnt(0): ~260 exposed
-        // LDS latencies per step pair, 2/3 of the kernel's time).  The slot pair that straddles the slot-blocks gets
-        // its partner through an UNCONDITIONAL term: every wave reads its mailbox row (one address for the whole wave)
-        // and multiplies it by a coefficient that is zero in all lanes but the one concerned.
-        // (wave-uniform; read two rows at a time: one address for the whole wave, so what a read costs is the instruction)
-        const double2* mbx2 = reinterpret_cast<const double2*>((SB == 2 && sb == 1) ? bbQ + part * RP : bbP + part * RP);
-        static_assert(SB == 1 || RP % 2 == 0, "mailbox rows are read in pairs");
-        const double selP = bndR ? 1.0 : 0.0;
+        // conditional mailbox read per row every LDS read was followed by its own s_waitcnt lgkmcnt(0)).  The slot pair
+        // that straddles the slot-blocks: in the row loops the two lanes concerned see "no partner" (their DPP fetch
+        // returns 0), and each makes up for it in a short loop of its own afterwards -- everything is linear in the
+        // missing column.  (Before: an unconditional mailbox term in every lane, i.e. 2 RP broadcast reads per wave and
+        // step pair for two lanes of the workgroup; the LDS pipe is this kernel's bottleneck.)
         {
           double p0 = 0.0, p1 = 0.0;
           if (act) {
             double pf[kPF];
-            double2 pm[kPM];
 #pragma unroll
             for (int u = 0; u < kPF; ++u)
               if (RBR + u < RP) pf[u] = BT(u);
-            if constexpr (SB == 2) {
-#pragma unroll
-              for (int u = 0; u < kPM; ++u)
-                if (2 * u < RP) pm[u] = mbx2[u];
-            }
 #pragma unroll
             for (int rr = 0; rr < RP; ++rr) {
               // (register-only fences: without them hipcc fetches ALL rows of the neighbour first -- a third column in
               // registers; volatile asm statements keep their order, so each row's fetch waits for the previous row's FMA)
               asm volatile("" : "+v"(a[rr]));
-              double pr = dpp_shift0<0x130>(a[rr]);          // lane + 1 (0 for lane 63 and for a switched-off lane)
-              if constexpr (SB == 2) {                        // slot 63: its partner's column is in the mailbox
-                pr = fma(selP, (rr & 1) ? pm[(rr / 2) % kPM].y : pm[(rr / 2) % kPM].x, pr);
-                if ((rr & 1) && rr / 2 + kPM < RP / 2) pm[(rr / 2) % kPM] = mbx2[rr / 2 + kPM];
-              }
+              const double pr = dpp_shift0<0x130>(a[rr]);    // lane + 1 (0 for lane 63 and for a switched-off lane)
               double q;
               if (rr < RBR) {
                 q = breg[rr < RBR ? rr : 0];
@@ -359,6 +352,20 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
               } else {
                 p0 = fma(q, pr, p0);
                 asm volatile("" : "+v"(p0));
+              }
+            }
+          }
+          if constexpr (SB == 2) {
+            if (bndR && act) {                                     // slot 63: Q_63 . P_64, the lower column of slot 64 from the mailbox
+              const double2* mb = reinterpret_cast<const double2*>(bbP + part * RP);
+#pragma unroll
+              for (int rr = 0; rr < RP; rr += 2) {
+                const double2 mv = mb[rr / 2];
+                const double q0 = rr < RBR ? breg[rr < RBR ? rr : 0] : BT(rr - RBR);
+                const double q1 = rr + 1 < RBR ? breg[rr + 1 < RBR ? rr + 1 : 0] : BT(rr + 1 - RBR);
+                p0 = fma(q0, mv.x, p0);
+                p1 = fma(q1, mv.y, p1);
+                EIG_FIX_FENCE(rr);
               }
             }
           }
@@ -399,21 +406,15 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
           double fe0 = 0.0, fe1 = 0.0;
           if (act) {
             double pfq[kPF];
-            double2 pm[kPM];
 #pragma unroll
             for (int u = 0; u < kPF; ++u)
               if (RBR + u < RP) pfq[u] = BT(u);
-            if constexpr (SB == 2) {
-#pragma unroll
-              for (int u = 0; u < kPM; ++u)
-                if (2 * u < RP) pm[u] = mbx2[u];
-            }
 #pragma unroll
             for (int rr = 0; rr < RP; ++rr) {
               // the neighbour's rows are fetched a second time (once for the inner product, once here); laundering a[rr]
               // keeps hipcc from merging the two fetches across the barrier, and orders this row behind the previous one
               asm volatile("" : "+v"(a[rr]));
-              double pr = dpp_shift0<0x130>(a[rr]);
+              const double pr = dpp_shift0<0x130>(a[rr]);
               // (the left neighbour's element comes from the lane next door for the LDS rows too -- it has just loaded it:
               // two vector moves instead of a second LDS read; the LDS pipe is this kernel's bottleneck)
               double q;
@@ -423,13 +424,7 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
                 q = pfq[(rr - RBR) % kPF];
                 if (rr + kPF < RP) pfq[(rr - RBR) % kPF] = BT(rr + kPF - RBR);
               }
-              double ql = dpp_shift0<0x138>(q);              // lane - 1 (0 for lane 0)
-              if constexpr (SB == 2) {
-                const double mb = (rr & 1) ? pm[(rr / 2) % kPM].y : pm[(rr / 2) % kPM].x;
-                if ((rr & 1) && rr / 2 + kPM < RP / 2) pm[(rr / 2) % kPM] = mbx2[rr / 2 + kPM];
-                pr = fma(selP, mb, pr);                      // slot 63 <- lower column of slot 64
-                ql = bndL ? mb : ql;                         // slot 64 <- upper column of slot 63 (a lane mask, no register)
-              }
+              const double ql = dpp_shift0<0x138>(q);        // lane - 1 (0 for lane 0)
               if (rr < RBR) {
                 xpay_inplace(breg[rr < RBR ? rr : 0], coefR, pr);
               } else {
@@ -447,6 +442,36 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
                   fe0 = fma(a[rr], qn, fe0);
                   asm volatile("" : "+v"(fe0));
                 }
+              }
+            }
+          }
+          if constexpr (SB == 2) {
+            if (bndR && act) {                                     // slot 63: new upper column = (P_64 +) coefR Q_63
+              const double2* mb = reinterpret_cast<const double2*>(bbP + part * RP);
+#pragma unroll
+              for (int rr = 0; rr < RP; rr += 2) {
+                const double2 mv = mb[rr / 2];
+                if (rr < RBR) breg[rr < RBR ? rr : 0] += mv.x;
+                else BT(rr - RBR) = BT(rr - RBR) + mv.x;
+                if (rr + 1 < RBR) breg[rr + 1 < RBR ? rr + 1 : 0] += mv.y;
+                else BT(rr + 1 - RBR) = BT(rr + 1 - RBR) + mv.y;
+                fe0 = fma(a[rr], mv.x, fe0);
+                fe1 = fma(a[rr + 1], mv.y, fe1);
+                EIG_FIX_FENCE(rr);
+              }
+            }
+            if (bndL && act) {                                     // slot 64: new lower column = (Q_63 +) coefL P_64
+              const double2* mb = reinterpret_cast<const double2*>(bbQ + part * RP);
+#pragma unroll
+              for (int rr = 0; rr < RP; rr += 2) {
+                const double2 mv = mb[rr / 2];
+                a[rr] += mv.x;
+                a[rr + 1] += mv.y;
+                const double q0 = rr < RBR ? breg[rr < RBR ? rr : 0] : BT(rr - RBR);
+                const double q1 = rr + 1 < RBR ? breg[rr + 1 < RBR ? rr + 1 : 0] : BT(rr + 1 - RBR);
+                fe0 = fma(mv.x, q0, fe0);
+                fe1 = fma(mv.y, q1, fe1);
+                EIG_FIX_FENCE(rr);
               }
             }
           }
@@ -507,7 +532,7 @@ static hipError_t launch_eig_one(const EigArgs& e, int grid, hipStream_t st) {
 }
 
 #ifndef EIG_RBR2
-#define EIG_RBR2 42
+#define EIG_RBR2 50
 #endif
 int eig_wg_max_order() { return 208; }
 
