@@ -48,6 +48,15 @@ CONFIGS = {
     # C2's geometry (60 levels, its observation lattice) at the production ensemble size, on a 48 x 48 piece of the domain
     "C2-cols-k100": dict(nx=48, ny=48, nz=60, k=100, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2900.0, err=3.0,
                          ztop=18000.0, seed=20240619, halo=True),
+    # SURVEY.md section 8(d)'s imbalance case: C2's grid and lattice, but observations only inside a radar disc of 60 km
+    # radius around the domain centre (points further than the cut-off from the disc have no local observation at all)
+    "C2-disc": dict(nx=240, ny=240, nz=60, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2900.0, err=3.0,
+                    ztop=18000.0, seed=20240620, disc=60000.0),
+    "C2-mini-disc": dict(nx=48, ny=48, nz=12, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
+                         ztop=18000.0, seed=20240621, disc=12000.0),
+    # few local observations per point (n ~ 20 < k): the rim of a radar disc
+    "C2-mini-sparse": dict(nx=48, ny=48, nz=12, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=6000.0, err=3.0,
+                           ztop=18000.0, seed=20240622, halo=True),
     "C1": dict(nx=40, ny=40, nz=30, k=20, dx=15000.0, hloc=120000.0, vloc=4000.0, spacing=30000.0, err=3.0,
                ztop=18000.0, seed=20240608),
 }
@@ -70,6 +79,15 @@ def lattice(cfg, device):
     return ax(cfg["nx"] * cfg["dx"], nh), ax(cfg["ny"] * cfg["dx"], nh), ax(cfg["ztop"], nhz), nh, nhz
 
 
+def disc_mask(cfg, ox, oy):
+    """[noy, nox] mask of the lattice columns that carry observations: all of them, or (cfg["disc"] = radius in metres)
+    those inside a radar disc around the domain centre."""
+    if not cfg.get("disc"):
+        return torch.ones(len(oy), len(ox), dtype=torch.bool, device=ox.device)
+    cx, cy = 0.5 * cfg["nx"] * cfg["dx"], 0.5 * cfg["ny"] * cfg["dx"]
+    return ((ox[None, :] - cx) ** 2 + (oy[:, None] - cy) ** 2) <= cfg["disc"] ** 2
+
+
 def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval_kind="iid"):
     cfg = CONFIGS[cfg_name]
     nx, ny, nz, k = cfg["nx"], cfg["ny"], cfg["nz"], cfg["k"]
@@ -82,6 +100,7 @@ def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval_kind="
     nox, noy, noz = len(ox), len(oy), len(oz)
     nobs = nox * noy * noz
     kld = k + 1
+    dmask = disc_mask(cfg, ox, oy)
     ensval = torch.randn(nobs, kld, generator=g, device=device, dtype=f64) * 2.0
     ensval[:, :k] -= ensval[:, :k].mean(dim=1, keepdim=True)
     dep = torch.randn(nobs, generator=g, device=device, dtype=f64) * math.sqrt(err * err + 4.0)
@@ -117,6 +136,8 @@ def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval_kind="
         nd2 = ndh * ndh + (ndv * ndv)[None, :, None, None]
         ok = (okz & (ndv <= DIST_ZERO_FAC))[None, :, None, None] & oky[:, None, :, None] & okx[:, None, None, :]
         ok = ok & (ndh <= DIST_ZERO_FAC) & (nd2 <= DIST_ZERO_FAC_SQUARE)
+        if cfg.get("disc"):
+            ok = ok & dmask[iy.clamp(0, noy - 1)[:, None, :, None], ix.clamp(0, nox - 1)[:, None, None, :]]
         oidx = (iz[None, :, None, None] * noy + iy[:, None, :, None]) * nox + ix[:, None, None, :]
         okf = ok.reshape(nij, -1)
         counts_all.append(okf.sum(dim=1))
@@ -239,6 +260,9 @@ def search_tables(w, pkg, device, max_nobs=0):
     ri = (ox / dx).repeat(noy * noz)
     rj = (oy / dx).repeat_interleave(nox).repeat(noz)
     lev = oz.repeat_interleave(nox * noy)
+    nlat = ri.numel()                                  # rows of the full lattice (= rows of w["ensval"])
+    kept = disc_mask(cfg, ox, oy).reshape(-1).repeat(noz).nonzero(as_tuple=False).squeeze(1)   # lattice rows with an observation
+    ri, rj, lev = ri[kept], rj[kept], lev[kept]
     spc = hloc * DIST_ZERO_FAC / 6.0
     ngrd_i = min(math.ceil(dx * nx / spc), nx)
     ngrd_j = min(math.ceil(dx * ny / spc), ny)
@@ -251,6 +275,8 @@ def search_tables(w, pkg, device, max_nobs=0):
     ogj = (torch.ceil(rj * ngrd_j / ny).long() + nsch_j).clamp(1, next_j)
     cell = (ogj - 1) * next_i + (ogi - 1)
     order = torch.argsort(cell, stable=True)
+    ri, rj, lev = ri[order], rj[order], lev[order]
+    order = kept[order]                                # table row -> lattice row
     counts = torch.bincount(cell, minlength=next_i * next_j).view(next_j, next_i)
     ends = torch.cumsum(counts.reshape(-1), 0).view(next_j, next_i)
     ac = torch.zeros(next_j, next_i + 1, dtype=torch.int64, device=device)
@@ -265,7 +291,7 @@ def search_tables(w, pkg, device, max_nobs=0):
                 vert_loc=d64([vloc]), varloc=d64([1.0]), max_nobs=i32([0]), ngrd_i=i32([ngrd_i]), ngrd_j=i32([ngrd_j]),
                 ngrdsch_i=i32([nsch_i]), ngrdsch_j=i32([nsch_j]), ngrdext_i=i32([next_i]), ngrdext_j=i32([next_j]),
                 ac_off=torch.zeros(1, dtype=torch.int64, device=device), ac_ext=ac.reshape(-1).to(torch.int32),
-                ob_ri=ri[order].contiguous(), ob_rj=rj[order].contiguous(), ob_lev=lev[order].contiguous(),
+                ob_ri=ri.contiguous(), ob_rj=rj.contiguous(), ob_lev=lev.contiguous(),
                 ob_dat=torch.full_like(ri, 1.0e5), ob_err=torch.full_like(ri, cfg["err"]))
     t.limit_hint = 2 if max_nobs > 0 else 1
     if max_nobs > 0:
@@ -277,10 +303,10 @@ def search_tables(w, pkg, device, max_nobs=0):
         g2.manual_seed(cfg["seed"] + 4242)
         ens2 = torch.randn(w["ensval"].shape, generator=g2, device=device, dtype=f64) * 2.0
         ens2[:, :w["k"]] -= ens2[:, :w["k"]].mean(dim=1, keepdim=True)
-        dep2 = torch.randn(nrow, generator=g2, device=device, dtype=f64) * float(w["dep"].std())
+        dep2 = torch.randn(nlat, generator=g2, device=device, dtype=f64) * float(w["dep"].std())
         w["ensval"] = torch.cat([w["ensval"], ens2])
         w["dep"] = torch.cat([w["dep"], dep2])
-        order = torch.cat([order, order + nrow])
+        order = torch.cat([order, order + nlat])
         t.nctype, t.ngroup = 2, 2
         rep = lambda a: a.repeat(2)
         keep = dict(group_start=i32([0, 1, 2]), group_member=i32([0, 1]), vmode=i32([1, 1]),

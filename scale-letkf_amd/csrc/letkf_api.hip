@@ -45,6 +45,7 @@ struct letkf_ctx {
   double* ws = nullptr;       // large-k workspace
   size_t ws_bytes = 0;
   char* warm_ws = nullptr;    // wave kernel: eigenvectors handed from point to point inside a run
+  unsigned* sched = nullptr;  // wave kernel: the 8 run counters of the dynamic scheduling (512 bytes)
   size_t warm_ws_bytes = 0;
   char* scratch = nullptr;    // staging for the host-pointer entry
   size_t scratch_bytes = 0;
@@ -201,6 +202,8 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
     if (wbytes > c->warm_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));   // old buffer may still be in use
     if (int rc = ensure_bytes(c, &c->warm_ws, &c->warm_ws_bytes, wbytes)) return rc;
     a.warm_ws = reinterpret_cast<double*>(c->warm_ws);
+    if (!c->sched) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->sched), 512));
+    a.sched = LETKF_KNOB("LETKF_AMD_STATIC_SCHED") ? nullptr : c->sched;   // PROF knob: the static dealing, for A/B runs
     a.warm_dbg = 0;
     if (const char* e = LETKF_KNOB("LETKF_AMD_WARM_DBG")) a.warm_dbg = std::atoi(e);
     a.prof = nullptr;
@@ -219,6 +222,12 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
     HIP_TRY(hipMemsetAsync(prof_dev, 0, 10 * sizeof(unsigned long long), c->stream));
     a.prof = prof_dev;
 #endif
+    if (a.sched) HIP_TRY(hipMemsetAsync(a.sched, 0, 512, c->stream));
+    // points without observations / with beta = 0: one streaming pass, thread per point (letkf_trivial.hip)
+    if (letkf::trivial_pass_supports(a) && !LETKF_KNOB("LETKF_AMD_NO_TRIVIAL_PASS")) {
+      HIP_TRY(letkf::launch_trivial_points(a, c->stream));
+      a.skip_trivial = 1;
+    }
     HIP_TRY(letkf::launch_wave_kernel(a, c->num_cu, c->stream));
     c->last_path = "letkf_wave_kernel<KR=" + std::to_string(letkf::wave_kernel_kr(a.k)) + ",NV=" + std::to_string(a.nv) +
                    ",NW=" + (a.k <= 62 ? "1" : "2") + (a.mode == 2 ? ",FUSED" : "") + ">";
@@ -366,6 +375,7 @@ int letkf_ctx_destroy(letkf_ctx* c) {
     }
     if (c->ws) (void)hipFree(c->ws);
     if (c->warm_ws) (void)hipFree(c->warm_ws);
+    if (c->sched) (void)hipFree(c->sched);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->staged_ws) (void)hipFree(c->staged_ws);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

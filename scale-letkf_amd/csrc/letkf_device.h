@@ -64,6 +64,8 @@ struct PointArgs {
   double* warm_ws;
   int run_len, wave_grid, warm_dbg;
   long warm_stride;           // >= 1: a run walks points p, p + warm_stride, ... (letkf_das_args.warm_stride)
+  int skip_trivial;           // points with beta == 0 or without observations were done by letkf_trivial_points_kernel: skip them
+  unsigned* sched;            // dynamic run scheduling: 8 counters 64 bytes apart, zeroed before the launch (null: static dealing)
   unsigned long long* prof;   // profiling build (-DLETKF_WAVE_PROF) only: per-phase s_memtime totals, else null
 };
 
@@ -135,6 +137,8 @@ int wave_kernel_kr(int k);   // rows of the instantiation that serves k
 void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, long stride, int* run_len, int* grid,
                        size_t* ws_bytes);
 hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st);
+bool trivial_pass_supports(const PointArgs& a);
+hipError_t launch_trivial_points(const PointArgs& a, hipStream_t st);
 hipError_t launch_obs_departure(const letkf_qc_params& p, long nobs, const int* elm, const double* dat, const double* err,
                                 double* ensval, long kld, double* val, int* qc, int num_cu, hipStream_t st);
 hipError_t obs_mesh_sort(const letkf_mesh& m, long nobs, const int* ctype, const double* ri, const double* rj,

@@ -123,6 +123,64 @@ __device__ __forceinline__ long xcd_remap_w(long orig, long n) {
   return base + j;
 }
 
+// Dynamic run scheduling (PointArgs::sched): the run ids [0, n) are cut into 8 contiguous ranges, one per XCD -- the same
+// ranges as the static dealing of round 1, so that neighbouring columns still meet in one L2 -- and every wave (two-wave
+// points: every workgroup) draws its next run from its own XCD's counter; when that range is used up it takes runs from
+// the range that has most left.  A domain whose observations sit in one place (a radar disc: the columns outside have no observation
+// and cost a hundredth of a column inside) left whole XCDs idle under the static dealing (C2-disc: 259 -> 147 ms).
+// `fs` runs of every range are handed out last and in quarters, so that the waves do not end a whole run (C2: a column of
+// 60 points, 14 ms) apart; which points start a quarter -- i.e. start cold -- is a fixed function of the launch shape, so
+// results stay bitwise reproducible from run to run.
+// Returns 8 * run id + (0: the whole run, 4 + s: its quarter s), or -1.  Called by lane 0 of a wave; the counters are 64
+// bytes apart and zeroed by the host before every launch.
+struct SchedRange {
+  int base, whole, f, t;   // first run id; runs handed out whole; runs handed out in quarters: every t-th one, last
+  __device__ __forceinline__ SchedRange(const int x, const int n, const int fs) {
+    const int q = n >> 3, r = n & 7, len = q + (x < r ? 1 : 0);
+    base = x * q + (x < r ? x : r);
+    f = fs < len ? fs : len;
+    whole = len - f;
+    t = f > 0 ? len / f : 1;
+  }
+  __device__ __forceinline__ int units() const { return whole + 4 * f; }
+  // unit i of the range -> 8 * run id + (0: the whole run, 4 + s: its quarter s)
+  __device__ __forceinline__ int unit(const int i) const {
+    if (i < whole) {
+      const int head = f * (t - 1);                       // (whole > 0 implies t >= 2 or f == 0)
+      const int g = i < head ? i / (t - 1) : 0;
+      return 8 * (base + (i < head ? g * t + (i - g * (t - 1)) : f * t + (i - head)));
+    }
+    return 8 * (base + ((i - whole) >> 2) * t + (t - 1)) + 4 + ((i - whole) & 3);
+  }
+};
+__device__ __forceinline__ int sched_draw(unsigned* cnt, const int xcd, const int n, const int fs) {
+  {
+    const SchedRange own(xcd, n, fs);
+    if (own.units() > 0) {
+      const int i = (int)atomicAdd(&cnt[16 * xcd], 1u);
+      if (i < own.units()) return own.unit(i);
+    }
+  }
+  // own range used up: help where most is left (so that all ranges end together, each with its quartered runs last)
+#pragma unroll 1
+  for (int tries = 0; tries < 64; ++tries) {
+    int best = -1, most = 0;
+#pragma unroll 1
+    for (int x = 0; x < 8; ++x) {
+      const int left = SchedRange(x, n, fs).units() - (int)__hip_atomic_load(&cnt[16 * x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (left > most) {
+        most = left;
+        best = x;
+      }
+    }
+    if (best < 0) return -1;
+    const SchedRange rg(best, n, fs);
+    const int i = (int)atomicAdd(&cnt[16 * best], 1u);
+    if (i < rg.units()) return rg.unit(i);
+  }
+  return -1;
+}
+
 constexpr int kTnW = 8;               // obs rows per LDS tile (per wave)
 constexpr int kChunk = 8;             // columns per LDS transposition chunk
 constexpr int kVld = kChunk + 2;      // row stride of the transposition buffer (doubles, even)
@@ -436,7 +494,11 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
 #define PROF_FLUSH if (A.prof && wlane == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&A.prof[i_], prof_t[i_]); }
 #else
 #define PROF_DECL
+#ifdef LETKF_MARK_FENCE   // A/B knob (make VARIANT=...): compiler-level fences where the PROF twin reads its clock
+#define PROF_MARK(i) { if ((LETKF_MARK_FENCE >> (i)) & 1) asm volatile("" ::: "memory"); }
+#else
 #define PROF_MARK(i)
+#endif
 #define PROF_FLUSH
 #endif
 
@@ -480,16 +542,53 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
   // gues3d's point order: up a column), run number = chunk * S + b -- neighbouring runs are neighbouring columns
   const long S = A.warm_stride, nA = A.npts / S;
   const long nruns = S * ((nA + run_len - 1) / run_len);
-  const long nB = (nruns + PPW - 1) / PPW;
   // this wave's slot of the warm-start workspace: [KR][NL] doubles, lane-fastest
   double* uws = (WARM && run_len > 1) ? A.warm_ws + ((size_t)blockIdx.x * PPW + wv) * ((size_t)KR * NL) + lane : nullptr;
   PROF_DECL
-  for (long B = blockIdx.x; B < nB; B += gridDim.x) {
-   const long rid = xcd_remap_w(B, nB) * PPW + wv;
+#ifdef LETKF_WAVE_PROF
+  long Bstat = blockIdx.x;
+#endif
+  // runs handed out in quarters at the end of every XCD's range: as many as the XCD has waves (workgroups) in flight
+  const int fsplit = run_len >= 8 ? min((int)(gridDim.x * PPW / 8), NW == 1 ? 256 : 64) : 0;
+  for (long it_ = 0; it_ < nruns; ++it_) {
+   long rid;
+#ifdef LETKF_WAVE_PROF
+   if (!A.sched) {
+     // static (PROF twin only, LETKF_AMD_STATIC_SCHED): blocks of PPW consecutive runs, dealt to the workgroups in the
+     // order of their XCDs -- what the production kernel did before the dynamic scheduling
+     const long nB = (nruns + PPW - 1) / PPW;
+     if (Bstat >= nB) break;
+     rid = xcd_remap_w(Bstat, nB) * PPW + wv;
+     Bstat += gridDim.x;
+     if (rid >= nruns) continue;
+     rid *= 8;
+   } else
+#endif
+   {
+     // dynamic: the next run of this XCD's range (or of a neighbour's, once that is used up)
+     if constexpr (NW == 1) {
+       int g = -1;
+       if (wlane == 0) g = sched_draw(A.sched, (int)(blockIdx.x & 7), (int)nruns, fsplit);
+       rid = __builtin_amdgcn_readfirstlane(g);
+     } else {
+       int* slot_ = reinterpret_cast<int*>(red + 6);
+       __syncthreads();
+       if (threadIdx.x == 0) *slot_ = sched_draw(A.sched, (int)(blockIdx.x & 7), (int)nruns, fsplit);
+       __syncthreads();
+       rid = *slot_;
+     }
+     if (rid < 0) break;
+   }
+   int ir0 = 0, ir1 = run_len;
+   if (rid & 4) {
+     ir0 = (int)(rid & 3) * run_len >> 2;
+     ir1 = ((int)(rid & 3) + 1) * run_len >> 2;
+   }
+   rid >>= 3;
    const long rchunk = rid / S, rb = rid - rchunk * S;
-   const long ra0 = (rid < nruns) ? rchunk * run_len : nA;
+   const long ra0 = rchunk * run_len;
    bool have_u = false;
-   for (int ir = 0; ir < run_len; ++ir) {
+   for (int ir = ir0; ir < ir1; ++ir) {
     if (ra0 + ir >= nA) break;
     const long pt = (ra0 + ir) * S + rb;
     // Everything built from the lane number is the same for every point of the run, so hipcc hoists it out of this
@@ -512,6 +611,10 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
       if (A.beta) beta = A.beta[pt];
     } else {
       n = A.nobsl[pt];
+    }
+    if (A.skip_trivial && (n == 0 || beta == 0.0)) {   // done by the streaming pass (letkf_trivial.hip)
+      if (beta != 0.0) have_u = false;         // (as below: a point without observations leaves no eigenvectors behind,
+      continue;                                //  a beta = 0 point does not touch the run's)
     }
     // per-lane member offset, laundered so that LICM does not park 2*NV hoisted 64-bit offsets in VGPRs
     long moff = (long)lane * A.sm;
@@ -1017,7 +1120,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
       // leave the eigenvectors behind for the next point of the run.  Here, while g is still entirely in registers:
       // further down part of it is spilled, and a store loop that alternates scratch reloads with global stores
       // pays one store-acknowledge latency per element (s_waitcnt vmcnt counts both) -- measured 41 us per point.
-      if (uws && (solved || !MAPPLY) && !(A.warm_dbg & 2)) {
+      if (uws && solved && !(A.warm_dbg & 2)) {
         // (the pointer is laundered every 8 rows: otherwise all KR row addresses are hoisted out of the point loop
         // as 64-bit values, spilled, and reloaded one by one in front of each store -- same serialisation)
         unsigned long long pa = reinterpret_cast<unsigned long long>(uws);
@@ -1039,7 +1142,8 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
       else if (!(lmx > 0.0)) st = 2;
       else if (lmn < lmx * 1.4901161193847656e-08) st = 3;
     }
-    if constexpr (WARM) have_u = uws != nullptr && st == 0 && (solved || !MAPPLY);
+    // (a point without observations hands nothing on: its V = I would be a cold start anyway)
+    if constexpr (WARM) have_u = uws != nullptr && st == 0 && solved;
     const double sc1 = colvalid ? sqrt(km1 / lam) : 0.0;      // T spectrum
     const double sc2 = colvalid ? 1.0 / lam : 0.0;            // Pa spectrum
 

@@ -1,6 +1,7 @@
 """obs_local fused into the loop body (letkf_das_points_fused_dev) against the two-step path it replaces
 (letkf_obs_search_dev lists -> letkf_das_points_dev): same candidate order, same 4-obs MFMA grouping, so the analysis,
-inflation and status must be BIT-identical, and nobs_out must be the list lengths; the two-step path itself is checked
+inflation and status must be BIT-identical (points without observations: equal to rounding, they take different
+kernels), and nobs_out must be the list lengths; the two-step path itself is checked
 against the oracle elsewhere (test_gpu_search.py, test_gpu_das.py)."""
 import numpy as np
 import pytest
@@ -67,7 +68,14 @@ def test_fused_search_equals_search_then_solve(k, det, cfg):
     assert int(counts.max()) > 256 and int(counts.min()) < 192      # points with one and with several staging batches
     m0, m1 = a0.view(nv, nens, npts), a1.view(nv, nens, npts)
     members = list(range(k)) + ([k + 1] if det else [])
-    assert torch.equal(m0[:, members], m1[:, members])
+    # points with observations (and beta = 0 points: a copy): bit for bit.  Points WITHOUT observations leave the list
+    # path through the streaming pass (letkf_trivial.hip) and the fused path through the solve kernel's closed-form
+    # branch: the same formulas in two kernels, equal to rounding
+    empty = live & (counts == 0)
+    assert torch.equal(m0[:, members][:, :, ~empty], m1[:, members][:, :, ~empty])
+    if int(empty.sum()) > 0:
+        e0, e1 = m0[:, members][:, :, empty], m1[:, members][:, :, empty]
+        assert float(((e0 - e1).abs() / e1.abs().clamp_min(1.0)).max()) <= 4e-16 * 8
     assert torch.equal(i0, i1)
 
 
