@@ -290,6 +290,10 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
     HIP_TRY(hipEventCreate(&ev.e1));
     HIP_TRY(hipEventRecord(ev.e0, c->stream));
   }
+  if (letkf::trivial_pass_supports(a) && !LETKF_KNOB("LETKF_AMD_NO_TRIVIAL_PASS")) {   // as in launch()
+    HIP_TRY(letkf::launch_trivial_points(a, c->stream));
+    s.A.skip_trivial = 1;
+  }
   for (long p0 = 0; p0 < a.npts; p0 += nb) {
     s.pt0 = p0;
     s.nbatch = (a.npts - p0 < nb) ? a.npts - p0 : nb;

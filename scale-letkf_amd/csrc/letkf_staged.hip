@@ -138,6 +138,13 @@ __global__ void __launch_bounds__(kGBlock) letkf_stage_gram_kernel(const StagedA
     }
     const int n = ov.n;
     __syncthreads();
+    if (A.skip_trivial && (n == 0 || beta == 0.0)) {  // done by the streaming pass (letkf_trivial.hip): no stage touches it
+      if (tid == 0) {
+        S.meta[2 * it] = 255;
+        S.meta[2 * it + 1] = -1;
+      }
+      continue;
+    }
     if (A.mode == 0 && beta == 0.0) {                 // letkf_tools.f90:333-359: nothing to solve
       if (tid == 0) {
         S.meta[2 * it] = 0;
@@ -431,6 +438,7 @@ __global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const Staged
     double* a0 = das ? A.anal + pt * A.sp : nullptr;
     __syncthreads();
 
+    if (mode == 255) continue;                         // (the streaming pass has written this point)
     if (mode == 0) {                                   // beta == 0: letkf_tools.f90:333-359
       for (int e = tid; e < nv * k; e += nthr) {
         const int v = e / k, mm = e - v * k;

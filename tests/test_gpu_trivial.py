@@ -107,7 +107,7 @@ def test_points_without_observations_every_switch(name, k):
 @pytest.mark.parametrize("k", [50, 100, 144])
 def test_points_without_observations_beside_each_solve_path(k):
     """k = 50: one wave per point; 100: two waves per point (the skip sits between workgroup barriers); 144: the staged
-    path, which keeps its own closed form"""
+    path, which hands them to the same pass"""
     _run(k, 96, CONFIGS["rtps_inflated_adaptive_det"], seed=7 + k)
 
 
