@@ -218,8 +218,8 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
   if (wave) {
 #ifdef LETKF_WAVE_PROF
     static unsigned long long* prof_dev = nullptr;
-    if (!prof_dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&prof_dev), 10 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(prof_dev, 0, 10 * sizeof(unsigned long long), c->stream));
+    if (!prof_dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&prof_dev), 24 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(prof_dev, 0, 24 * sizeof(unsigned long long), c->stream));
     a.prof = prof_dev;
 #endif
     if (a.sched) HIP_TRY(hipMemsetAsync(a.sched, 0, 512, c->stream));
@@ -233,7 +233,7 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
                    ",NW=" + (a.k <= 62 ? "1" : "2") + (a.mode == 2 ? ",FUSED" : "") + ">";
 #ifdef LETKF_WAVE_PROF
     {
-      unsigned long long h[10];
+      unsigned long long h[24];
       HIP_TRY(hipMemcpyAsync(h, prof_dev, sizeof(h), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
       unsigned long long tot = 0;
@@ -241,6 +241,9 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
       std::fprintf(stderr, "[letkf prof] wave-time share by phase (s_memtime ticks, all waves):");
       for (int i = 0; i < 10; ++i) std::fprintf(stderr, " p%d=%.1f%%", i, tot ? 100.0 * (double)h[i] / (double)tot : 0.0);
       std::fprintf(stderr, " total=%llu\n", tot);
+      std::fprintf(stderr, "[letkf prof] first wave start .. last wave end: %llu ticks; waves by units done (0..11+):", h[11] - ~h[10]);
+      for (int i = 12; i < 24; ++i) std::fprintf(stderr, " %llu", h[i]);
+      std::fprintf(stderr, "\n");
     }
 #endif
   } else {

@@ -123,27 +123,34 @@ __device__ __forceinline__ long xcd_remap_w(long orig, long n) {
   return base + j;
 }
 
-// Dynamic run scheduling (PointArgs::sched): the run ids [0, n) are cut into 8 contiguous ranges, one per XCD -- the same
-// ranges as the static dealing of round 1, so that neighbouring columns still meet in one L2 -- and every wave (two-wave
-// points: every workgroup) draws its next run from its own XCD's counter; when that range is used up it takes runs from
-// the range that has most left.  A domain whose observations sit in one place (a radar disc: the columns outside have no observation
-// and cost a hundredth of a column inside) left whole XCDs idle under the static dealing (C2-disc: 259 -> 147 ms).
-// `fs` runs of every range are handed out last and in quarters, so that the waves do not end a whole run (C2: a column of
-// 60 points, 14 ms) apart; which points start a quarter -- i.e. start cold -- is a fixed function of the launch shape, so
-// results stay bitwise reproducible from run to run.
-// Returns 8 * run id + (0: the whole run, 4 + s: its quarter s), or -1.  Called by lane 0 of a wave; the counters are 64
-// bytes apart and zeroed by the host before every launch.
+// Dynamic run scheduling (PointArgs::sched).  The runs are handed out in UNITS of `ub` consecutive run ids (1 for runs of
+// 16 points or more; short runs are bundled so that a draw covers ~16 points), and the units [0, n) are cut into 8
+// contiguous ranges, one per XCD -- the same ranges as the static dealing of round 1, so that neighbouring columns still
+// meet in one L2.  Every wave (two-wave points: every workgroup) starts with a unit that is its own by its position in
+// the grid -- no 2048 waves queueing at 8 counters when the kernel starts; on a small grid that is all there is -- and then
+// draws the next one from its XCD's counter (one device-scope atomicAdd, preceded by a load so that a finished range costs
+// no read-modify-write); when that range is used up it takes units from the range that has most left.  A domain whose
+// observations sit in one place (a radar disc: the columns outside have no observation and cost a hundredth of a column
+// inside) left whole XCDs idle under the static dealing (C2-disc: 259 -> 147 ms).
+// `fs` units of every range (ub = 1 only) are handed out last and in quarters, so that the waves do not end a whole run
+// (C2: a column of 60 points, 14 ms) apart: every t-th one, a sample spread over the range, so that the quarters carry the
+// range's average work wherever its observations sit.  Which points start a quarter -- i.e. start cold -- is a fixed
+// function of the launch shape, so results stay bitwise reproducible from run to run.
+// A drawn unit is coded as 8 * unit id + (0: whole, 4 + s: quarter s of its run), -1: nothing left.  The draw functions
+// are called by ONE lane; the counters are 64 bytes apart and zeroed by the host before every launch.
 struct SchedRange {
-  int base, whole, f, t;   // first run id; runs handed out whole; runs handed out in quarters: every t-th one, last
-  __device__ __forceinline__ SchedRange(const int x, const int n, const int fs) {
+  int base, whole, f, t, nstat;   // first unit id; units handed out whole; quartered units: every t-th one, last; units given out statically
+  __device__ __forceinline__ SchedRange(const int x, const int n, const int fs, const int ppw) {
     const int q = n >> 3, r = n & 7, len = q + (x < r ? 1 : 0);
     base = x * q + (x < r ? x : r);
     f = fs < len ? fs : len;
     whole = len - f;
     t = f > 0 ? len / f : 1;
+    const int mine = (((int)gridDim.x - x + 7) >> 3) * ppw;   // waves (workgroups) of the grid that sit on XCD x
+    nstat = mine < units() ? mine : units();
   }
   __device__ __forceinline__ int units() const { return whole + 4 * f; }
-  // unit i of the range -> 8 * run id + (0: the whole run, 4 + s: its quarter s)
+  // hand-out position i of the range -> code
   __device__ __forceinline__ int unit(const int i) const {
     if (i < whole) {
       const int head = f * (t - 1);                       // (whole > 0 implies t >= 2 or f == 0)
@@ -153,12 +160,21 @@ struct SchedRange {
     return 8 * (base + ((i - whole) >> 2) * t + (t - 1)) + 4 + ((i - whole) & 3);
   }
 };
-__device__ __forceinline__ int sched_draw(unsigned* cnt, const int xcd, const int n, const int fs) {
+__device__ __forceinline__ int sched_load(const unsigned* c) {
+  return (int)__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the unit that belongs to wave-slot `slot` (= (blockIdx.x >> 3) * PPW + wave) of XCD `xcd` without asking anybody
+__device__ __forceinline__ int sched_first(const int xcd, const int slot, const int n, const int fs, const int ppw) {
+  const SchedRange own(xcd, n, fs, ppw);
+  return slot < own.nstat ? own.unit(slot) : -1;
+}
+__device__ __forceinline__ int sched_draw(unsigned* cnt, const int xcd, const int n, const int fs, const int ppw) {
   {
-    const SchedRange own(xcd, n, fs);
-    if (own.units() > 0) {
+    const SchedRange own(xcd, n, fs, ppw);
+    const int dyn = own.units() - own.nstat;
+    if (dyn > 0 && sched_load(&cnt[16 * xcd]) < dyn) {
       const int i = (int)atomicAdd(&cnt[16 * xcd], 1u);
-      if (i < own.units()) return own.unit(i);
+      if (i < dyn) return own.unit(own.nstat + i);
     }
   }
   // own range used up: help where most is left (so that all ranges end together, each with its quartered runs last)
@@ -167,16 +183,17 @@ __device__ __forceinline__ int sched_draw(unsigned* cnt, const int xcd, const in
     int best = -1, most = 0;
 #pragma unroll 1
     for (int x = 0; x < 8; ++x) {
-      const int left = SchedRange(x, n, fs).units() - (int)__hip_atomic_load(&cnt[16 * x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const SchedRange rg(x, n, fs, ppw);
+      const int left = rg.units() - rg.nstat - sched_load(&cnt[16 * x]);
       if (left > most) {
         most = left;
         best = x;
       }
     }
     if (best < 0) return -1;
-    const SchedRange rg(best, n, fs);
+    const SchedRange rg(best, n, fs, ppw);
     const int i = (int)atomicAdd(&cnt[16 * best], 1u);
-    if (i < rg.units()) return rg.unit(i);
+    if (i < rg.units() - rg.nstat) return rg.unit(rg.nstat + i);
   }
   return -1;
 }
@@ -489,9 +506,13 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
 // the extra code cost 15 % of its speed (registers / instruction cache), measured.
 // Profiling build (make PROF=1): per-phase wave time from s_memtime, kept in SGPRs, summed over all waves.
 #ifdef LETKF_WAVE_PROF
-#define PROF_DECL unsigned long long prof_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#define PROF_DECL unsigned long long prof_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_amdgcn_s_memtime(); const unsigned long long prof_t0 = prof_last; int prof_units = 0;
 #define PROF_MARK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_t[i] += t_ - prof_last; prof_last = t_; }
-#define PROF_FLUSH if (A.prof && wlane == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&A.prof[i_], prof_t[i_]); }
+// [10]: ~earliest wave start, [11]: latest wave end (s_memtime), [12 + u]: waves that did u units (u capped at 11)
+#define PROF_FLUSH if (A.prof && wlane == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&A.prof[i_], prof_t[i_]); \
+    atomicMax(&A.prof[10], ~prof_t0); atomicMax(&A.prof[11], (unsigned long long)__builtin_amdgcn_s_memtime()); \
+    atomicAdd(&A.prof[12 + (prof_units < 11 ? prof_units : 11)], 1ull); }
+#define PROF_UNIT ++prof_units;
 #else
 #define PROF_DECL
 #ifdef LETKF_MARK_FENCE   // A/B knob (make VARIANT=...): compiler-level fences where the PROF twin reads its clock
@@ -500,6 +521,7 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
 #define PROF_MARK(i)
 #endif
 #define PROF_FLUSH
+#define PROF_UNIT
 #endif
 
 template <int KR, int NV, bool KKOUT, int NW, bool FUSED>
@@ -548,10 +570,22 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
 #ifdef LETKF_WAVE_PROF
   long Bstat = blockIdx.x;
 #endif
-  // runs handed out in quarters at the end of every XCD's range: as many as the XCD has waves (workgroups) in flight
-  const int fsplit = run_len >= 8 ? min((int)(gridDim.x * PPW / 8), NW == 1 ? 256 : 64) : 0;
+  // units of the scheduling: short runs are bundled (a draw should cover ~16 points); whole runs of 8 points or more may
+  // be handed out in quarters at the end of every XCD's range, as many as the XCD has waves (workgroups) in flight
+  // (bundling only while it leaves every wave of the grid four units or more: a small batch keeps one run per draw)
+  int ub = run_len >= 16 ? 1 : (16 + run_len - 1) / run_len;
+  {
+    const long most = nruns / (4L * gridDim.x * PPW);
+    if (ub > most) ub = most < 1 ? 1 : (int)most;
+  }
+  const int nunits = (int)((nruns + ub - 1) / ub);
+  const int fsplit = (ub == 1 && run_len >= 8) ? min((int)(gridDim.x * PPW / 8), NW == 1 ? 256 : 64) : 0;
+  bool first_draw = true;
+  int pend = 0;                                // runs of the drawn unit that are still to do
+  long next_rid = 0;
   for (long it_ = 0; it_ < nruns; ++it_) {
    long rid;
+   int ir0 = 0, ir1 = run_len;
 #ifdef LETKF_WAVE_PROF
    if (!A.sched) {
      // static (PROF twin only, LETKF_AMD_STATIC_SCHED): blocks of PPW consecutive runs, dealt to the workgroups in the
@@ -561,30 +595,45 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
      rid = xcd_remap_w(Bstat, nB) * PPW + wv;
      Bstat += gridDim.x;
      if (rid >= nruns) continue;
-     rid *= 8;
    } else
 #endif
-   {
-     // dynamic: the next run of this XCD's range (or of a neighbour's, once that is used up)
+   if (pend > 0) {
+     rid = next_rid++;
+     --pend;
+   } else {
+     int code;
      if constexpr (NW == 1) {
        int g = -1;
-       if (wlane == 0) g = sched_draw(A.sched, (int)(blockIdx.x & 7), (int)nruns, fsplit);
-       rid = __builtin_amdgcn_readfirstlane(g);
+       if (wlane == 0) {
+         if (first_draw) g = sched_first((int)(blockIdx.x & 7), (int)(blockIdx.x >> 3) * PPW + wv, nunits, fsplit, PPW);
+         if (g < 0) g = sched_draw(A.sched, (int)(blockIdx.x & 7), nunits, fsplit, PPW);
+       }
+       code = __builtin_amdgcn_readfirstlane(g);
      } else {
        int* slot_ = reinterpret_cast<int*>(red + 6);
        __syncthreads();
-       if (threadIdx.x == 0) *slot_ = sched_draw(A.sched, (int)(blockIdx.x & 7), (int)nruns, fsplit);
+       if (threadIdx.x == 0) {
+         int g = -1;
+         if (first_draw) g = sched_first((int)(blockIdx.x & 7), (int)(blockIdx.x >> 3) * PPW + wv, nunits, fsplit, PPW);
+         if (g < 0) g = sched_draw(A.sched, (int)(blockIdx.x & 7), nunits, fsplit, PPW);
+         *slot_ = g;
+       }
        __syncthreads();
-       rid = *slot_;
+       code = *slot_;
      }
-     if (rid < 0) break;
+     first_draw = false;
+     PROF_MARK(9)                              // (PROF twin: the time spent drawing)
+     if (code < 0) break;
+     PROF_UNIT
+     if (code & 4) {
+       ir0 = (code & 3) * run_len >> 2;
+       ir1 = ((code & 3) + 1) * run_len >> 2;
+     }
+     rid = (long)(code >> 3) * ub;
+     const long left = nruns - rid;
+     pend = (int)(left < ub ? left : ub) - 1;
+     next_rid = rid + 1;
    }
-   int ir0 = 0, ir1 = run_len;
-   if (rid & 4) {
-     ir0 = (int)(rid & 3) * run_len >> 2;
-     ir1 = ((int)(rid & 3) + 1) * run_len >> 2;
-   }
-   rid >>= 3;
    const long rchunk = rid / S, rb = rid - rchunk * S;
    const long ra0 = rchunk * run_len;
    bool have_u = false;
@@ -1516,8 +1565,35 @@ static hipError_t launch_wave(const PointArgs& a, int num_cu, hipStream_t st) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((letkf_wave_kernel<KR, NV, KKOUT, NW, FUSED>), dim3(a.wave_grid), dim3(NW == 1 ? 256 : 128), lds, st, a);
-  (void)num_cu;
+  // Dynamic scheduling: a grid of exactly the workgroups that are resident together (every wave owns its first unit by
+  // its position, the rest is drawn; a workgroup that had to wait for a slot would sit on its first unit until the others
+  // have drawn everything else).  The PROF twin's static dealing keeps round 1's oversubscribed grid.
+  int grid = a.wave_grid;
+  if (a.sched) {
+    static int occ = 0;                        // (per instantiation)
+    if (occ == 0) {
+      int nb = 0;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, letkf_wave_kernel<KR, NV, KKOUT, NW, FUSED>,
+                                                                  NW == 1 ? 256 : 128, lds);
+      occ = (e == hipSuccess && nb > 0) ? nb : (NW == 1 ? 2 : 1);
+      (void)hipGetLastError();
+    }
+    const long res = (long)occ * num_cu;
+    const long S = a.warm_stride > 1 ? a.warm_stride : 1, rl = a.run_len > 1 ? a.run_len : 1;
+    const long nruns = S * ((a.npts / S + rl - 1) / rl);
+    constexpr int PPW = NW == 1 ? 4 : 1;
+    if (NW == 1 && nruns < 8 * res * PPW) {
+      // A small batch (fewer than 8 runs per resident wave) on one-wave points: every wave gets exactly one run, by its
+      // position, and the hardware starts the next workgroup when one is done.  Measured with the PROF twin on C2-mini
+      // (2.25 runs per wave): of two waves on a SIMD the older one is served first and draws most of the runs, the
+      // younger one is left with its last run when everything is drawn, alone on its SIMD -- 4.9 ms against 4.4 ms.
+      const long need = 8 * (((nruns + 7) / 8 + PPW - 1) / PPW);
+      if (grid > need) grid = (int)need;
+    } else if (grid > res) {
+      grid = (int)res;
+    }
+  }
+  hipLaunchKernelGGL((letkf_wave_kernel<KR, NV, KKOUT, NW, FUSED>), dim3(grid), dim3(NW == 1 ? 256 : 128), lds, st, a);
   return hipGetLastError();
 }
 
