@@ -202,7 +202,10 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
     if (wbytes > c->warm_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));   // old buffer may still be in use
     if (int rc = ensure_bytes(c, &c->warm_ws, &c->warm_ws_bytes, wbytes)) return rc;
     a.warm_ws = reinterpret_cast<double*>(c->warm_ws);
-    if (!c->sched) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->sched), 512));
+    if (!c->sched) {
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->sched), 512));
+      HIP_TRY(hipMemsetAsync(c->sched, 0, 512, c->stream));   // (later launches reset it themselves when they draw)
+    }
     a.sched = LETKF_KNOB("LETKF_AMD_STATIC_SCHED") ? nullptr : c->sched;   // PROF knob: the static dealing, for A/B runs
     a.warm_dbg = 0;
     if (const char* e = LETKF_KNOB("LETKF_AMD_WARM_DBG")) a.warm_dbg = std::atoi(e);
@@ -222,7 +225,6 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
     HIP_TRY(hipMemsetAsync(prof_dev, 0, 24 * sizeof(unsigned long long), c->stream));
     a.prof = prof_dev;
 #endif
-    if (a.sched) HIP_TRY(hipMemsetAsync(a.sched, 0, 512, c->stream));
     // points without observations / with beta = 0: one streaming pass, thread per point (letkf_trivial.hip)
     if (letkf::trivial_pass_supports(a) && !LETKF_KNOB("LETKF_AMD_NO_TRIVIAL_PASS")) {
       HIP_TRY(letkf::launch_trivial_points(a, c->stream));

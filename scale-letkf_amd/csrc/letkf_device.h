@@ -8,6 +8,19 @@
 
 namespace letkf {
 
+// Plan of the solve kernel's dynamic run scheduling (letkf_wave.hip), worked out on the host for the grid that is
+// launched and read by the kernel from its arguments (scalar loads): per XCD range x of the unit ids
+//   base[x]  first unit id;  whole[x]  units handed out whole;  f[x]  units handed out in quarters (every t[x]-th of
+//   the range, last);  nstat[x]  hand-out positions given to the waves by their position in the grid (no counter);
+//   magic[x] = floor(2^40 / (t[x] - 1)) + 1: i / (t - 1) = (i * magic) >> 40 for i < 2^20
+// ub = runs per unit, nruns = runs in all.
+struct SchedPlan {
+  int base[8], whole[8], f[8], t[8], nstat[8];
+  unsigned long long magic[8];
+  int ub;
+  long nruns;
+};
+
 struct PointArgs {
   int k, nv;
   int mode;            // 0: CSR gather from the obs table (das_letkf body); 1: dense hdxb batch (letkf_core);
@@ -66,6 +79,7 @@ struct PointArgs {
   long warm_stride;           // >= 1: a run walks points p, p + warm_stride, ... (letkf_das_args.warm_stride)
   int skip_trivial;           // points with beta == 0 or without observations were done by letkf_trivial_points_kernel: skip them
   unsigned* sched;            // dynamic run scheduling: 8 counters 64 bytes apart, zeroed before the launch (null: static dealing)
+  SchedPlan plan;             // ... and its plan, filled in by launch_wave_kernel for the grid it launches
   unsigned long long* prof;   // profiling build (-DLETKF_WAVE_PROF) only: per-phase s_memtime totals, else null
 };
 

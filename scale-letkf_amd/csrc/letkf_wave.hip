@@ -123,58 +123,53 @@ __device__ __forceinline__ long xcd_remap_w(long orig, long n) {
   return base + j;
 }
 
-// Dynamic run scheduling (PointArgs::sched).  The runs are handed out in UNITS of `ub` consecutive run ids (1 for runs of
-// 16 points or more; short runs are bundled so that a draw covers ~16 points), and the units [0, n) are cut into 8
-// contiguous ranges, one per XCD -- the same ranges as the static dealing of round 1, so that neighbouring columns still
-// meet in one L2.  Every wave (two-wave points: every workgroup) starts with a unit that is its own by its position in
-// the grid -- no 2048 waves queueing at 8 counters when the kernel starts; on a small grid that is all there is -- and then
-// draws the next one from its XCD's counter (one device-scope atomicAdd, preceded by a load so that a finished range costs
-// no read-modify-write); when that range is used up it takes units from the range that has most left.  A domain whose
-// observations sit in one place (a radar disc: the columns outside have no observation and cost a hundredth of a column
-// inside) left whole XCDs idle under the static dealing (C2-disc: 259 -> 147 ms).
-// `fs` units of every range (ub = 1 only) are handed out last and in quarters, so that the waves do not end a whole run
-// (C2: a column of 60 points, 14 ms) apart: every t-th one, a sample spread over the range, so that the quarters carry the
+// Dynamic run scheduling (PointArgs::sched, PointArgs::plan).  The runs are handed out in UNITS of `ub` consecutive run
+// ids (1 for runs of 16 points or more; short runs are bundled so that a draw covers ~16 points), and the units [0, n) are
+// cut into 8 contiguous ranges, one per XCD -- the same ranges as the static dealing of round 1, so that neighbouring
+// columns still meet in one L2.  Every wave (two-wave points: every workgroup) starts with a unit that is its own by its
+// position in the grid -- no 2048 waves queueing at 8 counters when the kernel starts -- and then draws the next one from
+// its XCD's counter (a device-scope load, so that a finished range costs no read-modify-write, then one atomicAdd by one
+// lane); when that range is used up it takes units from the range that has most left.  A domain whose observations sit
+// in one place (a radar disc: the columns outside have no observation and cost a hundredth of a column inside) left
+// whole XCDs idle under the static dealing (C2-disc: 259 -> 147 ms).
+// f units of every range (ub = 1 only) are handed out last and in quarters, so that the waves do not end a whole run (C2:
+// a column of 60 points, 14 ms) apart: every t-th one, a sample spread over the range, so that the quarters carry the
 // range's average work wherever its observations sit.  Which points start a quarter -- i.e. start cold -- is a fixed
 // function of the launch shape, so results stay bitwise reproducible from run to run.
-// A drawn unit is coded as 8 * unit id + (0: whole, 4 + s: quarter s of its run), -1: nothing left.  The draw functions
-// are called by ONE lane; the counters are 64 bytes apart and zeroed by the host before every launch.
-struct SchedRange {
-  int base, whole, f, t, nstat;   // first unit id; units handed out whole; quartered units: every t-th one, last; units given out statically
-  __device__ __forceinline__ SchedRange(const int x, const int n, const int fs, const int ppw) {
-    const int q = n >> 3, r = n & 7, len = q + (x < r ? 1 : 0);
-    base = x * q + (x < r ? x : r);
-    f = fs < len ? fs : len;
-    whole = len - f;
-    t = f > 0 ? len / f : 1;
-    const int mine = (((int)gridDim.x - x + 7) >> 3) * ppw;   // waves (workgroups) of the grid that sit on XCD x
-    nstat = mine < units() ? mine : units();
-  }
-  __device__ __forceinline__ int units() const { return whole + 4 * f; }
-  // hand-out position i of the range -> code
-  __device__ __forceinline__ int unit(const int i) const {
-    if (i < whole) {
-      const int head = f * (t - 1);                       // (whole > 0 implies t >= 2 or f == 0)
-      const int g = i < head ? i / (t - 1) : 0;
-      return 8 * (base + (i < head ? g * t + (i - g * (t - 1)) : f * t + (i - head)));
+// A drawn unit is coded as 8 * unit id + (0: whole, 4 + s: quarter s of its run), -1: nothing left.
+// Everything here is wave-uniform and written so that it stays in scalar registers (the plan comes from the kernel
+// arguments; the one division is a multiplication by a host-made reciprocal): the first version did this arithmetic in
+// lane 0's vector registers, and the vector registers it needed around every draw cost the kernel 250 B/lane of scratch
+// and 50 GB of spill traffic per C2 launch.
+__device__ __forceinline__ int sched_unit(const SchedPlan& P, const int x, const int i) {
+  const int whole = P.whole[x], f = P.f[x], t = P.t[x], base = P.base[x];
+  if (i < whole) {
+    const int head = f * (t - 1);
+    if (i < head) {
+      const int g = (int)(((unsigned long long)(unsigned)i * P.magic[x]) >> 40);   // i / (t - 1)
+      return 8 * (base + g * t + (i - g * (t - 1)));
     }
-    return 8 * (base + ((i - whole) >> 2) * t + (t - 1)) + 4 + ((i - whole) & 3);
+    return 8 * (base + f * t + (i - head));
   }
-};
-__device__ __forceinline__ int sched_load(const unsigned* c) {
-  return (int)__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return 8 * (base + ((i - whole) >> 2) * t + (t - 1)) + 4 + ((i - whole) & 3);
 }
-// the unit that belongs to wave-slot `slot` (= (blockIdx.x >> 3) * PPW + wave) of XCD `xcd` without asking anybody
-__device__ __forceinline__ int sched_first(const int xcd, const int slot, const int n, const int fs, const int ppw) {
-  const SchedRange own(xcd, n, fs, ppw);
-  return slot < own.nstat ? own.unit(slot) : -1;
+// the same word in every lane, as a scalar
+__device__ __forceinline__ int sched_peek(const unsigned* c) {
+  return __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-__device__ __forceinline__ int sched_draw(unsigned* cnt, const int xcd, const int n, const int fs, const int ppw) {
+__device__ __forceinline__ int sched_take(unsigned* c) {
+  int i = 0;
+  if ((threadIdx.x & 63) == 0) i = (int)atomicAdd(c, 1u);
+  return __builtin_amdgcn_readfirstlane(i);
+}
+// called by a whole wave; slot = the wave's (workgroup's) position among those of its XCD, or -1 after its first unit
+__device__ __forceinline__ int sched_next(const SchedPlan& P, unsigned* cnt, const int xcd, const int slot) {
+  if (slot >= 0 && slot < P.nstat[xcd]) return sched_unit(P, xcd, slot);
   {
-    const SchedRange own(xcd, n, fs, ppw);
-    const int dyn = own.units() - own.nstat;
-    if (dyn > 0 && sched_load(&cnt[16 * xcd]) < dyn) {
-      const int i = (int)atomicAdd(&cnt[16 * xcd], 1u);
-      if (i < dyn) return own.unit(own.nstat + i);
+    const int dyn = P.whole[xcd] + 4 * P.f[xcd] - P.nstat[xcd];
+    if (dyn > 0 && sched_peek(&cnt[16 * xcd]) < dyn) {
+      const int i = sched_take(&cnt[16 * xcd]);
+      if (i < dyn) return sched_unit(P, xcd, P.nstat[xcd] + i);
     }
   }
   // own range used up: help where most is left (so that all ranges end together, each with its quartered runs last)
@@ -183,19 +178,45 @@ __device__ __forceinline__ int sched_draw(unsigned* cnt, const int xcd, const in
     int best = -1, most = 0;
 #pragma unroll 1
     for (int x = 0; x < 8; ++x) {
-      const SchedRange rg(x, n, fs, ppw);
-      const int left = rg.units() - rg.nstat - sched_load(&cnt[16 * x]);
+      const int left = P.whole[x] + 4 * P.f[x] - P.nstat[x] - sched_peek(&cnt[16 * x]);
       if (left > most) {
         most = left;
         best = x;
       }
     }
     if (best < 0) return -1;
-    const SchedRange rg(best, n, fs, ppw);
-    const int i = (int)atomicAdd(&cnt[16 * best], 1u);
-    if (i < rg.units() - rg.nstat) return rg.unit(rg.nstat + i);
+    const int i = sched_take(&cnt[16 * best]);
+    if (i < P.whole[best] + 4 * P.f[best] - P.nstat[best]) return sched_unit(P, best, P.nstat[best] + i);
   }
   return -1;
+}
+
+// host: the plan for a grid of `grid` workgroups with ppw wave-slots each, `resident` wave-slots in flight per XCD
+static void sched_make_plan(SchedPlan& P, const long npts, const long stride, const int run_len, const int grid, const int ppw,
+                            const int resident_per_xcd) {
+  const long S = stride > 1 ? stride : 1, rl = run_len > 1 ? run_len : 1;
+  const long nruns = S * ((npts / S + rl - 1) / rl);
+  // short runs are bundled (a draw should cover ~16 points), as long as that leaves every wave-slot of the grid four units
+  int ub = rl >= 16 ? 1 : (int)((16 + rl - 1) / rl);
+  const long most = nruns / (4L * grid * ppw);
+  if (ub > most) ub = most < 1 ? 1 : (int)most;
+  const long n = (nruns + ub - 1) / ub;
+  // whole runs of 8 points or more may be quartered at the end of a range: as many as the XCD has wave-slots in flight
+  const int fs = (ub == 1 && rl >= 8) ? ((long)grid * ppw / 8 < resident_per_xcd ? (int)((long)grid * ppw / 8) : resident_per_xcd) : 0;
+  const int q = (int)(n >> 3), r = (int)(n & 7);
+  for (int x = 0; x < 8; ++x) {
+    const int len = q + (x < r ? 1 : 0);
+    P.base[x] = x * q + (x < r ? x : r);
+    P.f[x] = fs < len ? fs : len;
+    P.whole[x] = len - P.f[x];
+    P.t[x] = P.f[x] > 0 ? len / P.f[x] : 1;
+    const long mine = (long)((grid - x + 7) >> 3) * ppw;              // wave-slots of the grid that sit on XCD x
+    const long units = (long)P.whole[x] + 4L * P.f[x];
+    P.nstat[x] = (int)(mine < units ? mine : units);
+    P.magic[x] = P.t[x] > 1 ? ((1ull << 40) / (unsigned long long)(P.t[x] - 1)) + 1ull : 0ull;
+  }
+  P.ub = ub;
+  P.nruns = nruns;
 }
 
 constexpr int kTnW = 8;               // obs rows per LDS tile (per wave)
@@ -563,33 +584,23 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
   // the points as an array [nA][S], p = a S + b: a run walks a at fixed b (S = 1: consecutive points; S = nij1 with
   // gues3d's point order: up a column), run number = chunk * S + b -- neighbouring runs are neighbouring columns
   const long S = A.warm_stride, nA = A.npts / S;
-  const long nruns = S * ((nA + run_len - 1) / run_len);
   // this wave's slot of the warm-start workspace: [KR][NL] doubles, lane-fastest
   double* uws = (WARM && run_len > 1) ? A.warm_ws + ((size_t)blockIdx.x * PPW + wv) * ((size_t)KR * NL) + lane : nullptr;
   PROF_DECL
 #ifdef LETKF_WAVE_PROF
   long Bstat = blockIdx.x;
 #endif
-  // units of the scheduling: short runs are bundled (a draw should cover ~16 points); whole runs of 8 points or more may
-  // be handed out in quarters at the end of every XCD's range, as many as the XCD has waves (workgroups) in flight
-  // (bundling only while it leaves every wave of the grid four units or more: a small batch keeps one run per draw)
-  int ub = run_len >= 16 ? 1 : (16 + run_len - 1) / run_len;
-  {
-    const long most = nruns / (4L * gridDim.x * PPW);
-    if (ub > most) ub = most < 1 ? 1 : (int)most;
-  }
-  const int nunits = (int)((nruns + ub - 1) / ub);
-  const int fsplit = (ub == 1 && run_len >= 8) ? min((int)(gridDim.x * PPW / 8), NW == 1 ? 256 : 64) : 0;
   bool first_draw = true;
   int pend = 0;                                // runs of the drawn unit that are still to do
   long next_rid = 0;
-  for (long it_ = 0; it_ < nruns; ++it_) {
+  for (;;) {
    long rid;
    int ir0 = 0, ir1 = run_len;
 #ifdef LETKF_WAVE_PROF
    if (!A.sched) {
      // static (PROF twin only, LETKF_AMD_STATIC_SCHED): blocks of PPW consecutive runs, dealt to the workgroups in the
      // order of their XCDs -- what the production kernel did before the dynamic scheduling
+     const long nruns = S * ((nA + run_len - 1) / run_len);
      const long nB = (nruns + PPW - 1) / PPW;
      if (Bstat >= nB) break;
      rid = xcd_remap_w(Bstat, nB) * PPW + wv;
@@ -602,21 +613,15 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
      --pend;
    } else {
      int code;
+     const int slot0 = first_draw ? (int)(blockIdx.x >> 3) * PPW + __builtin_amdgcn_readfirstlane(wv) : -1;
      if constexpr (NW == 1) {
-       int g = -1;
-       if (wlane == 0) {
-         if (first_draw) g = sched_first((int)(blockIdx.x & 7), (int)(blockIdx.x >> 3) * PPW + wv, nunits, fsplit, PPW);
-         if (g < 0) g = sched_draw(A.sched, (int)(blockIdx.x & 7), nunits, fsplit, PPW);
-       }
-       code = __builtin_amdgcn_readfirstlane(g);
+       code = sched_next(A.plan, A.sched, (int)(blockIdx.x & 7), slot0);
      } else {
        int* slot_ = reinterpret_cast<int*>(red + 6);
        __syncthreads();
-       if (threadIdx.x == 0) {
-         int g = -1;
-         if (first_draw) g = sched_first((int)(blockIdx.x & 7), (int)(blockIdx.x >> 3) * PPW + wv, nunits, fsplit, PPW);
-         if (g < 0) g = sched_draw(A.sched, (int)(blockIdx.x & 7), nunits, fsplit, PPW);
-         *slot_ = g;
+       if (threadIdx.x < 64) {                  // (wave 0 draws for the workgroup)
+         const int g = sched_next(A.plan, A.sched, (int)(blockIdx.x & 7), slot0);
+         if (threadIdx.x == 0) *slot_ = g;
        }
        __syncthreads();
        code = *slot_;
@@ -629,9 +634,9 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
        ir0 = (code & 3) * run_len >> 2;
        ir1 = ((code & 3) + 1) * run_len >> 2;
      }
-     rid = (long)(code >> 3) * ub;
-     const long left = nruns - rid;
-     pend = (int)(left < ub ? left : ub) - 1;
+     rid = (long)(code >> 3) * A.plan.ub;
+     const long left = A.plan.nruns - rid;
+     pend = (int)(left < A.plan.ub ? left : A.plan.ub) - 1;
      next_rid = rid + 1;
    }
    const long rchunk = rid / S, rb = rid - rchunk * S;
@@ -1593,7 +1598,19 @@ static hipError_t launch_wave(const PointArgs& a, int num_cu, hipStream_t st) {
       grid = (int)res;
     }
   }
-  hipLaunchKernelGGL((letkf_wave_kernel<KR, NV, KKOUT, NW, FUSED>), dim3(grid), dim3(NW == 1 ? 256 : 128), lds, st, a);
+  PointArgs b = a;
+  if (a.sched) {
+    sched_make_plan(b.plan, a.npts, a.warm_stride, a.run_len, grid, NW == 1 ? 4 : 1, NW == 1 ? 256 : 64);
+    // the counters start at zero -- unless every unit is given out by position (a small batch): then nothing is drawn,
+    // and whatever non-negative counts an earlier launch left behind read as "nothing left"
+    bool draws = false;
+    for (int x = 0; x < 8; ++x) draws = draws || b.plan.whole[x] + 4 * b.plan.f[x] > b.plan.nstat[x];
+    if (draws) {
+      hipError_t e = hipMemsetAsync(a.sched, 0, 512, st);
+      if (e != hipSuccess) return e;
+    }
+  }
+  hipLaunchKernelGGL((letkf_wave_kernel<KR, NV, KKOUT, NW, FUSED>), dim3(grid), dim3(NW == 1 ? 256 : 128), lds, st, b);
   return hipGetLastError();
 }
 

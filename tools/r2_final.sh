@@ -13,7 +13,7 @@ echo "== variants"
 timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --ensval correlated 2>/dev/null | tee $O/bench_c2_correlated.json | j C2-correlated
 timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --max-nobs 100 2>/dev/null | tee $O/bench_c2_maxnobs100.json | j C2-maxnobs100
 timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-search-in-step 2>/dev/null | tee $O/bench_c2_solveonly.json | j C2-solve-only
-for w in C2-mini C2-mini-k20 C2-mini-k100 C2-slab-k100 C4-slab C4-mini C3-mini C3-slab C5-slab; do
+for w in C2-mini C2-mini-k20 C2-mini-k100 C2-slab-k100 C2-cols-k100 C2-disc C2-mini-disc C2-mini-sparse C4-slab C4-mini C3-mini C3-slab C5-slab; do
   timeout -k 10 300 python bench.py --workload $w --steps 3 --warmup 1 --cpu-seconds 4 2>/dev/null | tee $O/bench_$w.json | j $w
 done
 echo "== staged kernels"
