@@ -482,6 +482,13 @@ int letkf_ctx_last_path(letkf_ctx *ctx, char *buf, int32_t len);
 int letkf_ctx_timing_enable(letkf_ctx *ctx, int enable);
 int letkf_ctx_timing_read(letkf_ctx *ctx, double *avg_ms, int64_t *nlaunch, int reset);
 
+/* Self-check of the solve kernel's run scheduling (host only, no device needed): builds the plan that a launch over
+ * npts points with warm-start stride `stride`, runs of run_len points and a grid of `grid` workgroups (ppw wave-slots
+ * each, resident_per_xcd of them in flight per XCD) would use, walks every hand-out position of every range through the
+ * same code the kernel runs, and returns 0 iff every run is handed out exactly once -- whole, or as its four quarters.
+ * For the CPU test suite (tests/test_sched_plan.py). */
+int letkf_sched_plan_check(int64_t npts, int64_t stride, int32_t run_len, int32_t grid, int32_t ppw, int32_t resident_per_xcd);
+
 #ifdef __cplusplus
 }
 #endif

@@ -221,8 +221,8 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
   if (wave) {
 #ifdef LETKF_WAVE_PROF
     static unsigned long long* prof_dev = nullptr;
-    if (!prof_dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&prof_dev), 24 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(prof_dev, 0, 24 * sizeof(unsigned long long), c->stream));
+    if (!prof_dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&prof_dev), 26 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(prof_dev, 0, 26 * sizeof(unsigned long long), c->stream));
     a.prof = prof_dev;
 #endif
     // points without observations / with beta = 0: one streaming pass, thread per point (letkf_trivial.hip)
@@ -235,7 +235,7 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
                    ",NW=" + (a.k <= 62 ? "1" : "2") + (a.mode == 2 ? ",FUSED" : "") + ">";
 #ifdef LETKF_WAVE_PROF
     {
-      unsigned long long h[24];
+      unsigned long long h[26];
       HIP_TRY(hipMemcpyAsync(h, prof_dev, sizeof(h), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
       unsigned long long tot = 0;
@@ -245,7 +245,7 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
       std::fprintf(stderr, " total=%llu\n", tot);
       std::fprintf(stderr, "[letkf prof] first wave start .. last wave end: %llu ticks; waves by units done (0..11+):", h[11] - ~h[10]);
       for (int i = 12; i < 24; ++i) std::fprintf(stderr, " %llu", h[i]);
-      std::fprintf(stderr, "\n");
+      std::fprintf(stderr, "; units done in all: %llu\n", h[24]);
     }
 #endif
   } else {
@@ -405,6 +405,10 @@ int letkf_ctx_synchronize(letkf_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return LETKF_OK;
+}
+
+int letkf_sched_plan_check(int64_t npts, int64_t stride, int32_t run_len, int32_t grid, int32_t ppw, int32_t resident_per_xcd) {
+  return letkf::sched_plan_check((long)npts, (long)stride, run_len, grid, ppw, resident_per_xcd);
 }
 
 int letkf_ctx_last_path(letkf_ctx* c, char* buf, int32_t len) {

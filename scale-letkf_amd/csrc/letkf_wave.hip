@@ -17,6 +17,7 @@
 //                   scale/letkf/letkf_tools.f90:457-513.  T / Pa themselves are only formed on request.
 
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdint.h>
 
 #include <cstdlib>
@@ -141,7 +142,7 @@ __device__ __forceinline__ long xcd_remap_w(long orig, long n) {
 // arguments; the one division is a multiplication by a host-made reciprocal): the first version did this arithmetic in
 // lane 0's vector registers, and the vector registers it needed around every draw cost the kernel 250 B/lane of scratch
 // and 50 GB of spill traffic per C2 launch.
-__device__ __forceinline__ int sched_unit(const SchedPlan& P, const int x, const int i) {
+__host__ __device__ __forceinline__ int sched_unit(const SchedPlan& P, const int x, const int i) {
   const int whole = P.whole[x], f = P.f[x], t = P.t[x], base = P.base[x];
   if (i < whole) {
     const int head = f * (t - 1);
@@ -495,6 +496,34 @@ __device__ __forceinline__ void warm_start_product_mfma(double (&g)[KR], const d
 
 }  // namespace
 
+// include/letkf_amd.h, letkf_sched_plan_check: every run exactly once (whole or as four quarters)?
+int sched_plan_check(long npts, long stride, int run_len, int grid, int ppw, int resident_per_xcd) {
+  if (npts < 0 || grid < 1 || ppw < 1 || run_len < 1) return -1;
+  SchedPlan P;
+  sched_make_plan(P, npts, stride, run_len, grid, ppw, resident_per_xcd);
+  if (P.nruns > (1L << 27)) return -2;
+  std::vector<unsigned char> seen((size_t)P.nruns, 0);   // bit 7: whole, bits 0-3: quarters
+  for (int x = 0; x < 8; ++x) {
+    if (P.nstat[x] < 0 || P.nstat[x] > P.whole[x] + 4 * P.f[x]) return -3;
+    for (int i = 0; i < P.whole[x] + 4 * P.f[x]; ++i) {
+      const int code = sched_unit(P, x, i);
+      const long u = code >> 3;
+      for (long rid = u * P.ub; rid < (u + 1) * P.ub && rid < P.nruns; ++rid) {
+        if (rid < 0) return -4;
+        const unsigned char bit = (code & 4) ? (unsigned char)(1u << (code & 3)) : (unsigned char)0x80;
+        if ((code & 4) && P.ub != 1) return -5;
+        if (seen[(size_t)rid] & (bit | ((code & 4) ? 0x80 : 0x0f))) return -6;    // handed out twice
+        seen[(size_t)rid] |= bit;
+      }
+      if (u * P.ub >= P.nruns) return -7;                                          // a unit beyond the last run
+    }
+  }
+  for (long rid = 0; rid < P.nruns; ++rid)
+    if (seen[(size_t)rid] != 0x80 && seen[(size_t)rid] != 0x0f) return -8;         // missed, or quartered in part
+  return 0;
+}
+
+
 // smallest k the instantiation <KR, NW> is dispatched for (launch_wave_kernel walks the instances in this order)
 __host__ __device__ constexpr int wave_kmin(int KR, int NW) {
   return NW == 1 ? (KR == 16 ? 1 : KR == 32 ? 17 : KR == 48 ? 33 : KR == 50 ? 49 : KR == 64 ? 51 : 1)
@@ -529,10 +558,11 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
 #ifdef LETKF_WAVE_PROF
 #define PROF_DECL unsigned long long prof_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_amdgcn_s_memtime(); const unsigned long long prof_t0 = prof_last; int prof_units = 0;
 #define PROF_MARK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_t[i] += t_ - prof_last; prof_last = t_; }
-// [10]: ~earliest wave start, [11]: latest wave end (s_memtime), [12 + u]: waves that did u units (u capped at 11)
+// [10]: ~earliest wave start, [11]: latest wave end (s_memtime), [12 + u]: waves that did u units (u capped at 11),
+// [24]: units done in all (= the plan's units if every one was drawn exactly once)
 #define PROF_FLUSH if (A.prof && wlane == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&A.prof[i_], prof_t[i_]); \
     atomicMax(&A.prof[10], ~prof_t0); atomicMax(&A.prof[11], (unsigned long long)__builtin_amdgcn_s_memtime()); \
-    atomicAdd(&A.prof[12 + (prof_units < 11 ? prof_units : 11)], 1ull); }
+    atomicAdd(&A.prof[12 + (prof_units < 11 ? prof_units : 11)], 1ull); atomicAdd(&A.prof[24], (unsigned long long)prof_units); }
 #define PROF_UNIT ++prof_units;
 #else
 #define PROF_DECL
@@ -613,7 +643,11 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
      --pend;
    } else {
      int code;
+#ifdef LETKF_SCHED_RFL   // A/B knob: with the wave number made scalar here hipcc's allocation of the whole kernel changes (scratch 388 -> 612 B/lane)
      const int slot0 = first_draw ? (int)(blockIdx.x >> 3) * PPW + __builtin_amdgcn_readfirstlane(wv) : -1;
+#else
+     const int slot0 = first_draw ? (int)(blockIdx.x >> 3) * PPW + wv : -1;
+#endif
      if constexpr (NW == 1) {
        code = sched_next(A.plan, A.sched, (int)(blockIdx.x & 7), slot0);
      } else {
