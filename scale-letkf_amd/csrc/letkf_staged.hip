@@ -44,7 +44,16 @@ __device__ __forceinline__ double wsum(double v) {
 constexpr int kGT = 4;         // Gram register tile
 constexpr int kGMaxT = 3;      // tiles per thread and pass
 constexpr int kGBlock = 512;
-constexpr int kABlock = 512;
+#ifndef STAGE_APPLY_BLOCK
+#define STAGE_APPLY_BLOCK 512
+#endif
+#ifndef STAGE_APPLY_MINWG
+#define STAGE_APPLY_MINWG 1
+#endif
+#ifndef STAGE_APPLY_LDSCAP
+#define STAGE_APPLY_LDSCAP (150 * 1024)
+#endif
+constexpr int kABlock = STAGE_APPLY_BLOCK;
 constexpr int kMaxNb = 16;     // right-hand sides: nv + 2 <= 16
 
 struct Slab {
@@ -406,7 +415,7 @@ __device__ __forceinline__ int ov_n_of(const PointArgs& A, long pt) {
 }
 
 // LDS: lam [k] | tau [k] | pi [k] | om [k] | swl [k] | small [8 nv + 32] | P / C, q
-__global__ void __launch_bounds__(kABlock) letkf_stage_apply_kernel(const StagedArgs S, const int pcq_doubles) {
+__global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_kernel(const StagedArgs S, const int pcq_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const PointArgs& A = S.A;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
@@ -820,7 +829,7 @@ hipError_t launch_stage_apply(const StagedArgs& s, hipStream_t st) {
   const size_t fixed = (size_t)5 * (k + 2) + 8 * (size_t)s.A.nv + 32;
   // room for P / C (primal: up to k + 2 columns) and, while it fits, for q as well (dual: two matrices of ~n columns)
   size_t pcq = (size_t)2 * nb * (k + 4);
-  while ((fixed + pcq) * sizeof(double) > 150 * 1024 && pcq > 0) pcq = pcq > (size_t)nb * 64 ? pcq - (size_t)nb * 64 : 0;
+  while ((fixed + pcq) * sizeof(double) > STAGE_APPLY_LDSCAP && pcq > 0) pcq = pcq > (size_t)nb * 64 ? pcq - (size_t)nb * 64 : 0;
   const size_t lds = (fixed + pcq) * sizeof(double);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_stage_apply_kernel),
