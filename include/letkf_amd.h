@@ -60,6 +60,13 @@ int letkf_ctx_destroy(letkf_ctx *ctx);
  * default (null) stream.  A fresh context runs on its own non-blocking stream until this is called. */
 int letkf_ctx_set_stream(letkf_ctx *ctx, void *hip_stream);
 int letkf_ctx_synchronize(letkf_ctx *ctx);
+/* Options of a context.  LETKF_OPT_STAGED_POLY (default 1): on the staged path (k > 100) a grid point with fewer local
+ * observations than members whose loop body returns no k x k matrix is analysed without an eigen-decomposition -- the
+ * transform and w-bar are Chebyshev expansions in the n x n matrix Z Z^T + (k-1)/rho I applied to the right-hand sides
+ * (same result to rounding); 0: every such point goes through the Jacobi eigen stage (what replaces
+ * common/common_mtx.f90:41 mtx_eigen), as points with n >= k or with trans / Pa outputs always do. */
+#define LETKF_OPT_STAGED_POLY 1
+int letkf_ctx_set_option(letkf_ctx *ctx, int option, int value);
 
 /*---------------------------------------------------------------------------
  * (1) Fine boundary, host pointers, one problem:

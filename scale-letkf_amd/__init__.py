@@ -130,7 +130,7 @@ class BetaParams(C.Structure):
 
 
 EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", "letkf_ctx_destroy",
-           "letkf_ctx_set_stream", "letkf_ctx_synchronize", "letkf_core_c", "letkf_core_batch_dev",
+           "letkf_ctx_set_stream", "letkf_ctx_set_option", "letkf_ctx_synchronize", "letkf_core_c", "letkf_core_batch_dev",
            "letkf_das_points_dev", "letkf_das_points_fused_dev", "letkf_obs_search_dev", "letkf_obs_search_columns_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
            "letkf_state_trans_dev", "letkf_member_points_dev", "letkf_ens_spread_dev",
            "letkf_obs_departure_dev", "letkf_obs_mesh_sort_dev", "letkf_obs_halo_plan_dev",
@@ -195,6 +195,11 @@ class Context:
 
     def set_stream(self, stream_handle):
         self._check(self._l.letkf_ctx_set_stream(self._c, C.c_void_p(stream_handle)))
+
+    OPT_STAGED_POLY = 1     # include/letkf_amd.h LETKF_OPT_STAGED_POLY
+
+    def set_option(self, option, value):
+        self._check(self._l.letkf_ctx_set_option(self._c, C.c_int(option), C.c_int(value)))
 
     def synchronize(self):
         self._check(self._l.letkf_ctx_synchronize(self._c))

@@ -53,6 +53,7 @@ struct letkf_ctx {
   size_t staged_ws_bytes = 0;
   std::string last_path;      // kernels the last loop-body / letkf_core launch went through (bench.py reports it)
   bool timing = false;
+  bool staged_poly = true;    // LETKF_OPT_STAGED_POLY
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 };
 
@@ -288,6 +289,9 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
   s.info = s.meta + 2 * nb;
   s.kkout = kkout;
   s.wg_max_order = letkf::eig_wg_max_order();
+  // eigen-free observation-space points (letkf_staged.hip, poly_apply): the loop body without k x k outputs
+  s.poly_max_n = (a.mode == 0 && !kkout && c->staged_poly) ? letkf::stage_poly_max_n(a.k, a.nv) : 0;
+  s.poly_max_deg = 64;
   s.A.max_sweep = 60;
   EventPair ev;
   if (c->timing) {
@@ -320,7 +324,7 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
     c->events.emplace_back(ev.e0, ev.e1);
     ev.e0 = ev.e1 = nullptr;
   }
-  c->last_path = std::string("staged: letkf_stage_gram_kernel + ") +
+  c->last_path = std::string("staged: letkf_stage_gram_kernel + ") + (s.poly_max_n > 0 ? "[n < k: Chebyshev apply, no eigen stage] " : "") +
                  (a.k <= 128 ? "letkf_eig_wg_kernel<4,32,32,1>" : "letkf_eig_wg_kernel<4,52,16,2>") +
                  (a.k > s.wg_max_order ? " / letkf_eig_block_kernel" : "") + " + letkf_stage_apply_kernel";
   return LETKF_OK;
@@ -391,6 +395,14 @@ int letkf_ctx_destroy(letkf_ctx* c) {
   }
   delete c;
   return LETKF_OK;
+}
+
+int letkf_ctx_set_option(letkf_ctx* c, int option, int value) {
+  if (!c) return fail(LETKF_E_INVALID, "null context");
+  switch (option) {
+    case LETKF_OPT_STAGED_POLY: c->staged_poly = value != 0; return LETKF_OK;
+    default: return fail(LETKF_E_INVALID, "unknown option");
+  }
 }
 
 int letkf_ctx_set_stream(letkf_ctx* c, void* hip_stream) {

@@ -104,7 +104,11 @@ struct StagedArgs {
   int* info;
   int kkout;           // slab carries W (k x k outputs requested)
   int wg_max_order;    // largest order the workgroup Jacobi takes
+  int poly_max_n;      // eigen-free observation-space points (letkf_staged.hip, "polynomial path"): most rows, 0 = off
+  int poly_max_deg;    // ... and the highest Chebyshev degree worth it (above: the Jacobi)
 };
+int stage_apply_pcq_doubles(int k, int nv);
+int stage_poly_max_n(int k, int nv);
 size_t eig_wg_lds_bytes(int NP, int RP, int RBR, int SB);
 int eig_wg_max_order();
 hipError_t launch_eig_wg(const EigArgs& e, int mcap, int num_cu, hipStream_t st);

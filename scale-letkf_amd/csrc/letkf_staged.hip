@@ -356,6 +356,49 @@ __global__ void __launch_bounds__(kGBlock) letkf_stage_gram_kernel(const StagedA
       sl.SC[1] = red[1];
       sl.SC[2] = red[2];
     }
+    // ---- polynomial path (stage 3, "eigen-free"): M = S + c I with S = Z Z^T positive semi-definite, so M's spectrum
+    // lies in [c, c + |S|] for any norm bound |S| >= lambda_max(S); the smaller of the Frobenius norm and the largest
+    // absolute row sum is free here (M is in L2).  cond = (c + |S|) / c fixes the Chebyshev degree that reaches 1e-16 for
+    // functions analytic away from 0 (1/x, the T and Pa spectra): rate (sqrt(cond) - 1) / (sqrt(cond) + 1) per degree.
+    if (S.poly_max_n > 0 && dual && m >= 2 && m <= S.poly_max_n && m <= nthr) {
+      __syncthreads();                                // (G complete: every thread's stores; red[] read above)
+      double fs = 0.0, rs = 0.0;
+      if (tid < m) {
+        for (int c = 0; c < m; ++c) {
+          double v = sl.G[(size_t)c * ldg + tid];
+          if (c == tid) v -= shift;
+          fs = fma(v, v, fs);
+          rs += fabs(v);
+        }
+      }
+      fs = wsum(fs);
+#pragma unroll
+      for (int mk = 1; mk < 64; mk <<= 1) rs = fmax(rs, __shfl_xor(rs, mk, 64));
+      if ((tid & 63) == 0) {                          // per-wave partials (sqrt(w) in swl is no longer needed), summed in a fixed order
+        swl[tid >> 6] = fs;
+        swl[16 + (tid >> 6)] = rs;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double f2 = 0.0, r1 = 0.0;
+        for (int w = 0; w < (nthr >> 6); ++w) {
+          f2 += swl[w];
+          r1 = fmax(r1, swl[16 + w]);
+        }
+        const double bound = fmin(sqrt(f2), r1) * (1.0 + 1e-12);
+        const double sk = sqrt((shift + bound) / shift);
+        const double rate = (sk - 1.0) / (sk + 1.0);
+        int deg = rate > 0.0 ? (int)ceil(log(1e-16) / log(rate)) + 1 : 4;
+        if (deg < 4) deg = 4;
+        if (bound >= 0.0 && deg <= S.poly_max_deg) {  // (a NaN anywhere fails both tests: the Jacobi path reports it)
+          S.meta[2 * it] = 2 | (3 << 8);
+          S.info[2 * it] = 0;                         // no sweeps ...
+          S.info[2 * it + 1] = 1;                     // ... and nothing that could fail to converge
+          sl.SC[5] = bound;
+          sl.SC[6] = (double)deg;
+        }
+      }
+    }
   }
 }
 
@@ -406,6 +449,131 @@ __device__ __forceinline__ void rows_comb(const double* __restrict__ Cm, const i
     for (int b = 0; b < kMaxNb; ++b)
       if (b < nbr) O[(size_t)b * ldo + i] = acc[b];
   }
+}
+
+// ---------------------------------------------------------------- the polynomial ("eigen-free") apply, observation space
+// Everything stage 3 takes from the eigen-decomposition M = U L U^T of the n x n matrix M = Z Z^T + c I is a FUNCTION of M
+// applied to a handful of vectors: q_b = U g(L) U^T t_b for the nb right-hand sides t_0,1 = sqrt(w) dep(_det), t_2+v = Z x'_v,
+// with g = 1/L for w-bar and g = the T spectrum -sqrt(k-1) / (sqrt(c) sqrt(L) (sqrt(c) + sqrt(L))) for the members, plus the
+// quadratic forms t^T M^-1 t of RTPS (var_a, letkf_tools.f90:1981-1990).  The shift c = (k-1)/rho keeps cond(M) small
+// (C3 / C5: 1.5 exact, ~3 with the free norm bound of stage 1), so a Chebyshev expansion of g on [c, c + |S|] reaches
+// 1e-16 in ~20-30 terms: 2 n^2 nb flops each -- a third of the flops of the Jacobi's ~9 sweeps, and regular, barrier-
+// per-degree work instead of a latency-bound iteration.  The functions are analytic on the interval (the nearest
+// singularity is L = 0), the coefficients come from interpolation at the Chebyshev nodes of the point's own interval.
+// Thread i owns row i (n <= blockDim.x): T_d[b][i] in registers, the current T_d of all rows in LDS ([row][NBP], read as
+// broadcasts), ping-pong, one barrier per degree.  On return q_b[i] sits in pcq[b * nq + i] and va[v] = t_v^T M^-1 t_v.
+// The nbr right-hand sides are dealt to PARTS of the workgroup, NBL to each (part h = threads [h R, (h + 1) R), R = the
+// rows rounded up to whole wavefronts): n <= 64: 2 per part, <= 128: 4, <= 256: 8, above: all 16 in one part -- more
+// loads of M in flight per CU (the iteration is bound by the latency of streaming M from L2 / MALL once per degree:
+// 320 KB at n = 200, too much for LDS next to the buffers) and few enough registers per thread to keep 8 rows of loads
+// ahead of their use.
+template <int NBL>
+__device__ __forceinline__ void poly_apply(const Slab& sl, const int n, const int ldg, const int k, const int nv, const int nbr,
+                                           const double shift, const double sqc, const double sqkm1, double* fw, double* ft,
+                                           double* cw, double* ct, double* pcq, const int nq, double* va) {
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+  const int NBP = (nbr + 1) & ~1;
+  const double bound = sl.SC[5];
+  const int deg = (int)sl.SC[6], N = deg + 1;
+  const double lo = shift, hi = shift + bound;
+  const double half = 0.5 * (hi - lo), mid = 0.5 * (hi + lo);
+  // g at the Chebyshev nodes, then the coefficients c_i = (2 - [i = 0]) / N sum_j g(x_j) cos(pi i (j + 1/2) / N)
+  for (int j = tid; j < N; j += nthr) {
+    const double L = fma(half, cospi(((double)j + 0.5) / (double)N), mid);
+    const double sL = sqrt(L);
+    fw[j] = 1.0 / L;
+    ft[j] = -sqkm1 / (sqc * sL * (sqc + sL));
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += nthr) {
+    double sw_ = 0.0, st_ = 0.0;
+    for (int j = 0; j < N; ++j) {
+      const double cc = cospi((double)i * ((double)j + 0.5) / (double)N);
+      sw_ = fma(fw[j], cc, sw_);
+      st_ = fma(ft[j], cc, st_);
+    }
+    const double f = (i == 0 ? 1.0 : 2.0) / (double)N;
+    cw[i] = sw_ * f;
+    ct[i] = st_ * f;
+  }
+  const int R = (n + 63) & ~63;
+  const int h = tid / R, b0 = h * NBL;                  // (wave-uniform: R is a multiple of 64)
+  const int ir = tid - h * R;
+  const bool act = ir < n && b0 < nbr;
+  const int i = act ? ir : 0;
+  double* cur = pcq;
+  double* oth = pcq + (size_t)n * NBP;
+  double t0[NBL], t1[NBL], yw[NBL], yt[NBL];
+#pragma unroll
+  for (int bl = 0; bl < NBL; ++bl) {
+    const bool on = act && b0 + bl < nbr;
+    t0[bl] = on ? sl.TT[(size_t)(b0 + bl) * k + i] : 0.0;
+    t1[bl] = yw[bl] = yt[bl] = 0.0;
+    if (on) cur[(size_t)i * NBP + b0 + bl] = t0[bl];
+  }
+  __syncthreads();
+  for (int e = tid; e < nwv * nv; e += nthr) fw[e] = 0.0;   // (the node values are used up: per-wave partials of the quadratic forms)
+  const double inv = 1.0 / half;                        // M~ = (M - mid I) / half maps the interval to [-1, 1]
+  const double* gi = sl.G + i;
+  for (int d = 1; d <= deg; ++d) {
+    double acc[NBL];
+#pragma unroll
+    for (int bl = 0; bl < NBL; ++bl) acc[bl] = 0.0;
+    if (act) {
+      for (int j0 = 0; j0 < n; j0 += 8) {
+        double mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = j0 + u < n ? gi[(size_t)(j0 + u) * ldg] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double* tj = cur + (size_t)(j0 + u < n ? j0 + u : n - 1) * NBP + b0;
+#pragma unroll
+          for (int bl = 0; bl < NBL; ++bl) acc[bl] = fma(mv[u], tj[bl], acc[bl]);   // (columns past nbr: padding / the neighbour's, unused)
+        }
+      }
+    }
+    const double cwd = cw[d], ctd = ct[d], cw0 = cw[0], ct0 = ct[0];
+#pragma unroll
+    for (int bl = 0; bl < NBL; ++bl) {
+      double tn;
+      if (d == 1) {
+        tn = (acc[bl] - mid * t0[bl]) * inv;           // T_1 = M~ t
+        yw[bl] = cw0 * t0[bl];
+        yt[bl] = ct0 * t0[bl];
+      } else {
+        tn = fma(2.0 * inv, acc[bl] - mid * t1[bl], -t0[bl]);   // T_d = 2 M~ T_d-1 - T_d-2
+        t0[bl] = t1[bl];
+      }
+      t1[bl] = tn;
+      yw[bl] = fma(cwd, tn, yw[bl]);
+      yt[bl] = fma(ctd, tn, yt[bl]);
+      if (act && b0 + bl < nbr) oth[(size_t)i * NBP + b0 + bl] = tn;
+    }
+    __syncthreads();
+    double* sw2 = cur;
+    cur = oth;
+    oth = sw2;
+  }
+  // (every read of the two T buffers lies behind the loop's last barrier: pcq is free)
+  // quadratic forms t_v^T M^-1 t_v: per-wave partials (zero from the waves that hold other right-hand sides), summed in a
+  // fixed order
+#pragma unroll
+  for (int bl = 0; bl < NBL; ++bl) {
+    const int b = b0 + bl;
+    if (b >= 2 && b < nbr) {                            // (wave-uniform)
+      double p = act ? sl.TT[(size_t)b * k + i] * yw[bl] : 0.0;
+      p = wsum(p);
+      if (lane == 0) fw[wv * nv + (b - 2)] = p;
+    }
+    if (act && b < nbr) pcq[(size_t)b * nq + i] = b < 2 ? yw[bl] : yt[bl];
+  }
+  __syncthreads();
+  for (int v = tid; v < nv; v += nthr) {
+    double s_ = 0.0;
+    for (int w = 0; w < nwv; ++w) s_ += fw[w * nv + v];
+    va[v] = s_;
+  }
+  __syncthreads();
 }
 
 }  // namespace
@@ -465,6 +633,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
       continue;
     }
     const bool dual = mode == 2;
+    const bool poly = solver == 3;                     // eigen-free: sl.G still holds M itself
     const int ldg = m | 1;
     // the workgroup Jacobi pads an odd order with a zero column that ends up anywhere among the stored columns
     const int mc = solver == 1 ? (m + 1) & ~1 : m;
@@ -475,8 +644,8 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     const bool qq_lds = pc_lds && (long)nb * (mq + nq) <= pcq_doubles;
     double* PCp = pc_lds ? pcq : sl.PC;
     const int kq = pc_lds ? mq : k + 2;                 // row length of PC
-    double* QQp = qq_lds ? pcq + (size_t)nb * mq : sl.QQ;
-    const int qld = qq_lds ? nq : k;
+    double* QQp = poly ? pcq : qq_lds ? pcq + (size_t)nb * mq : sl.QQ;
+    const int qld = (poly || qq_lds) ? nq : k;
     const double shift = sl.SC[3], infl_old = sl.SC[4];
     ObsView ov;
     ov.A = &A;
@@ -493,7 +662,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     const int n = ov.n;
 
     // ---------------- normalise the eigen-columns: lambda_j = |g_j|, e_j = g_j / lambda_j (in place)
-    for (int j = wv; j < mc; j += nwv) {
+    for (int j = wv; j < (poly ? 0 : mc); j += nwv) {
       double* gj = sl.G + (size_t)j * ldg;
       double ss = 0.0;
       for (int r = lane; r < m; r += 64) ss = fma(gj[r], gj[r], ss);
@@ -513,7 +682,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
 
     // ---------------- status (common_mtx.f90:66-78) and the spectra
     int st = 0;
-    {
+    if (!poly) {
       double lmx = 0.0, lmn = 1e300;
       for (int j = lane; j < mc; j += 64) {
         lmx = fmax(lmx, lam[j]);
@@ -536,7 +705,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     const double sqc = sqrt(shift), sqkm1 = sqrt(km1);
     const double tau0 = dual ? sqrt(km1 / shift) : 0.0;            // f_T(c) = sqrt(rho)
     const double pi0 = dual ? 1.0 / shift : 0.0;                   // f_Pa(c) = rho / (k-1)
-    for (int j = tid; j < mc; j += nthr) {
+    for (int j = tid; j < (poly ? 0 : mc); j += nthr) {
       const double l = lam[j];
       if (!(l > 0.0) && mc != m) {                     // padding column: no contribution anywhere
         om[j] = tau[j] = pis[j] = 0.0;
@@ -599,7 +768,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     __syncthreads();
 
     // ---------------- coefficients P[b][j] = e_j . TT[b]
-    cols_dot(sl.G, ldg, m, mc, sl.TT, k, nbr, PCp, kq);
+    if (!poly) cols_dot(sl.G, ldg, m, mc, sl.TT, k, nbr, PCp, kq);
     // var_g per variable (RTPS), needed with or without observations
     if (das)
       for (int v = wv; v < nv; v += nwv) {
@@ -609,6 +778,12 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
         if (lane == 0) varg[v] = s;
       }
     __syncthreads();
+    if (poly) {
+      if (m <= 64 && nthr >= 512) poly_apply<2>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, nq, xsm + 7 * nv);
+      else if (m <= 128 && nthr >= 512) poly_apply<4>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, nq, xsm + 7 * nv);
+      else if (m <= 256 && nthr >= 512) poly_apply<8>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, nq, xsm + 7 * nv);
+      else poly_apply<kMaxNb>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, nq, xsm + 7 * nv);
+    }
 
     // ---------------- relaxation scalars per variable (letkf_tools.f90:457-469, :1953-2002)
     if (das)
@@ -621,9 +796,13 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
         } else if (A.relax_alpha_spread != 0.0) {      // RTPS: var_a = x'^T Pa x' = pi0 |x'|^2 + sum_j pi_j P_j^2
           const double var_g = varg[v];
           double var_a = 0.0;
-          for (int j = 0; j < mc; ++j) {
-            const double p = PCp[(size_t)(2 + v) * kq + j];
-            var_a = fma(p * p, pis[j], var_a);
+          if (poly) {
+            var_a = -xsm[7 * nv + v] / shift;          // sum_j pi_j P_j^2 = -(1/c) t^T M^-1 t, t = Z x'_v
+          } else {
+            for (int j = 0; j < mc; ++j) {
+              const double p = PCp[(size_t)(2 + v) * kq + j];
+              var_a = fma(p * p, pis[j], var_a);
+            }
           }
           var_a = fma(pi0, var_g, var_a);
           if (var_g > 0.0 && var_a > 0.0)
@@ -634,7 +813,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
       }
     __syncthreads();
     // ---------------- C = spectrum * P  (in place): rows 0, 1 with 1/lambda (w-bar), rows 2.. with the T spectrum
-    for (int e = tid; e < nbr * mc; e += nthr) {
+    for (int e = tid; e < (poly ? 0 : nbr * mc); e += nthr) {
       const int b = e / mc, j = e - b * mc;
       PCp[(size_t)b * kq + j] *= (b < 2) ? om[j] : tau[j];
     }
@@ -644,7 +823,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     if (!dual) {
       rows_comb(sl.G, ldg, k, mc, PCp, kq, nbr, sl.OUT, k);
     } else {
-      rows_comb(sl.G, ldg, n, mc, PCp, kq, nbr, QQp, qld);      // q_b = U c_b  (obs space)
+      if (!poly) rows_comb(sl.G, ldg, n, mc, PCp, kq, nbr, QQp, qld);      // q_b = U c_b  (obs space; poly_apply left q there)
       __syncthreads();
       // OUT[b][mm] = sum_i Z[i][mm] q_b[i]: one thread per member, the obs rows streamed (coalesced along mm)
       for (int mm = tid; mm < k; mm += nthr) {
@@ -824,12 +1003,31 @@ hipError_t launch_stage_gram(const StagedArgs& s, size_t lds_max, hipStream_t st
   return hipGetLastError();
 }
 
-hipError_t launch_stage_apply(const StagedArgs& s, hipStream_t st) {
-  const int k = s.A.k, nb = s.A.nv + 2;
-  const size_t fixed = (size_t)5 * (k + 2) + 8 * (size_t)s.A.nv + 32;
-  // room for P / C (primal: up to k + 2 columns) and, while it fits, for q as well (dual: two matrices of ~n columns)
+// LDS doubles of stage 3 beyond its fixed part: room for P / C (primal: up to k + 2 columns) and, while it fits, for q as
+// well (dual: two matrices of ~n columns); the polynomial path keeps its two [n][nb] buffers there
+int stage_apply_pcq_doubles(int k, int nv) {
+  const int nb = nv + 2;
+  const size_t fixed = (size_t)5 * (k + 2) + 8 * (size_t)nv + 32;
   size_t pcq = (size_t)2 * nb * (k + 4);
+  const size_t pcq_poly = (size_t)2 * ((nb + 1) & ~1) * (size_t)(k - 1 < kABlock ? k - 1 : kABlock) + 16;   // poly_apply: every n < k (+ slack: the row reads run past a part's columns)
+  if (pcq < pcq_poly) pcq = pcq_poly;
   while ((fixed + pcq) * sizeof(double) > STAGE_APPLY_LDSCAP && pcq > 0) pcq = pcq > (size_t)nb * 64 ? pcq - (size_t)nb * 64 : 0;
+  return (int)pcq;
+}
+
+// most observation rows the polynomial path takes: a thread per row, two [n][nb] buffers and q [nb][n + 2] in that room
+int stage_poly_max_n(int k, int nv) {
+  const int nb = nv + 2, nbp = (nb + 1) & ~1;
+  long n = stage_apply_pcq_doubles(k, nv) / (2 * nbp);
+  if (n > kABlock) n = kABlock;
+  while (n > 0 && (long)nb * ((n + 2) & ~1L) > stage_apply_pcq_doubles(k, nv)) --n;
+  return (int)n;
+}
+
+hipError_t launch_stage_apply(const StagedArgs& s, hipStream_t st) {
+  const int k = s.A.k;
+  const size_t fixed = (size_t)5 * (k + 2) + 8 * (size_t)s.A.nv + 32;
+  const size_t pcq = (size_t)stage_apply_pcq_doubles(k, s.A.nv);
   const size_t lds = (fixed + pcq) * sizeof(double);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_stage_apply_kernel),
