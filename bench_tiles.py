@@ -211,7 +211,7 @@ def run(args, ctx, pkg, dev, rank, world):
     kern_ms, nlaunch = ctx.timing_read(reset=True)
     csum = float(anal.view(nv, nens, npts)[:, :k].sum().item())          # (slot k, the mean, is not written by the loop)
     stat = torch.tensor([elapsed, float(keep["nnz"]), float(keep["nt"]), float((status != 0).sum().item()),
-                         float(nsweep.double().sum().item()), kern_ms, float(keep["rows_received"]), csum], dtype=f64,
+                         float(nsweep.clamp(min=0).double().sum().item()), kern_ms, float(keep["rows_received"]), csum], dtype=f64,
                         device=dev)
     mx = stat.clone()
     if world > 1:

@@ -241,6 +241,13 @@ def alg_flops_dual(n, k, nv):
     return 2.0 * n * n * k + 9.0 * n ** 3 + 2.0 * (2.0 * n * k * nb) + 2.0 * (2.0 * n * n * nb) + 4.0 * nv * k
 
 
+def alg_flops_poly(n, k, nv, deg):
+    """The observation-space analysis without an eigen-decomposition (letkf_staged.hip poly_apply): Z Z^T, deg products
+    of the n x n matrix with the nb = nv + 2 right-hand sides (the Chebyshev recurrence), Z b and Z^T q."""
+    nb = nv + 2
+    return 2.0 * n * n * k + deg * 2.0 * n * n * nb + 2.0 * (2.0 * n * k * nb) + 6.0 * deg * n * nb + 4.0 * nv * k
+
+
 def alg_flops_required(n, k, nv, rtps=True):
     f = alg_flops_per_solve(n, k, nv, rtps)
     return min(f, alg_flops_dual(n, k, nv)) if n < k else f

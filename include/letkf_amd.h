@@ -172,7 +172,7 @@ typedef struct {
   double *transm_out;        /* dev [npts][k] or NULL */
   double *pa_out;            /* dev [npts][k*k] or NULL */
   int32_t *status;           /* dev [npts] or NULL */
-  int32_t *nsweep;           /* dev [npts] or NULL */
+  int32_t *nsweep;           /* dev [npts] or NULL: Jacobi sweeps; < 0: -(Chebyshev degree) of a point analysed without an eigen stage (LETKF_OPT_STAGED_POLY) */
   double *rtps_infl_out;     /* dev [npts*nv] or NULL: the RTPS factor applied to T per variable, work3da of
                                 RELAX_SPREAD_OUT (scale/letkf/letkf_tools.f90:271-276, 460-462, 735-759); 1 where
                                 no RTPS factor applies (RTPP / none / beta = 0 / Q_UPDATE_TOP skip) */

@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(kGBlock) letkf_stage_gram_kernel(const StagedA
     // lies in [c, c + |S|] for any norm bound |S| >= lambda_max(S); the smaller of the Frobenius norm and the largest
     // absolute row sum is free here (M is in L2).  cond = (c + |S|) / c fixes the Chebyshev degree that reaches 1e-16 for
     // functions analytic away from 0 (1/x, the T and Pa spectra): rate (sqrt(cond) - 1) / (sqrt(cond) + 1) per degree.
-    if (S.poly_max_n > 0 && dual && m >= 2 && m <= S.poly_max_n && m <= nthr) {
+    if (S.poly_max_n > 0 && m >= 2 && m <= S.poly_max_n && m <= nthr) {   // (dual: M = Z Z^T + c I, n x n; primal: A = Z^T Z + c I, k x k)
       __syncthreads();                                // (G complete: every thread's stores; red[] read above)
       double fs = 0.0, rs = 0.0;
       if (tid < m) {
@@ -385,14 +385,16 @@ __global__ void __launch_bounds__(kGBlock) letkf_stage_gram_kernel(const StagedA
           f2 += swl[w];
           r1 = fmax(r1, swl[16 + w]);
         }
-        const double bound = fmin(sqrt(f2), r1) * (1.0 + 1e-12);
+        // (never an empty interval: all-zero weights or perturbations give S = 0)
+        const double bound = fmax(fmin(sqrt(f2), r1) * (1.0 + 1e-12), 1e-6 * shift);
         const double sk = sqrt((shift + bound) / shift);
         const double rate = (sk - 1.0) / (sk + 1.0);
         int deg = rate > 0.0 ? (int)ceil(log(1e-16) / log(rate)) + 1 : 4;
         if (deg < 4) deg = 4;
-        if (bound >= 0.0 && deg <= S.poly_max_deg) {  // (a NaN anywhere fails both tests: the Jacobi path reports it)
-          S.meta[2 * it] = 2 | (3 << 8);
-          S.info[2 * it] = 0;                         // no sweeps ...
+        if (f2 <= 1.7e308 && deg <= S.poly_max_deg) {   // (a NaN / Inf anywhere in M makes the sum of squares fail this test:
+                                                        //  the eigen stage then reports the point, status 1)
+          S.meta[2 * it] = (dual ? 2 : 1) | (3 << 8);
+          S.info[2 * it] = -deg;                      // no sweeps: nsweep reports -(degree) ...
           S.info[2 * it + 1] = 1;                     // ... and nothing that could fail to converge
           sl.SC[5] = bound;
           sl.SC[6] = (double)deg;
@@ -470,7 +472,8 @@ __device__ __forceinline__ void rows_comb(const double* __restrict__ Cm, const i
 template <int NBL>
 __device__ __forceinline__ void poly_apply(const Slab& sl, const int n, const int ldg, const int k, const int nv, const int nbr,
                                            const double shift, const double sqc, const double sqkm1, double* fw, double* ft,
-                                           double* cw, double* ct, double* pcq, const int nq, double* va) {
+                                           double* cw, double* ct, double* pcq, double* qout, const int nq, double* va,
+                                           const bool dual) {
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
   const int NBP = (nbr + 1) & ~1;
   const double bound = sl.SC[5];
@@ -482,7 +485,7 @@ __device__ __forceinline__ void poly_apply(const Slab& sl, const int n, const in
     const double L = fma(half, cospi(((double)j + 0.5) / (double)N), mid);
     const double sL = sqrt(L);
     fw[j] = 1.0 / L;
-    ft[j] = -sqkm1 / (sqc * sL * (sqc + sL));
+    ft[j] = dual ? -sqkm1 / (sqc * sL * (sqc + sL)) : sqkm1 / sL;   // T = sqrt(rho) I + Z^T U g U^T Z  |  T = sqrt(k-1) A^-1/2
   }
   __syncthreads();
   for (int i = tid; i < N; i += nthr) {
@@ -565,7 +568,7 @@ __device__ __forceinline__ void poly_apply(const Slab& sl, const int n, const in
       p = wsum(p);
       if (lane == 0) fw[wv * nv + (b - 2)] = p;
     }
-    if (act && b < nbr) pcq[(size_t)b * nq + i] = b < 2 ? yw[bl] : yt[bl];
+    if (act && b < nbr) qout[(size_t)b * nq + i] = b < 2 ? yw[bl] : yt[bl];
   }
   __syncthreads();
   for (int v = tid; v < nv; v += nthr) {
@@ -779,10 +782,10 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
       }
     __syncthreads();
     if (poly) {
-      if (m <= 64 && nthr >= 512) poly_apply<2>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, nq, xsm + 7 * nv);
-      else if (m <= 128 && nthr >= 512) poly_apply<4>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, nq, xsm + 7 * nv);
-      else if (m <= 256 && nthr >= 512) poly_apply<8>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, nq, xsm + 7 * nv);
-      else poly_apply<kMaxNb>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, nq, xsm + 7 * nv);
+      if (m <= 64 && nthr >= 512) poly_apply<2>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
+      else if (m <= 128 && nthr >= 512) poly_apply<4>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
+      else if (m <= 256 && nthr >= 512) poly_apply<8>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
+      else poly_apply<kMaxNb>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
     }
 
     // ---------------- relaxation scalars per variable (letkf_tools.f90:457-469, :1953-2002)
@@ -797,7 +800,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
           const double var_g = varg[v];
           double var_a = 0.0;
           if (poly) {
-            var_a = -xsm[7 * nv + v] / shift;          // sum_j pi_j P_j^2 = -(1/c) t^T M^-1 t, t = Z x'_v
+            var_a = dual ? -xsm[7 * nv + v] / shift : xsm[7 * nv + v];   // sum_j pi_j P_j^2 = -(1/c) t^T M^-1 t, t = Z x'_v  |  x'^T A^-1 x'
           } else {
             for (int j = 0; j < mc; ++j) {
               const double p = PCp[(size_t)(2 + v) * kq + j];
@@ -821,7 +824,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
 
     // ---------------- back to member space: OUT[b][mm]
     if (!dual) {
-      rows_comb(sl.G, ldg, k, mc, PCp, kq, nbr, sl.OUT, k);
+      if (!poly) rows_comb(sl.G, ldg, k, mc, PCp, kq, nbr, sl.OUT, k);   // (poly_apply has written OUT)
     } else {
       if (!poly) rows_comb(sl.G, ldg, n, mc, PCp, kq, nbr, QQp, qld);      // q_b = U c_b  (obs space; poly_apply left q there)
       __syncthreads();
@@ -1009,7 +1012,7 @@ int stage_apply_pcq_doubles(int k, int nv) {
   const int nb = nv + 2;
   const size_t fixed = (size_t)5 * (k + 2) + 8 * (size_t)nv + 32;
   size_t pcq = (size_t)2 * nb * (k + 4);
-  const size_t pcq_poly = (size_t)2 * ((nb + 1) & ~1) * (size_t)(k - 1 < kABlock ? k - 1 : kABlock) + 16;   // poly_apply: every n < k (+ slack: the row reads run past a part's columns)
+  const size_t pcq_poly = (size_t)2 * ((nb + 1) & ~1) * (size_t)(k < kABlock ? k : kABlock) + 16;   // poly_apply: every n < k (+ slack: the row reads run past a part's columns)
   if (pcq < pcq_poly) pcq = pcq_poly;
   while ((fixed + pcq) * sizeof(double) > STAGE_APPLY_LDSCAP && pcq > 0) pcq = pcq > (size_t)nb * 64 ? pcq - (size_t)nb * 64 : 0;
   return (int)pcq;

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-r02}
 O=gpurun_out/final_$TAG
 mkdir -p $O
-j() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'ms/step', round(d['ms_per_step'],2), 'solves/s', int(d['value']), 'solve-only', int(d['solve_only_solves_per_s']), 'kernel_ms', round(d['roofline']['kernel_ms'],2), 'frac', round(d['roofline']['frac'],4), d['roofline']['bound'], 'sweeps', round(d.get('jacobi_sweeps_mean'),2), 'bad', d.get('nonzero_status_points'), 'n_mean', d['config']['workload'].split('mean')[1][:7])"; }
+j() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'ms/step', round(d['ms_per_step'],2), 'solves/s', int(d['value']), 'solve-only', int(d['solve_only_solves_per_s']), 'kernel_ms', round(d['roofline']['kernel_ms'],2), 'frac', round(d['roofline']['frac'],4), d['roofline']['bound'], 'sweeps', round(d.get('jacobi_sweeps_mean'),2), 'cheb-deg', d.get('chebyshev_degree_mean') and round(d.get('chebyshev_degree_mean'),1), 'bad', d.get('nonzero_status_points'), 'n_mean', d['config']['workload'].split('mean')[1][:7])"; }
 echo "== pytest -m gpu"; timeout -k 10 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 echo "== tools/profile.sh"; tools/profile.sh $TAG > $O/profile.log 2>&1; tail -12 $O/profile.log | cut -c1-300
 echo "== tools/pmc_sq.sh"; tools/pmc_sq.sh $TAG > $O/sq.log 2>&1; tail -12 $O/sq.log
