@@ -50,6 +50,9 @@ constexpr int kGBlock = 512;
 #ifndef STAGE_APPLY_MINWG
 #define STAGE_APPLY_MINWG 1
 #endif
+#ifndef STAGE_POLY_ROWS
+#define STAGE_POLY_ROWS 8      // rows of M whose loads are issued ahead of their FMAs (poly_apply)
+#endif
 #ifndef STAGE_APPLY_LDSCAP
 #define STAGE_APPLY_LDSCAP (150 * 1024)
 #endif
@@ -523,12 +526,12 @@ __device__ __forceinline__ void poly_apply(const Slab& sl, const int n, const in
 #pragma unroll
     for (int bl = 0; bl < NBL; ++bl) acc[bl] = 0.0;
     if (act) {
-      for (int j0 = 0; j0 < n; j0 += 8) {
-        double mv[8];
+      for (int j0 = 0; j0 < n; j0 += STAGE_POLY_ROWS) {
+        double mv[STAGE_POLY_ROWS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) mv[u] = j0 + u < n ? gi[(size_t)(j0 + u) * ldg] : 0.0;
+        for (int u = 0; u < STAGE_POLY_ROWS; ++u) mv[u] = j0 + u < n ? gi[(size_t)(j0 + u) * ldg] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < STAGE_POLY_ROWS; ++u) {
           const double* tj = cur + (size_t)(j0 + u < n ? j0 + u : n - 1) * NBP + b0;
 #pragma unroll
           for (int bl = 0; bl < NBL; ++bl) acc[bl] = fma(mv[u], tj[bl], acc[bl]);   // (columns past nbr: padding / the neighbour's, unused)
