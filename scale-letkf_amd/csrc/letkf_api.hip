@@ -293,7 +293,7 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
   // (its node values, coefficients and per-wave partials live in stage 3's five [k + 2] LDS arrays: small k with nv != 11
   // comes here too and keeps the eigen stage)
   s.poly_max_deg = 64;
-  s.poly_max_n = (a.mode == 0 && !kkout && c->staged_poly && a.k + 2 >= s.poly_max_deg + 1 && a.k + 2 >= 8 * a.nv)
+  s.poly_max_n = (a.mode == 0 && !kkout && c->staged_poly && a.k + 2 >= s.poly_max_deg + 1 && a.k + 2 >= 8 * 16)
                      ? letkf::stage_poly_max_n(a.k, a.nv) : 0;
   s.A.max_sweep = 60;
   EventPair ev;

@@ -467,20 +467,28 @@ __device__ __forceinline__ void rows_comb(const double* __restrict__ Cm, const i
 // singularity is L = 0), the coefficients come from interpolation at the Chebyshev nodes of the point's own interval.
 // Thread i owns row i (n <= blockDim.x): T_d[b][i] in registers, the current T_d of all rows in LDS ([row][NBP], read as
 // broadcasts), ping-pong, one barrier per degree.  On return q_b[i] sits in pcq[b * nq + i] and va[v] = t_v^T M^-1 t_v.
-// The nbr right-hand sides are dealt to PARTS of the workgroup, NBL to each (part h = threads [h R, (h + 1) R), R = the
-// rows rounded up to whole wavefronts): n <= 64: 2 per part, <= 128: 4, <= 256: 8, above: all 16 in one part -- more
-// loads of M in flight per CU (the iteration is bound by the latency of streaming M from L2 / MALL once per degree:
-// 320 KB at n = 200, too much for LDS next to the buffers) and few enough registers per thread to keep 8 rows of loads
-// ahead of their use.
-template <int NBL>
+// The product M T_d runs on the FP64 matrix cores (v_mfma_f64_16x16x4: A = a 16 x 4 tile of M straight from L2 -- lane l
+// loads M[i0 + (l & 15)][j0 + (l >> 4)], 128 contiguous bytes per 16 lanes --, B = 4 rows of T_d from LDS, lane l reads
+// T[j0 + (l >> 4)][l & 15] = 64 consecutive doubles, conflict-free; D: lane l holds rows (l >> 4) + 4 r, r < 4, of column
+// l & 15).  A wave owns the 16-row blocks w, w + 8, ... (BPW of them); the recurrence state T_d, T_d-1 and the two running
+// sums live in registers in D's layout, the new T_d goes to the other LDS buffer ([row][16], the right-hand sides padded to
+// 16 columns of which the last ones stay zero), ONE barrier per degree.  (First versions: a thread per row with broadcast
+// reads of T_d from LDS -- 62.9 ms on C3-slab with all right-hand sides per thread, 23.8 ms with the right-hand sides
+// dealt to parts of the workgroup and 8 rows of loads in flight; a fixed-degree timing twin showed 0.56 ms per degree
+// there, bound by the LDS broadcasts: 4 ds_read_b128 per row of M and wave.)
+template <int BPW>
 __device__ __forceinline__ void poly_apply(const Slab& sl, const int n, const int ldg, const int k, const int nv, const int nbr,
                                            const double shift, const double sqc, const double sqkm1, double* fw, double* ft,
                                            double* cw, double* ct, double* pcq, double* qout, const int nq, double* va,
                                            const bool dual) {
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
-  const int NBP = (nbr + 1) & ~1;
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
   const double bound = sl.SC[5];
+#ifdef STAGE_POLY_TIMING_DEG   // A/B twins only (make VARIANT=...): a fixed number of terms -- timing of the recurrence, results invalid
+  const int deg = STAGE_POLY_TIMING_DEG, N = deg + 1;
+#else
   const int deg = (int)sl.SC[6], N = deg + 1;
+#endif
   const double lo = shift, hi = shift + bound;
   const double half = 0.5 * (hi - lo), mid = 0.5 * (hi + lo);
   // g at the Chebyshev nodes, then the coefficients c_i = (2 - [i = 0]) / N sum_j g(x_j) cos(pi i (j + 1/2) / N)
@@ -502,58 +510,68 @@ __device__ __forceinline__ void poly_apply(const Slab& sl, const int n, const in
     cw[i] = sw_ * f;
     ct[i] = st_ * f;
   }
-  const int R = (n + 63) & ~63;
-  const int h = tid / R, b0 = h * NBL;                  // (wave-uniform: R is a multiple of 64)
-  const int ir = tid - h * R;
-  const bool act = ir < n && b0 < nbr;
-  const int i = act ? ir : 0;
+  const int nr16 = (n + 15) & ~15;
+  const int col = lane & 15, rq = lane >> 4;
   double* cur = pcq;
-  double* oth = pcq + (size_t)n * NBP;
-  double t0[NBL], t1[NBL], yw[NBL], yt[NBL];
+  double* oth = pcq + (size_t)nr16 * 16;
+  double t0[BPW][4], t1[BPW][4], yw[BPW][4], yt[BPW][4];
 #pragma unroll
-  for (int bl = 0; bl < NBL; ++bl) {
-    const bool on = act && b0 + bl < nbr;
-    t0[bl] = on ? sl.TT[(size_t)(b0 + bl) * k + i] : 0.0;
-    t1[bl] = yw[bl] = yt[bl] = 0.0;
-    if (on) cur[(size_t)i * NBP + b0 + bl] = t0[bl];
+  for (int bi = 0; bi < BPW; ++bi) {
+    const int i0 = (wv + bi * nwv) * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + rq + 4 * r;
+      t0[bi][r] = (row < n && col < nbr) ? sl.TT[(size_t)col * k + row] : 0.0;
+      t1[bi][r] = yw[bi][r] = yt[bi][r] = 0.0;
+      if (i0 < nr16) cur[(size_t)row * 16 + col] = t0[bi][r];
+    }
   }
   __syncthreads();
-  for (int e = tid; e < nwv * nv; e += nthr) fw[e] = 0.0;   // (the node values are used up: per-wave partials of the quadratic forms)
+  for (int e = tid; e < nwv * 16; e += nthr) fw[e] = 0.0;   // (the node values are used up: per-wave partials of the quadratic forms)
   const double inv = 1.0 / half;                        // M~ = (M - mid I) / half maps the interval to [-1, 1]
-  const double* gi = sl.G + i;
+  constexpr int KS = 16 / BPW;                          // k-steps (of 4 rows of M^T = columns j) whose loads go out together
   for (int d = 1; d <= deg; ++d) {
-    double acc[NBL];
+    d4 acc[BPW];
 #pragma unroll
-    for (int bl = 0; bl < NBL; ++bl) acc[bl] = 0.0;
-    if (act) {
-      for (int j0 = 0; j0 < n; j0 += STAGE_POLY_ROWS) {
-        double mv[STAGE_POLY_ROWS];
+    for (int bi = 0; bi < BPW; ++bi) acc[bi] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int j0 = 0; j0 < nr16; j0 += 4 * KS) {
+      double av[BPW][KS], bq[KS];
 #pragma unroll
-        for (int u = 0; u < STAGE_POLY_ROWS; ++u) mv[u] = j0 + u < n ? gi[(size_t)(j0 + u) * ldg] : 0.0;
+      for (int s = 0; s < KS; ++s) {
+        const int j = j0 + 4 * s + rq;
 #pragma unroll
-        for (int u = 0; u < STAGE_POLY_ROWS; ++u) {
-          const double* tj = cur + (size_t)(j0 + u < n ? j0 + u : n - 1) * NBP + b0;
-#pragma unroll
-          for (int bl = 0; bl < NBL; ++bl) acc[bl] = fma(mv[u], tj[bl], acc[bl]);   // (columns past nbr: padding / the neighbour's, unused)
+        for (int bi = 0; bi < BPW; ++bi) {
+          const int row = (wv + bi * nwv) * 16 + col;    // (A's row sits on lane & 15)
+          av[bi][s] = (j < n && row < n) ? sl.G[(size_t)j * ldg + row] : 0.0;
         }
       }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) bq[s] = j0 + 4 * s < nr16 ? cur[(size_t)(j0 + 4 * s) * 16 + lane] : 0.0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int bi = 0; bi < BPW; ++bi) acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[bi][s], bq[s], acc[bi], 0, 0, 0);
     }
     const double cwd = cw[d], ctd = ct[d], cw0 = cw[0], ct0 = ct[0];
 #pragma unroll
-    for (int bl = 0; bl < NBL; ++bl) {
-      double tn;
-      if (d == 1) {
-        tn = (acc[bl] - mid * t0[bl]) * inv;           // T_1 = M~ t
-        yw[bl] = cw0 * t0[bl];
-        yt[bl] = ct0 * t0[bl];
-      } else {
-        tn = fma(2.0 * inv, acc[bl] - mid * t1[bl], -t0[bl]);   // T_d = 2 M~ T_d-1 - T_d-2
-        t0[bl] = t1[bl];
+    for (int bi = 0; bi < BPW; ++bi) {
+      const int i0 = (wv + bi * nwv) * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double tn;
+        if (d == 1) {
+          tn = (acc[bi][r] - mid * t0[bi][r]) * inv;   // T_1 = M~ t
+          yw[bi][r] = cw0 * t0[bi][r];
+          yt[bi][r] = ct0 * t0[bi][r];
+        } else {
+          tn = fma(2.0 * inv, acc[bi][r] - mid * t1[bi][r], -t0[bi][r]);   // T_d = 2 M~ T_d-1 - T_d-2
+          t0[bi][r] = t1[bi][r];
+        }
+        t1[bi][r] = tn;
+        yw[bi][r] = fma(cwd, tn, yw[bi][r]);
+        yt[bi][r] = fma(ctd, tn, yt[bi][r]);
+        if (i0 < nr16) oth[(size_t)(i0 + rq + 4 * r) * 16 + col] = tn;
       }
-      t1[bl] = tn;
-      yw[bl] = fma(cwd, tn, yw[bl]);
-      yt[bl] = fma(ctd, tn, yt[bl]);
-      if (act && b0 + bl < nbr) oth[(size_t)i * NBP + b0 + bl] = tn;
     }
     __syncthreads();
     double* sw2 = cur;
@@ -561,22 +579,28 @@ __device__ __forceinline__ void poly_apply(const Slab& sl, const int n, const in
     oth = sw2;
   }
   // (every read of the two T buffers lies behind the loop's last barrier: pcq is free)
-  // quadratic forms t_v^T M^-1 t_v: per-wave partials (zero from the waves that hold other right-hand sides), summed in a
-  // fixed order
+  // q_b, and the quadratic forms t_v^T M^-1 t_v: a lane's rows, then the four lanes of a column, per-wave partials
+  // summed in a fixed order
+  double p = 0.0;
 #pragma unroll
-  for (int bl = 0; bl < NBL; ++bl) {
-    const int b = b0 + bl;
-    if (b >= 2 && b < nbr) {                            // (wave-uniform)
-      double p = act ? sl.TT[(size_t)b * k + i] * yw[bl] : 0.0;
-      p = wsum(p);
-      if (lane == 0) fw[wv * nv + (b - 2)] = p;
+  for (int bi = 0; bi < BPW; ++bi) {
+    const int i0 = (wv + bi * nwv) * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + rq + 4 * r;
+      if (row < n && col < nbr) {
+        p = fma(sl.TT[(size_t)col * k + row], yw[bi][r], p);
+        qout[(size_t)col * nq + row] = col < 2 ? yw[bi][r] : yt[bi][r];
+      }
     }
-    if (act && b < nbr) qout[(size_t)b * nq + i] = b < 2 ? yw[bl] : yt[bl];
   }
+  p += __shfl_xor(p, 16, 64);
+  p += __shfl_xor(p, 32, 64);
+  if (lane < 16) fw[wv * 16 + lane] = p;
   __syncthreads();
   for (int v = tid; v < nv; v += nthr) {
     double s_ = 0.0;
-    for (int w = 0; w < nwv; ++w) s_ += fw[w * nv + v];
+    for (int w = 0; w < nwv; ++w) s_ += fw[w * 16 + 2 + v];
     va[v] = s_;
   }
   __syncthreads();
@@ -785,10 +809,10 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
       }
     __syncthreads();
     if (poly) {
-      if (m <= 64 && nthr >= 512) poly_apply<2>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
-      else if (m <= 128 && nthr >= 512) poly_apply<4>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
-      else if (m <= 256 && nthr >= 512) poly_apply<8>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
-      else poly_apply<kMaxNb>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
+      const int nblk = (m + 15) >> 4, per = (nblk + nwv - 1) / nwv;   // 16-row blocks per wave
+      if (per <= 1) poly_apply<1>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
+      else if (per <= 2) poly_apply<2>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
+      else poly_apply<4>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
     }
 
     // ---------------- relaxation scalars per variable (letkf_tools.f90:457-469, :1953-2002)
@@ -1015,19 +1039,19 @@ int stage_apply_pcq_doubles(int k, int nv) {
   const int nb = nv + 2;
   const size_t fixed = (size_t)5 * (k + 2) + 8 * (size_t)nv + 32;
   size_t pcq = (size_t)2 * nb * (k + 4);
-  const size_t pcq_poly = (size_t)2 * ((nb + 1) & ~1) * (size_t)(k < kABlock ? k : kABlock) + 16;   // poly_apply: every n < k (+ slack: the row reads run past a part's columns)
+  const size_t pcq_poly = (size_t)2 * 16 * (size_t)(((k < kABlock ? k : kABlock) + 15) & ~15);   // poly_apply: two [rows to 16][16] buffers, any order <= min(k, 512)
   if (pcq < pcq_poly) pcq = pcq_poly;
   while ((fixed + pcq) * sizeof(double) > STAGE_APPLY_LDSCAP && pcq > 0) pcq = pcq > (size_t)nb * 64 ? pcq - (size_t)nb * 64 : 0;
   return (int)pcq;
 }
 
-// most observation rows the polynomial path takes: a thread per row, two [n][nb] buffers and q [nb][n + 2] in that room
+// largest order the polynomial path takes: two [n to 16][16] buffers, then q [nb][n + 2], in that room
 int stage_poly_max_n(int k, int nv) {
-  const int nb = nv + 2, nbp = (nb + 1) & ~1;
-  long n = stage_apply_pcq_doubles(k, nv) / (2 * nbp);
-  if (n > kABlock) n = kABlock;
-  while (n > 0 && (long)nb * ((n + 2) & ~1L) > stage_apply_pcq_doubles(k, nv)) --n;
-  return (int)n;
+  const int nb = nv + 2;
+  long n = (stage_apply_pcq_doubles(k, nv) / 32) & ~15L;   // two [n to 16][16] buffers
+  if (n > kABlock) n = kABlock;                            // (4 blocks of 16 rows per wave)
+  while (n > 0 && (long)nb * ((n + 2) & ~1L) > stage_apply_pcq_doubles(k, nv)) n -= 16;
+  return (int)(n > 0 ? n : 0);
 }
 
 hipError_t launch_stage_apply(const StagedArgs& s, hipStream_t st) {
