@@ -53,6 +53,9 @@ constexpr int kGBlock = 512;
 #ifndef STAGE_POLY_ROWS
 #define STAGE_POLY_ROWS 8      // rows of M whose loads are issued ahead of their FMAs (poly_apply)
 #endif
+#ifndef STAGE_POLY_RES
+#define STAGE_POLY_RES 0       // k-steps of M per wave that stay in registers across the degrees (poly_apply; A/B)
+#endif
 #ifndef STAGE_APPLY_LDSCAP
 #define STAGE_APPLY_LDSCAP (150 * 1024)
 #endif
@@ -530,11 +533,33 @@ __device__ __forceinline__ void poly_apply(const Slab& sl, const int n, const in
   for (int e = tid; e < nwv * 16; e += nthr) fw[e] = 0.0;   // (the node values are used up: per-wave partials of the quadratic forms)
   const double inv = 1.0 / half;                        // M~ = (M - mid I) / half maps the interval to [-1, 1]
   constexpr int KS = 16 / BPW;                          // k-steps (of 4 rows of M^T = columns j) whose loads go out together
+  // The first RS k-steps of a wave's A operands stay in registers across the degrees (the stream of M from L2 / MALL is
+  // what bounds the recurrence: 320 KB per degree and CU at n = 200)
+  constexpr int RS = BPW <= 2 ? STAGE_POLY_RES / BPW : 0;
+  double ares[BPW][RS > 0 ? RS : 1];
+#pragma unroll
+  for (int s = 0; s < RS; ++s) {
+    const int j = 4 * s + rq;
+#pragma unroll
+    for (int bi = 0; bi < BPW; ++bi) {
+      const int row = (wv + bi * nwv) * 16 + col;
+      ares[bi][s] = (j < n && row < n) ? sl.G[(size_t)j * ldg + row] : 0.0;
+    }
+  }
+  const int jres = 4 * RS < nr16 ? 4 * RS : nr16;       // columns [0, jres) come from the registers
   for (int d = 1; d <= deg; ++d) {
     d4 acc[BPW];
 #pragma unroll
     for (int bi = 0; bi < BPW; ++bi) acc[bi] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int j0 = 0; j0 < nr16; j0 += 4 * KS) {
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+      if (4 * s < nr16) {                               // (wave-uniform)
+        const double bq = cur[(size_t)(4 * s) * 16 + lane];
+#pragma unroll
+        for (int bi = 0; bi < BPW; ++bi) acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ares[bi][s], bq, acc[bi], 0, 0, 0);
+      }
+    }
+    for (int j0 = jres; j0 < nr16; j0 += 4 * KS) {
       double av[BPW][KS], bq[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
