@@ -778,10 +778,15 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     }
 
     // ---------------- stage the perturbations X[v][mm]; right-hand sides in the solver's space TT[b][.]
+    // (dual: a second copy of X in LDS -- the pcq region is free until the coefficients / the T buffers move in -- for the
+    //  Z x'_v pass below, which reads all of X once per observation row)
+    const bool x_lds = das && dual && (long)nv * k <= pcq_doubles;
     if (das) {
       for (int e = tid; e < nv * k; e += nthr) {
         const int v = e / k, mm = e - v * k;
-        sl.X[e] = g0[mm * A.sm + v * A.sv];
+        const double xv = g0[mm * A.sm + v * A.sv];
+        sl.X[e] = xv;
+        if (x_lds) pcq[e] = xv;
       }
       for (int v = tid; v < nv; v += nthr) {
         xmean[v] = g0[k * A.sm + v * A.sv];
@@ -805,11 +810,12 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
           double acc[kMaxNb];
 #pragma unroll
           for (int v = 0; v < kMaxNb; ++v) acc[v] = 0.0;
+          const double* xs = x_lds ? pcq : sl.X;
           for (int mm = lane; mm < k; mm += 64) {
             const double y = yr[(long)mm * ms];
 #pragma unroll
             for (int v = 0; v < kMaxNb; ++v)
-              if (v < nv) acc[v] = fma(y, sl.X[(size_t)v * k + mm], acc[v]);
+              if (v < nv) acc[v] = fma(y, xs[(size_t)v * k + mm], acc[v]);
           }
           const double sw = swl[i];
 #pragma unroll
@@ -885,13 +891,22 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
         double acc[kMaxNb];
 #pragma unroll
         for (int b = 0; b < kMaxNb; ++b) acc[b] = 0.0;
-        for (int i = 0; i < n; ++i) {
-          long ms;
-          const double* yr = ov.row(i, ms);
-          const double z = yr[(long)mm * ms] * swl[i];
+        for (int i0 = 0; i0 < n; i0 += 4) {               // four observation rows of loads ahead of their FMAs
+          double z[4];
 #pragma unroll
-          for (int b = 0; b < kMaxNb; ++b)
-            if (b < nbr) acc[b] = fma(z, QQp[(size_t)b * qld + i], acc[b]);
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u < n ? i0 + u : n - 1;
+            long ms;
+            const double* yr = ov.row(i, ms);
+            z[u] = i0 + u < n ? yr[(long)mm * ms] * swl[i] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u < n ? i0 + u : n - 1;
+#pragma unroll
+            for (int b = 0; b < kMaxNb; ++b)
+              if (b < nbr) acc[b] = fma(z[u], QQp[(size_t)b * qld + i], acc[b]);
+          }
         }
 #pragma unroll
         for (int b = 0; b < kMaxNb; ++b)
