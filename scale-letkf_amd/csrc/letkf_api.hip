@@ -190,6 +190,9 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
   bool wave = !force_block && letkf::wave_kernel_supports(a.k, a.nv, a.mode);
   if (const char* e = LETKF_KNOB("LETKF_AMD_STAGED_MIN_K"))   // PROF knob: A/B the staged path against the two-wave kernel
     if (a.mode != 2 && a.k >= std::atoi(e)) wave = false;
+#ifdef LETKF_STAGED_MIN_K   // A/B twins (make VARIANT=...): the same switch at compile time
+  if (a.mode != 2 && a.k >= LETKF_STAGED_MIN_K) wave = false;
+#endif
   // beyond the register kernels: the staged three-kernel path (the monolithic workgroup kernel below stays reachable
   // through the PROF twin's LETKF_AMD_FORCE_BLOCK / LETKF_AMD_MONOLITHIC knobs for A/B measurements)
   if (!wave && !force_block && a.mode != 2 && a.nv + 2 <= 16 && !LETKF_KNOB("LETKF_AMD_MONOLITHIC")) return launch_staged(c, a);
