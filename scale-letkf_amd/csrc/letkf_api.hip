@@ -293,10 +293,10 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
   s.kkout = kkout;
   s.wg_max_order = letkf::eig_wg_max_order();
   // eigen-free observation-space points (letkf_staged.hip, poly_apply): the loop body without k x k outputs
-  // (its node values, coefficients and per-wave partials live in stage 3's five [k + 2] LDS arrays: small k with nv != 11
-  // comes here too and keeps the eigen stage)
+  // (its node values and coefficients live in stage 3's [k + 2] LDS arrays, the 8 x 16 per-wave partials of the quadratic
+  // forms in the first two of them, which are contiguous: k >= 63; smaller k with nv != 11 comes here too and keeps the eigen stage)
   s.poly_max_deg = 64;
-  s.poly_max_n = (a.mode == 0 && !kkout && c->staged_poly && a.k + 2 >= s.poly_max_deg + 1 && a.k + 2 >= 8 * 16)
+  s.poly_max_n = (a.mode == 0 && !kkout && c->staged_poly && a.k + 2 >= s.poly_max_deg + 1 && 2 * (a.k + 2) >= 8 * 16)
                      ? letkf::stage_poly_max_n(a.k, a.nv) : 0;
   s.A.max_sweep = 60;
   EventPair ev;
