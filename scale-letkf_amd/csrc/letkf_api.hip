@@ -190,6 +190,10 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
   bool wave = !force_block && letkf::wave_kernel_supports(a.k, a.nv, a.mode);
   if (const char* e = LETKF_KNOB("LETKF_AMD_STAGED_MIN_K"))   // PROF knob: A/B the staged path against the two-wave kernel
     if (a.mode != 2 && a.k >= std::atoi(e)) wave = false;
+  // 63 <= k <= 100, loop body without k x k outputs: the staged path analyses such a point without an eigen-decomposition
+  // (letkf_staged.hip poly_apply; MEMBER = 100: 1.07 M solves/s against 0.64 M on the two-wave Jacobi kernel, same result to
+  // rounding).  The two-wave kernel keeps the calls that return T / Pa, and everything when LETKF_OPT_STAGED_POLY is 0.
+  if (wave && a.k >= 63 && a.mode == 0 && !a.trans_out && !a.pa_out && c->staged_poly && a.nv + 2 <= 16) wave = false;
 #ifdef LETKF_STAGED_MIN_K   // A/B twins (make VARIANT=...): the same switch at compile time
   if (a.mode != 2 && a.k >= LETKF_STAGED_MIN_K) wave = false;
 #endif

@@ -1,9 +1,10 @@
-"""The eigen-free observation-space points of the staged path (k > 100, n < k, loop body without k x k outputs;
+"""The eigen-free points of the staged path (k >= 63, loop body without k x k outputs;
 csrc/letkf_staged.hip poly_apply, include/letkf_amd.h LETKF_OPT_STAGED_POLY): the transform, w-bar and the RTPS
 quadratic form as Chebyshev expansions in M = Z Z^T + (k-1)/rho I instead of through mtx_eigen's replacement.
 Each case runs the SAME call twice -- option on and off -- and requires (1) both within the loop body's tolerance of the
 oracle's restatement of scale/letkf/letkf_tools.f90:313-527 (1e-10 * max(|x-bar|, |x'|) per variable, inflation 1e-12),
-(2) the two within 1e-11 of each other, (3) the sweep counts to show which path a point took: nsweep = -(Chebyshev degree) with the option
+(2) the two within 1e-11 of each other (option off: the Jacobi eigen stage for k > 100, the two-wave Jacobi kernel of
+csrc/letkf_wave.hip for 63 <= k <= 100), (3) the sweep counts to show which path a point took: nsweep = -(Chebyshev degree) with the option
 on (2 <= n < k: expansion in the n x n matrix; n >= k, k <= 512: in the k x k matrix), > 0 with it off."""
 import numpy as np
 import pytest
@@ -54,7 +55,7 @@ def oracle(c, k, nv, cfg):
 
 
 @pytest.mark.parametrize("name", ["rtps_adaptive_det", "rtpp", "rtps_qtop", "norelax"])
-@pytest.mark.parametrize("k,npts,nobs_tot,n_mean", [(144, 24, 500, 70), (144, 20, 600, 140), (320, 16, 700, 150), (320, 8, 900, 330), (1000, 4, 600, 200)])
+@pytest.mark.parametrize("k,npts,nobs_tot,n_mean", [(64, 16, 300, 40), (80, 16, 400, 100), (100, 24, 500, 70), (100, 16, 600, 150), (144, 24, 500, 70), (144, 20, 600, 140), (320, 16, 700, 150), (320, 8, 900, 330), (1000, 4, 600, 200)])
 def test_polynomial_points_equal_jacobi_points_and_oracle(name, k, npts, nobs_tot, n_mean):
     from test_gpu_das import CONFIGS, compare_anal
     cfg = CONFIGS[name]
