@@ -395,7 +395,9 @@ __global__ void __launch_bounds__(kGBlock) letkf_stage_gram_kernel(const StagedA
         const double bound = fmax(fmin(sqrt(f2), r1) * (1.0 + 1e-12), 1e-6 * shift);
         const double sk = sqrt((shift + bound) / shift);
         const double rate = (sk - 1.0) / (sk + 1.0);
-        int deg = rate > 0.0 ? (int)ceil(log(1e-16) / log(rate)) + 1 : 4;
+        int deg = 1 << 20;                             // (rate -> 1: hopeless, and log(rate) -> -0 must not reach the cast)
+        if (!(rate > 0.0)) deg = 4;
+        else if (rate < 0.999) deg = (int)ceil(log(1e-16) / log(rate)) + 1;
         if (deg < 4) deg = 4;
         if (f2 <= 1.7e308 && deg <= S.poly_max_deg) {   // (a NaN / Inf anywhere in M makes the sum of squares fail this test:
                                                         //  the eigen stage then reports the point, status 1)

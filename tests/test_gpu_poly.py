@@ -88,18 +88,23 @@ def test_polynomial_points_equal_jacobi_points_and_oracle(name, k, npts, nobs_to
         assert (w1[big] < 0).any(), (n[big], w1[big])
 
 
-def test_badly_conditioned_points_stay_on_the_jacobi():
+@pytest.mark.parametrize("scale", [1e-4, 1e-40])
+def test_badly_conditioned_points_stay_on_the_jacobi(scale):
     """tiny observation errors: |Z Z^T| >> (k-1)/rho, the Chebyshev degree for 1e-16 exceeds the cap and the point keeps
     the eigen stage -- same answer either way"""
     from test_gpu_das import CONFIGS, compare_anal
     cfg = CONFIGS["rtps"]
     k = 144
     c = das_case(k=k, nv=11, npts=12, nobs_tot=400, n_mean=60, seed=77, infl0=1.0)
-    c["rdiag"] = c["rdiag"] * 1e-4                    # errors 100 x smaller
-    ref = oracle(c, k, 11, cfg)
+    c["rdiag"] = c["rdiag"] * scale                   # errors 100 x smaller; 1e-20 x: cond ~ 1e40, the degree estimate saturates
     a1, i1, s1, w1 = run(c, k, 11, cfg, poly=True)
+    n = np.diff(c["obs_off"])
+    if scale < 1e-10:                                 # (no parity claim at cond 1e40: only that the point is NOT taken)
+        small = (n >= 2) & (c["beta"] != 0.0)
+        assert small.any() and (w1[small] >= 0).all(), (n, w1)
+        return
+    ref = oracle(c, k, 11, cfg)
     assert (s1 == 0).all()
     compare_anal(c, ref, a1, k, 11, False)
-    n = np.diff(c["obs_off"])
     small = (n >= 8) & (n < k) & (c["beta"] != 0.0)
     assert small.any() and (w1[small] > 0).all(), (n, w1)
