@@ -461,17 +461,18 @@ __device__ __forceinline__ void rows_comb(const double* __restrict__ Cm, const i
   }
 }
 
-// ---------------------------------------------------------------- the polynomial ("eigen-free") apply, observation space
+// ---------------------------------------------------------------- the polynomial ("eigen-free") apply
 // Everything stage 3 takes from the eigen-decomposition M = U L U^T of the n x n matrix M = Z Z^T + c I is a FUNCTION of M
 // applied to a handful of vectors: q_b = U g(L) U^T t_b for the nb right-hand sides t_0,1 = sqrt(w) dep(_det), t_2+v = Z x'_v,
 // with g = 1/L for w-bar and g = the T spectrum -sqrt(k-1) / (sqrt(c) sqrt(L) (sqrt(c) + sqrt(L))) for the members, plus the
 // quadratic forms t^T M^-1 t of RTPS (var_a, letkf_tools.f90:1981-1990).  The shift c = (k-1)/rho keeps cond(M) small
-// (C3 / C5: 1.5 exact, ~3 with the free norm bound of stage 1), so a Chebyshev expansion of g on [c, c + |S|] reaches
+// (C3 / C5: 1.5 exact, ~2.3 with the free norm bound of stage 1), so a Chebyshev expansion of g on [c, c + |S|] reaches
 // 1e-16 in ~20-30 terms: 2 n^2 nb flops each -- a third of the flops of the Jacobi's ~9 sweeps, and regular, barrier-
 // per-degree work instead of a latency-bound iteration.  The functions are analytic on the interval (the nearest
 // singularity is L = 0), the coefficients come from interpolation at the Chebyshev nodes of the point's own interval.
-// Thread i owns row i (n <= blockDim.x): T_d[b][i] in registers, the current T_d of all rows in LDS ([row][NBP], read as
-// broadcasts), ping-pong, one barrier per degree.  On return q_b[i] sits in pcq[b * nq + i] and va[v] = t_v^T M^-1 t_v.
+// The same holds in member space for a point with n >= k: functions of the k x k matrix A = Z^T Z + c I applied to r, r_det,
+// x'_v (g_T = sqrt(k-1) / sqrt(L); dual == false).  On return q_b[i] sits in qout[b * nq + i] (dual: the LDS copy that the
+// Z^T q pass reads; primal: OUT itself) and va[v] = t_v^T M^-1 t_v.
 // The product M T_d runs on the FP64 matrix cores (v_mfma_f64_16x16x4: A = a 16 x 4 tile of M straight from L2 -- lane l
 // loads M[i0 + (l & 15)][j0 + (l >> 4)], 128 contiguous bytes per 16 lanes --, B = 4 rows of T_d from LDS, lane l reads
 // T[j0 + (l >> 4)][l & 15] = 64 consecutive doubles, conflict-free; D: lane l holds rows (l >> 4) + 4 r, r < 4, of column
