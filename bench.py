@@ -49,6 +49,10 @@ def main():
     ap.add_argument("--ensval", default="iid", choices=["iid", "correlated"],
                     help="obs-space perturbations: independent draws, or an H-like combination of the (spatially "
                          "smooth) state perturbations around every observation + noise (SURVEY.md section 8(d))")
+    ap.add_argument("--obs-spread", type=float, default=0.0,
+                    help="scale the obs-space perturbations so that their standard deviation is this many observation "
+                         "errors (0: as generated -- 0.67 for iid, 0.81 for correlated); 2-3 is ordinary for radar "
+                         "reflectivity in convection")
     ap.add_argument("--max-nobs", type=int, default=0,
                     help="MAX_NOBS_PER_GRID: two radar ctypes on the lattice, each limited to this many observations")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -159,6 +163,11 @@ def main():
     ctx.to_perturbations(k, nv, npts, w["gues"], w["sp"], w["sm"], w["sv"])
     if args.ensval == "correlated":
         bw.correlate_ensval(w)      # needs the perturbations
+    spread_built = float(w["ensval"][:, :k].std().item()) / w["cfg"]["err"]
+    if args.obs_spread > 0.0:
+        w["ensval"][:, :k] *= args.obs_spread / spread_built
+        w["dep"] *= ((1.0 + args.obs_spread ** 2) / (1.0 + spread_built ** 2)) ** 0.5   # departures ~ N(0, err^2 + spread^2)
+    obs_spread = args.obs_spread if args.obs_spread > 0.0 else spread_built
     search_ms = None
     in_step = args.lists in ("search", "columns") and not args.no_search_in_step
     if args.lists != "torch":
@@ -271,9 +280,10 @@ def main():
         elapsed = float(tt.item())
     bad = int((status != 0).sum().item())
     sweeps_mean = float(nsweep.clamp(min=0).double().mean().item())
-    # points of the staged path analysed without an eigen stage report -(Chebyshev degree) (include/letkf_amd.h)
+    # points of the staged path analysed without an eigen stage report -(CG iterations) (include/letkf_amd.h)
     npoly = int((nsweep < 0).sum().item())
     cheb_deg_mean = float((-nsweep[nsweep < 0]).double().mean().item()) if npoly else None
+    cheb_deg_max = int((-nsweep[nsweep < 0]).max().item()) if npoly else None
     solves = npts * args.steps * world
     value = solves / elapsed
 
@@ -332,7 +342,7 @@ def main():
                "data": "synthetic",
                "config": {"workload": f"{args.workload}: {w['cfg']['nx']}x{w['cfg']['ny']}x{w['cfg']['nz']} grid, "
                                       f"k={k} members, nv={nv}, mean {n_mean:.1f} (max {w['n_max']}) local obs/point, "
-                                      f"relax={args.relax}, ensval={args.ensval}" + (", state member-fastest" if args.state_layout == "member" else "")
+                                      f"relax={args.relax}, ensval={args.ensval}, obs-space spread {obs_spread:.2f} obs errors" + (", state member-fastest" if args.state_layout == "member" else "")
                                       + (f", MAX_NOBS_PER_GRID={args.max_nobs} x 2 ctypes" if args.max_nobs else ""),
                           "points_per_gpu": npts, "obs_table_rows": int(w["ensval"].shape[0]),
                           "parallelism": f"grid-point shard x{n_gpus}" + ((" + RCCL obs all-gather (" + args.exchange + ")") if world > 1 else "")},
@@ -340,7 +350,9 @@ def main():
                "analysis_wall_s": elapsed / args.steps, "cycle_ms": elapsed / args.steps * 1e3,
                "solve_only_solves_per_s": (npts * world / kern_s) if kern_s > 0 else None,
                "nonzero_status_points": bad,
-               "jacobi_sweeps_mean": sweeps_mean, "chebyshev_points": npoly, "chebyshev_degree_mean": cheb_deg_mean,
+               "jacobi_sweeps_mean": sweeps_mean, "eigenfree_points": npoly, "eigenfree_iterations_mean": cheb_deg_mean, "eigenfree_iterations_max": cheb_deg_max,
+               "eigenfree_fallback_points": (int(((nsweep > 0) & (status == 0)).sum().item()) if npoly else 0),
+               "obs_spread": obs_spread,
                "lists": args.lists, "search_ms": search_ms,
                "search_in_step": bool(in_step),
                "parity_sample_max_rel": parity, "parity_tolerance": 1e-10,

@@ -242,10 +242,13 @@ def alg_flops_dual(n, k, nv):
 
 
 def alg_flops_poly(n, k, nv, deg):
-    """The observation-space analysis without an eigen-decomposition (letkf_staged.hip poly_apply): Z Z^T, deg products
-    of the n x n matrix with the nb = nv + 2 right-hand sides (the Chebyshev recurrence), Z b and Z^T q."""
+    """The analysis without an eigen-decomposition (letkf_krylov.hip): the Gram of the smaller formulation (order
+    m = min(n, k)), deg products of the m x m matrix with the nb = nv + 2 right-hand sides (CG iterations), the CG vector
+    updates and the combination of the residual history, Z b and Z^T q."""
     nb = nv + 2
-    return 2.0 * n * n * k + deg * 2.0 * n * n * nb + 2.0 * (2.0 * n * k * nb) + 6.0 * deg * n * nb + 4.0 * nv * k
+    m = min(n, k)
+    side = 2.0 * (2.0 * n * k * nb) if n < k else 2.0 * n * k * 2
+    return 2.0 * m * m * max(n, k) + deg * 2.0 * m * m * nb + side + 14.0 * deg * m * nb + 4.0 * nv * k
 
 
 def alg_flops_required(n, k, nv, rtps=True):

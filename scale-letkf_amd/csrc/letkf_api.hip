@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -273,8 +274,14 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
 // above), apply stage -- all on the context's stream, no host synchronisation in between.
 int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
   const int kkout = (a.trans_out || a.pa_out) ? 1 : 0;
-  const long wpp = letkf::staged_ws_per_point(a.k, a.nv, kkout);
-  const size_t budget = (size_t)6 << 30;                              // slabs of one batch: at most 6 GiB
+  // eigen-free stage (letkf_krylov.hip): the loop body without k x k outputs, any k whose point matrices (order min(n, k))
+  // fit the stage (<= 512 rows; larger orders keep the eigen stage)
+  const bool krylov = a.mode == 0 && !kkout && c->staged_poly;
+  const long hist = krylov ? letkf::stage_krylov_hist_doubles(a.k) : 0;
+  const long wpp = letkf::staged_ws_per_point(a.k, a.nv, kkout, hist);
+  // slabs of one batch: at most 6 GiB (+ as much again per 2 MB of residual history per point, up to 24 GiB)
+  size_t budget = (size_t)6 << 30;
+  if (hist) budget += std::min<size_t>((size_t)18 << 30, (size_t)hist * sizeof(double) * 3072);
   long nb = (long)(budget / ((size_t)wpp * sizeof(double)));
   const long want = (long)c->num_cu * 16;
   if (nb > want) nb = want;
@@ -296,12 +303,7 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
   s.info = s.meta + 2 * nb;
   s.kkout = kkout;
   s.wg_max_order = letkf::eig_wg_max_order();
-  // eigen-free observation-space points (letkf_staged.hip, poly_apply): the loop body without k x k outputs
-  // (its node values and coefficients live in stage 3's [k + 2] LDS arrays, the 8 x 16 per-wave partials of the quadratic
-  // forms in the first two of them, which are contiguous: k >= 63; smaller k with nv != 11 comes here too and keeps the eigen stage)
-  s.poly_max_deg = 64;
-  s.poly_max_n = (a.mode == 0 && !kkout && c->staged_poly && a.k + 2 >= s.poly_max_deg + 1 && 2 * (a.k + 2) >= 8 * 16)
-                     ? letkf::stage_poly_max_n(a.k, a.nv) : 0;
+  s.poly_max_n = krylov ? letkf::stage_krylov_max_n(a.k) : 0;
   s.A.max_sweep = 60;
   EventPair ev;
   if (c->timing) {
@@ -317,6 +319,7 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
     s.pt0 = p0;
     s.nbatch = (a.npts - p0 < nb) ? a.npts - p0 : nb;
     HIP_TRY(letkf::launch_stage_gram(s, c->lds_max, c->stream));
+    if (s.poly_max_n > 0) HIP_TRY(letkf::launch_stage_krylov(s, c->lds_max, c->stream));   // (points it gives up: eigen stage, next)
     letkf::EigArgs e;
     e.ws = s.A.ws;
     e.ws_per_point = wpp;
@@ -334,9 +337,9 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
     c->events.emplace_back(ev.e0, ev.e1);
     ev.e0 = ev.e1 = nullptr;
   }
-  c->last_path = std::string("staged: letkf_stage_gram_kernel + ") + (s.poly_max_n > 0 ? "[n < k: Chebyshev apply, no eigen stage] " : "") +
+  c->last_path = std::string("staged: letkf_stage_gram_kernel + ") + (s.poly_max_n > 0 ? "letkf_stage_krylov_kernel (CG + Lanczos; points it gives up: " : "") +
                  (a.k <= 128 ? "letkf_eig_wg_kernel<4,32,32,1>" : "letkf_eig_wg_kernel<4,52,16,2>") +
-                 (a.k > s.wg_max_order ? " / letkf_eig_block_kernel" : "") + " + letkf_stage_apply_kernel";
+                 (a.k > s.wg_max_order ? " / letkf_eig_block_kernel" : "") + (s.poly_max_n > 0 ? ")" : "") + " + letkf_stage_apply_kernel";
   return LETKF_OK;
 }
 

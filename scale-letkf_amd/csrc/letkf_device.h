@@ -85,9 +85,10 @@ struct PointArgs {
 
 // Staged (three-kernel) path, letkf_staged.hip / letkf_eig.hip: per point of a batch one workspace slab
 //   G [k * ldg] | V0 [k] | V1 [k] | SC [16] | X [nv k] | TT [nb k] | PC [nb k] | QQ [nb k] | OUT [nb k] | (W [k * ldg])
-// (ldg = k | 1, nb = nv + 2), meta[2 it] = mode | solver << 8 (mode 0: no eigenproblem, 1: primal k x k, 2: dual
-// n x n; solver 1: workgroup Jacobi, 2: block Jacobi), meta[2 it + 1] = matrix order m, info[2 it] = sweeps,
-// info[2 it + 1] = converged.
+// (ldg = k | 1, nb = nv + 2; + the residual history H of the eigen-free stage), meta[2 it] = mode | solver << 8 (mode 0: no
+// eigenproblem, 1: primal k x k, 2: dual n x n; solver 1: workgroup Jacobi, 2: block Jacobi, 3: eigen-free stage, which
+// rewrites it to 1 / 2 for a point it gives up), meta[2 it + 1] = matrix order m, info[2 it] = sweeps (eigen-free:
+// -(iterations)), info[2 it + 1] = converged.
 struct EigArgs {
   double* ws;
   long ws_per_point;
@@ -104,16 +105,18 @@ struct StagedArgs {
   int* info;
   int kkout;           // slab carries W (k x k outputs requested)
   int wg_max_order;    // largest order the workgroup Jacobi takes
-  int poly_max_n;      // eigen-free observation-space points (letkf_staged.hip, "polynomial path"): most rows, 0 = off
-  int poly_max_deg;    // ... and the highest Chebyshev degree worth it (above: the Jacobi)
+  int poly_max_n;      // eigen-free points (letkf_krylov.hip: conjugate gradients + Lanczos instead of an eigen-decomposition): largest order, 0 = off
 };
 int stage_apply_pcq_doubles(int k, int nv);
-int stage_poly_max_n(int k, int nv);
+int stage_krylov_max_n(int k);
+int stage_krylov_max_iter();
+long stage_krylov_hist_doubles(int k);
+hipError_t launch_stage_krylov(const StagedArgs& s, size_t lds_max, hipStream_t st);
 size_t eig_wg_lds_bytes(int NP, int RP, int RBR, int SB);
 int eig_wg_max_order();
 hipError_t launch_eig_wg(const EigArgs& e, int mcap, int num_cu, hipStream_t st);
 hipError_t launch_eig_block(const EigArgs& e, int kmax, int num_cu, hipStream_t st);
-long staged_ws_per_point(int k, int nv, int kkout);
+long staged_ws_per_point(int k, int nv, int kkout, long hist);
 hipError_t launch_stage_gram(const StagedArgs& s, size_t lds_max, hipStream_t st);
 hipError_t launch_stage_apply(const StagedArgs& s, hipStream_t st);
 

@@ -1,0 +1,511 @@
+// letkf_krylov.hip -- the eigen-free stage of the staged path (between the Gram stage and the apply stage of
+// letkf_staged.hip): everything the loop body of das_letkf (scale/letkf/letkf_tools.f90:313-527) takes from the
+// eigen-decomposition of letkf_core (common/common_letkf.f90:127-206) is a FUNCTION of the point's symmetric positive
+// definite matrix M applied to nb = nv + 2 vectors,
+//     q_b = M^-1 t_b        b = 0, 1          (w-bar and the deterministic member's weights; :169-195)
+//     q_b = g_T(M) t_b      b = 2 .. nv + 1   (the transform T applied to the perturbations x'_v; :197-216)
+//     va_v = t_v^T M^-1 t_v                   (RTPS, letkf_tools.f90:1981-1990)
+// with, in observation space (n < k: M = Z Z^T + c I, t_0,1 = sqrt(w) dep(_det), t_2+v = Z x'_v),
+//     g_T(L) = -sqrt(k-1) / (sqrt(c) sqrt(L) (sqrt(c) + sqrt(L)))   (T = sqrt(rho) I + Z^T g_T(M) Z)
+// and in member space (n >= k: M = A = Z^T Z + c I, t_0,1 = r, r_det, t_2+v = x'_v), g_T(L) = sqrt((k-1) / L).
+//
+// Round 2 expanded both functions in Chebyshev polynomials of M on [c, c + |S|] with a norm bound |S| >= lambda_max: the
+// degree grows with sqrt(cond), the norm bound overestimates cond, and above degree 64 (cond ~ 12: ensemble spread in
+// observation space of ~1.6 observation errors) the point fell back to the Jacobi.  This stage needs no bound and has no
+// cliff: CONJUGATE GRADIENTS on all right-hand sides at once (one product M R per iteration on the FP64 matrix cores, the
+// columns otherwise independent: their own alpha, beta) solve M q = t, and the Lanczos tridiagonal T_m that the CG
+// coefficients define (T_jj = 1/alpha_j + beta_j/alpha_j-1, T_j,j+1 = sqrt(beta_j+1)/alpha_j; Lanczos vectors
+// v_j = (-1)^j r_j / |r_j|) gives g_T(M) t ~ |t| V_m g_T(T_m) e_1 for the same Krylov space.  Krylov methods adapt to the
+// spectrum: the few dominant modes that correlated observations create cost one or two iterations each instead of
+// stretching the interval of a polynomial (spread 2.4 observation errors, cond 20-57: 28-30 iterations against a degree of
+// 80-140; cond 1.5: 14 against 23), the iteration ends on its own residual |r_j| <= 1e-15 |t|, and g_T(T_m) e_1 -- m <= 128
+// rows per column -- is a Chebyshev expansion on the TRIDIAGONAL matrix (three multiply-adds per row and degree, any
+// degree), its interval from Gershgorin's circles of T_m itself.  The residuals r_j go to the point's slab in a
+// lane-private layout (every lane reads back exactly what it wrote) and are combined once g_T(T_m) e_1 is known.
+// A point that does not converge in 128 iterations (or meets a non-positive curvature: M not positive definite to
+// rounding, NaN) is handed to the eigen stage, which runs after this kernel: meta's solver field is rewritten.
+//
+// Data flow of the product: a wave owns the 16-row blocks w, w + 8, ... (BPW of them) of the result; A operand = a 16 x 4
+// tile of M straight from the slab (lane l loads M[j0 + (l >> 4)][i0 + (l & 15)]: 128 contiguous bytes per 16 lanes; loads
+// of the next group of tiles are issued before the matrix-core instructions of the current one), B operand = 4 rows of
+// the residual block from LDS ([row][16]: the right-hand sides padded to 16 columns; 64 consecutive doubles per read),
+// D: lane l holds rows (l >> 4) + 4 r, r < 4, of column l & 15.  r, p, q = M p and x live in registers in D's layout.
+// Two barriers per iteration (single-reduction CG, Chronopoulos / Gear: rho = r.r and mu = r.Mr, then
+// beta = rho / rho', alpha = rho / (mu - rho beta / alpha')).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "letkf_jacobi_dev.h"
+#include "letkf_staged_dev.h"
+
+namespace letkf {
+
+using namespace staged_dev;
+using jacobi_dev::dpp_shift0;
+
+namespace {
+
+constexpr int kKBlock = 512;
+constexpr int kMmax = 128;        // CG iterations (rows of the Lanczos tridiagonal: two per lane)
+constexpr int kDcap = 1022;       // highest Chebyshev degree of the tridiagonal function (cond ~ 3000)
+constexpr double kTol2 = 1e-30;   // |r_j|^2 <= 1e-30 |t|^2
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct KryLds {
+  double* rbuf;    // [nr16cap][16]   the residual block, B operand of the product
+  double* ha;      // [kMmax][16]     alpha_j per column
+  double* hb;      // [kMmax][16]     beta_j
+  double* hr;      // [kMmax][16]     rho_j = |r_j|^2; later the combination coefficients
+  double* red;     // [2][8][16]      per-wave partial sums
+  double* cT;      // [kDcap + 2]     Chebyshev coefficients of g_T on the tridiagonals' interval
+  double* fT;      // [kDcap + 2]     g_T at the nodes
+  double* swl;     // [512]           sqrt(w_i) (dual)
+  double* misc;    // [32]
+};
+
+// One point.  Returns false when the point has to go to the eigen stage.
+template <int BPW>
+__device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, const int n, const int ldg, const int k,
+                                             const int nv, const int nbr, const double shift, const bool dual, int* iters_out) {
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
+  const int nr16 = (n + 15) & ~15, nblk = nr16 >> 4;
+  const int col = lane & 15, rq = lane >> 4;
+  double rr[BPW][4], pp[BPW][4], qq[BPW][4], xx[BPW][4];
+  // ---- r_0 = t, rho_0
+  {
+    double ps = 0.0;
+#pragma unroll
+    for (int bi = 0; bi < BPW; ++bi) {
+      const int i0 = (wv + bi * nwv) * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = i0 + rq + 4 * r;
+        rr[bi][r] = (row < n && col < nbr) ? sl.TT[(size_t)col * k + row] : 0.0;
+        pp[bi][r] = qq[bi][r] = xx[bi][r] = 0.0;
+        ps = fma(rr[bi][r], rr[bi][r], ps);
+        if (i0 < nr16) L.rbuf[(size_t)row * 16 + col] = rr[bi][r];
+      }
+    }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    if (lane < 16) L.red[wv * 16 + lane] = ps;
+  }
+  __syncthreads();
+  // A operand addresses: row i0 + col of M's column j (M is symmetric: column j of the slab = row j), clamped into the
+  // matrix -- padding rows / columns meet zero rows of the residual block or are dropped at the use
+  const double* arow[BPW];
+#pragma unroll
+  for (int bi = 0; bi < BPW; ++bi) {
+    const int row = (wv + bi * nwv) * 16 + col;
+    arow[bi] = sl.G + (row < n ? row : n - 1);
+  }
+  constexpr int KS = 8 / BPW > 1 ? 8 / BPW : 2;            // k-steps (4 columns of M each) per group of loads
+  const int ngrp = (nr16 / 4 + KS - 1) / KS;
+  double rho_old = 1.0, alpha_old = 1.0, tn2 = 0.0;
+  bool frozen = false, failed = false;
+  int mj = 0, j = 0;
+  for (;; ++j) {
+    double rho = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) rho += L.red[w * 16 + col];
+    if (j == 0) tn2 = rho;
+    if (!(rho == rho)) failed = true;                       // NaN anywhere in M or t
+    if (!frozen && !(rho > kTol2 * tn2)) {
+      frozen = true;
+      mj = j;
+    }
+    const bool all_frozen = __ballot(frozen) == ~0ull;
+    const bool any_failed = __ballot(failed) != 0ull;
+    if (all_frozen || any_failed || j == kMmax) break;      // (the same in every wave: all read the same sums)
+
+    // ---- w = M r_j
+    d4 acc[BPW];
+#pragma unroll
+    for (int bi = 0; bi < BPW; ++bi) acc[bi] = (d4){0.0, 0.0, 0.0, 0.0};
+    double av[2][BPW][KS];
+    auto fetch = [&](int g, double (&dst)[BPW][KS]) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int jj = (g * KS + s) * 4 + rq;
+        const size_t off = (size_t)(jj < n ? jj : n - 1) * ldg;
+#pragma unroll
+        for (int bi = 0; bi < BPW; ++bi) dst[bi][s] = arow[bi][off];
+      }
+    };
+    auto mma = [&](int g, const double (&src)[BPW][KS]) {
+      double bq[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int j0 = (g * KS + s) * 4;
+        bq[s] = j0 < nr16 ? L.rbuf[(size_t)j0 * 16 + lane] : 0.0;
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if ((g * KS + s) * 4 < nr16) {                      // (wave-uniform)
+#pragma unroll
+          for (int bi = 0; bi < BPW; ++bi)
+            if ((wv + bi * nwv) * 16 < nr16) acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(src[bi][s], bq[s], acc[bi], 0, 0, 0);
+        }
+      }
+    };
+    fetch(0, av[0]);
+    for (int g = 0; g < ngrp; g += 2) {
+      if (g + 1 < ngrp) fetch(g + 1, av[1]);
+      mma(g, av[0]);
+      if (g + 2 < ngrp) fetch(g + 2, av[0]);
+      if (g + 1 < ngrp) mma(g + 1, av[1]);
+    }
+    // ---- mu = r . w per column
+    double wreg[BPW][4];
+    double pm = 0.0;
+#pragma unroll
+    for (int bi = 0; bi < BPW; ++bi) {
+      const int i0 = (wv + bi * nwv) * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        wreg[bi][r] = (i0 + rq + 4 * r < n) ? acc[bi][r] : 0.0;
+        pm = fma(rr[bi][r], wreg[bi][r], pm);
+      }
+    }
+    pm += __shfl_xor(pm, 16, 64);
+    pm += __shfl_xor(pm, 32, 64);
+    if (lane < 16) L.red[128 + wv * 16 + lane] = pm;
+    __syncthreads();
+    double mu = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) mu += L.red[128 + w * 16 + col];
+    double alpha = 0.0, beta = 0.0;
+    if (!frozen) {
+      beta = j == 0 ? 0.0 : rho / rho_old;
+      const double denom = j == 0 ? mu : mu - rho * beta / alpha_old;
+      if (!(denom > 0.0)) failed = true;                    // M is not positive definite to rounding (or NaN)
+      alpha = rho / denom;
+      rho_old = rho;
+      alpha_old = alpha;
+    }
+    if (wv == 0 && lane < 16) {
+      L.ha[j * 16 + lane] = alpha;
+      L.hb[j * 16 + lane] = beta;
+      L.hr[j * 16 + lane] = rho;
+    }
+    // ---- r_j to the history (lane-private), then the updates
+    double ps = 0.0;
+#pragma unroll
+    for (int bi = 0; bi < BPW; ++bi) {
+      const int blk = wv + bi * nwv;
+      if (blk < nblk) {
+        double* hj = sl.H + (((size_t)j * nblk + blk) * 4) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          hj[r * 64] = rr[bi][r];
+          pp[bi][r] = fma(beta, pp[bi][r], rr[bi][r]);
+          qq[bi][r] = fma(beta, qq[bi][r], wreg[bi][r]);
+          xx[bi][r] = fma(alpha, pp[bi][r], xx[bi][r]);
+          rr[bi][r] = fma(-alpha, qq[bi][r], rr[bi][r]);
+          ps = fma(rr[bi][r], rr[bi][r], ps);
+          L.rbuf[(size_t)(blk * 16 + rq + 4 * r) * 16 + col] = rr[bi][r];
+        }
+      }
+    }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    if (lane < 16) L.red[wv * 16 + lane] = ps;
+    __syncthreads();
+  }
+  const int iters = j;
+  *iters_out = iters;
+  if (__ballot(failed) != 0ull || !(__ballot(frozen) == ~0ull)) return false;
+
+  // ================= g_T(T_m) e_1 for the columns b >= 2, m_b = mj rows each
+  // (a) the tridiagonals: wave w takes the columns 2 + w and 2 + w + 8; lane l holds rows 2l and 2l + 1
+  constexpr int NC = 2;
+  double a0[NC], a1[NC], bL[NC], bM[NC], bR[NC];
+  int mb[NC];
+  double gmax = 0.0;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int b = 2 + wv + 8 * c;
+    mb[c] = 0;
+    a0[c] = a1[c] = bL[c] = bM[c] = bR[c] = 0.0;
+    if (b < nbr) {                                          // (wave-uniform)
+      mb[c] = __shfl(mj, b, 64);                            // lane b (rq = 0) carries column b's count
+      const int m = mb[c];
+      auto diag = [&](int jj) -> double {
+        if (jj >= m) return 0.0;
+        double d = 1.0 / L.ha[jj * 16 + b];
+        if (jj > 0) d += L.hb[jj * 16 + b] / L.ha[(jj - 1) * 16 + b];
+        return d;
+      };
+      auto offd = [&](int jj) -> double {                   // between rows jj and jj + 1
+        if (jj < 0 || jj + 1 >= m) return 0.0;
+        return sqrt(L.hb[(jj + 1) * 16 + b]) / L.ha[jj * 16 + b];
+      };
+      a0[c] = diag(2 * lane);
+      a1[c] = diag(2 * lane + 1);
+      bL[c] = offd(2 * lane - 1);
+      bM[c] = offd(2 * lane);
+      bR[c] = offd(2 * lane + 1);
+      gmax = fmax(gmax, fmax(a0[c] + bL[c] + bM[c], a1[c] + bM[c] + bR[c]));
+    }
+  }
+#pragma unroll
+  for (int mk = 1; mk < 64; mk <<= 1) gmax = fmax(gmax, __shfl_xor(gmax, mk, 64));
+  if (lane == 0) L.misc[wv] = gmax;
+  __syncthreads();
+  double hi = 0.0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) hi = fmax(hi, L.misc[w]);
+  // (b) interval, degree, Chebyshev coefficients of g_T.  Ritz values lie in [lambda_min(M), lambda_max(M)], and
+  // lambda_min(M) >= c; the margin below c covers the rounding of the recurrence
+  const double lo = shift * (1.0 - 1e-9);
+  hi = fmax(hi * (1.0 + 1e-12), shift * (1.0 + 1e-6));
+  const double sk = sqrt(hi / lo), rate = (sk - 1.0) / (sk + 1.0);
+  int deg = (int)ceil(log(1e-17) / log(rate)) + 2;
+  if (!(deg >= 4)) deg = 4;
+  if (deg > kDcap) return false;                            // (uniform: hi is the same in every thread)
+  const int N = deg + 1;
+  const double half = 0.5 * (hi - lo), mid = 0.5 * (hi + lo), inv = 1.0 / half;
+  const double sqc = sqrt(shift), sqkm1 = sqrt((double)(k - 1));
+  for (int jn = tid; jn < N; jn += nthr) {
+    const double Lm = fma(half, cospi(((double)jn + 0.5) / (double)N), mid);
+    const double sL = sqrt(Lm);
+    L.fT[jn] = dual ? -sqkm1 / (sqc * sL * (sqc + sL)) : sqkm1 / sL;
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += nthr) {
+    // c_i = (2 - [i = 0]) / N sum_j g(x_j) cos(pi i (j + 1/2) / N); the cosines by rotation, re-seeded every 32 nodes
+    const double th = (double)i / (double)N;
+    const double cd = cospi(th), sd = sinpi(th);
+    double s_ = 0.0, cc = 0.0, ss = 0.0;
+    for (int jn = 0; jn < N; ++jn) {
+      if ((jn & 31) == 0) {
+        const double arg = (double)i * ((double)jn + 0.5) / (double)N;
+        cc = cospi(arg);
+        ss = sinpi(arg);
+      }
+      s_ = fma(L.fT[jn], cc, s_);
+      const double c2 = fma(cc, cd, -ss * sd);
+      ss = fma(ss, cd, cc * sd);
+      cc = c2;
+    }
+    L.cT[i] = s_ * ((i == 0 ? 1.0 : 2.0) / (double)N);
+  }
+  __syncthreads();
+  // (c) y = sum_d c_d T_d(T~) e_1, T~ = (T_m - mid) / half; then the combination coefficients y_j (-1)^j |t| / |r_j|
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int b = 2 + wv + 8 * c;
+    if (b < nbr) {
+      const int m = mb[c];
+      const double d0 = (a0[c] - mid) * inv, d1 = (a1[c] - mid) * inv;
+      const double eL = bL[c] * inv, eM = bM[c] * inv, eR = bR[c] * inv;
+      const bool r0 = 2 * lane < m, r1 = 2 * lane + 1 < m;
+      double u0 = lane == 0 && m > 0 ? 1.0 : 0.0, u1 = 0.0;   // T_0 e_1
+      double y0 = L.cT[0] * u0, y1 = 0.0;
+      // T_1
+      double nL = dpp_shift0<0x138>(u1), nR = dpp_shift0<0x130>(u0);
+      double v0 = r0 ? fma(d0, u0, fma(eM, u1, eL * nL)) : 0.0;
+      double v1 = r1 ? fma(d1, u1, fma(eM, u0, eR * nR)) : 0.0;
+      y0 = fma(L.cT[1], v0, y0);
+      y1 = fma(L.cT[1], v1, y1);
+      const double d0_2 = 2.0 * d0, d1_2 = 2.0 * d1, eL2 = 2.0 * eL, eM2 = 2.0 * eM, eR2 = 2.0 * eR;
+      for (int d = 2; d <= deg; ++d) {
+        nL = dpp_shift0<0x138>(v1);
+        nR = dpp_shift0<0x130>(v0);
+        const double t0 = r0 ? fma(d0_2, v0, fma(eM2, v1, fma(eL2, nL, -u0))) : 0.0;
+        const double t1 = r1 ? fma(d1_2, v1, fma(eM2, v0, fma(eR2, nR, -u1))) : 0.0;
+        u0 = v0;
+        u1 = v1;
+        v0 = t0;
+        v1 = t1;
+        const double cdv = L.cT[d];
+        y0 = fma(cdv, v0, y0);
+        y1 = fma(cdv, v1, y1);
+      }
+      const double t2 = L.hr[b];                             // rho_0 = |t|^2
+      const double rj0 = r0 ? L.hr[(2 * lane) * 16 + b] : 1.0, rj1 = r1 ? L.hr[(2 * lane + 1) * 16 + b] : 1.0;
+      if (2 * lane < iters) L.hr[(2 * lane) * 16 + b] = r0 ? y0 * sqrt(t2 / rj0) : 0.0;
+      if (2 * lane + 1 < iters) L.hr[(2 * lane + 1) * 16 + b] = r1 ? -y1 * sqrt(t2 / rj1) : 0.0;
+    }
+  }
+  __syncthreads();
+  // (d) x_T = sum_j coef_j r_j from the history
+  double xt[BPW][4];
+#pragma unroll
+  for (int bi = 0; bi < BPW; ++bi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xt[bi][r] = 0.0;
+  if (col >= 2 && col < nbr) {
+#pragma unroll
+    for (int bi = 0; bi < BPW; ++bi) {
+      const int blk = wv + bi * nwv;
+      if (blk < nblk) {
+        for (int jj = 0; jj < iters; ++jj) {
+          const double cf = L.hr[jj * 16 + col];
+          const double* hj = sl.H + (((size_t)jj * nblk + blk) * 4) * 64 + lane;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xt[bi][r] = fma(cf, hj[r * 64], xt[bi][r]);
+        }
+      }
+    }
+  }
+  // ---- q_b (dual: QQ, read by the Z^T q pass of the apply stage; primal: OUT itself) and the quadratic forms
+  double* qout = dual ? sl.QQ : sl.OUT;
+  double pq = 0.0;
+#pragma unroll
+  for (int bi = 0; bi < BPW; ++bi) {
+    const int i0 = (wv + bi * nwv) * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + rq + 4 * r;
+      if (row < n && col < nbr) {
+        pq = fma(sl.TT[(size_t)col * k + row], xx[bi][r], pq);
+        qout[(size_t)col * k + row] = col < 2 ? xx[bi][r] : xt[bi][r];
+      }
+    }
+  }
+  pq += __shfl_xor(pq, 16, 64);
+  pq += __shfl_xor(pq, 32, 64);
+  if (lane < 16) L.red[wv * 16 + lane] = pq;
+  __syncthreads();
+  for (int v = tid; v < nv; v += nthr) {
+    double s_ = 0.0;
+    for (int w = 0; w < nwv; ++w) s_ += L.red[w * 16 + 2 + v];
+    sl.PC[v] = s_;                                          // va_v = t_v^T M^-1 t_v
+  }
+  return true;
+}
+
+}  // namespace
+
+// LDS: rbuf [16 nr16cap] | ha | hb | hr [kMmax 16 each] | red [256] | cT | fT [kDcap + 2 each] | swl [512] | misc [32]
+// (the staging copy of X' for the Z x' pass of an observation-space point overlays rbuf .. hr)
+// BPW: 16-row blocks per wave = the orders the instantiation takes (1: m <= 128, 2: <= 256, 4: <= 512); a launch passes over
+// the points of the other classes, so that each class has the registers of its own kernel
+template <int BPW>
+__global__ void __launch_bounds__(kKBlock, 1) letkf_stage_krylov_kernel(const StagedArgs S, const int nr16cap, const int r0, const int xcap) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const PointArgs& A = S.A;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
+  const int k = A.k, nv = A.nv, nb = nv + 2;
+  KryLds L;
+  L.rbuf = smem;
+  L.ha = L.rbuf + (size_t)16 * nr16cap;
+  L.hb = L.ha + kMmax * 16;
+  L.hr = L.hb + kMmax * 16;
+  L.red = smem + r0;                                         // (r0 >= 16 nr16cap + 3 kMmax 16)
+  L.cT = L.red + 256;
+  L.fT = L.cT + (kDcap + 2);
+  L.swl = L.fT + (kDcap + 2);
+  L.misc = L.swl + 512;
+  double* xl = smem;                                         // [nv k] when it fits (xcap doubles)
+
+  for (long it = blockIdx.x; it < S.nbatch; it += gridDim.x) {
+    const long pt = S.pt0 + it;
+    const int meta0 = S.meta[2 * it], m = S.meta[2 * it + 1];
+    if ((meta0 >> 8) != 3) continue;                         // (uniform for the workgroup)
+    {
+      const int per = (((m + 15) >> 4) + 7) >> 3;            // 16-row blocks per wave
+      if ((per <= 1 ? 1 : per <= 2 ? 2 : 4) != BPW) continue;
+    }
+    Slab sl = slab_of(A.ws + (size_t)it * A.ws_per_block, k, nv, S.kkout);
+    const bool dual = (meta0 & 0xff) == 2;
+    const double shift = sl.SC[3];
+    const double* g0 = A.gues + pt * A.sp;
+    ObsView ov;
+    ov.A = &A;
+    ov.pt = pt;
+    ov.o0 = A.obs_off[pt];
+    ov.n = (int)(A.obs_off[pt + 1] - ov.o0);
+    const int n = ov.n;
+    __syncthreads();                                         // (LDS of the previous point is free)
+    // ---- right-hand sides in the solver's space: TT[b][.]
+    if (!dual) {
+      for (int e = tid; e < 2 * k; e += nthr) sl.TT[e] = e < k ? sl.V0[e] : sl.V1[e - k];
+      for (int e = tid; e < nv * k; e += nthr) {
+        const int v = e / k, mm = e - v * k;
+        sl.TT[2 * k + e] = g0[mm * A.sm + v * A.sv];
+      }
+    } else {
+      const bool x_lds = (long)nv * k <= xcap;
+      for (int i = tid; i < n; i += nthr) {
+        double w, d, dd, rl;
+        ov.weights(i, w, d, dd, rl);
+        L.swl[i] = sqrt(w);
+      }
+      if (x_lds)
+        for (int e = tid; e < nv * k; e += nthr) {
+          const int v = e / k, mm = e - v * k;
+          xl[e] = g0[mm * A.sm + v * A.sv];
+        }
+      for (int e = tid; e < 2 * n; e += nthr) sl.TT[(size_t)(e < n ? 0 : 1) * k + (e < n ? e : e - n)] = e < n ? sl.V0[e] : sl.V1[e - n];
+      __syncthreads();
+      // TT[2 + v][i] = (Z x'_v)_i: one wave per observation row
+      for (int i = wv; i < n; i += nwv) {
+        long ms;
+        const double* yr = ov.row(i, ms);
+        double acc[kMaxNb];
+#pragma unroll
+        for (int v = 0; v < kMaxNb; ++v) acc[v] = 0.0;
+        for (int mm = lane; mm < k; mm += 64) {
+          const double y = yr[(long)mm * ms];
+#pragma unroll
+          for (int v = 0; v < kMaxNb; ++v)
+            if (v < nv) acc[v] = fma(y, x_lds ? xl[(size_t)v * k + mm] : g0[mm * A.sm + v * A.sv], acc[v]);
+        }
+        const double sw = L.swl[i];
+#pragma unroll
+        for (int v = 0; v < kMaxNb; ++v)
+          if (v < nv) {
+            const double s = wsum(acc[v]);
+            if (lane == 0) sl.TT[(size_t)(2 + v) * k + i] = s * sw;
+          }
+      }
+    }
+    __syncthreads();
+    const int ldg = m | 1;
+    int iters = 0;
+    const bool ok = krylov_point<BPW>(sl, L, m, ldg, k, nv, nb, shift, dual, &iters);
+    if (tid == 0) {
+      if (ok) {
+        S.info[2 * it] = -iters;                             // nsweep reports -(iterations) ...
+        S.info[2 * it + 1] = 1;                              // ... and the point is converged
+      } else {
+        S.meta[2 * it] = (meta0 & 0xff) | ((m <= S.wg_max_order ? 1 : 2) << 8);   // to the eigen stage (runs next)
+      }
+    }
+  }
+}
+
+int stage_krylov_max_n(int k) { return k < kKBlock ? (k + 15) & ~15 : kKBlock; }
+int stage_krylov_max_iter() { return kMmax; }
+
+long stage_krylov_hist_doubles(int k) { return (long)kMmax * 16 * stage_krylov_max_n(k); }
+
+hipError_t launch_stage_krylov(const StagedArgs& s, size_t lds_max, hipStream_t st) {
+  const int k = s.A.k;
+  const int nr16cap = stage_krylov_max_n(k);
+  const size_t fixed = (size_t)256 + 2 * (kDcap + 2) + 512 + 32;
+  const size_t over = (size_t)16 * nr16cap + 3 * (size_t)kMmax * 16;   // rbuf .. hr: what the staging copy of X' may overlay
+  const size_t budget = (lds_max > 160 * 1024 ? 160 * 1024 : lds_max) - 1024;
+  size_t xcap = (size_t)s.A.nv * k;
+  if ((fixed + (xcap > over ? xcap : over)) * sizeof(double) > budget) xcap = 0;   // X' straight from the state then
+  const size_t r0 = xcap > over ? xcap : over;
+  const size_t lds = (fixed + r0) * sizeof(double);
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)s.nbatch), dim3(kKBlock), lds, st, s, nr16cap, (int)r0, (int)xcap);
+    return hipGetLastError();
+  };
+  hipError_t e = go(&letkf_stage_krylov_kernel<1>);
+  if (e == hipSuccess && nr16cap > 128) e = go(&letkf_stage_krylov_kernel<2>);
+  if (e == hipSuccess && nr16cap > 256) e = go(&letkf_stage_krylov_kernel<4>);
+  return e;
+}
+
+}  // namespace letkf

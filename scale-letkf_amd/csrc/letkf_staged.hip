@@ -29,17 +29,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "letkf_device.h"
+#include "letkf_staged_dev.h"
 
 namespace letkf {
 
-namespace {
+using namespace staged_dev;
 
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
+namespace {
 
 constexpr int kGT = 4;         // Gram register tile
 constexpr int kGMaxT = 3;      // tiles per thread and pass
@@ -50,77 +46,20 @@ constexpr int kGBlock = 512;
 #ifndef STAGE_APPLY_MINWG
 #define STAGE_APPLY_MINWG 1
 #endif
-#ifndef STAGE_POLY_ROWS
-#define STAGE_POLY_ROWS 8      // rows of M whose loads are issued ahead of their FMAs (poly_apply)
-#endif
-#ifndef STAGE_POLY_RES
-#define STAGE_POLY_RES 0       // k-steps of M per wave that stay in registers across the degrees (poly_apply; A/B)
-#endif
 #ifndef STAGE_APPLY_LDSCAP
 #define STAGE_APPLY_LDSCAP (150 * 1024)
 #endif
 constexpr int kABlock = STAGE_APPLY_BLOCK;
-constexpr int kMaxNb = 16;     // right-hand sides: nv + 2 <= 16
-
-struct Slab {
-  double *G, *V0, *V1, *SC, *X, *TT, *PC, *QQ, *OUT, *W;
-};
-__device__ __forceinline__ Slab slab_of(double* base, int k, int nv, int kkout) {
-  const int ldg = k | 1, nb = nv + 2;
-  Slab s;
-  s.G = base;
-  s.V0 = s.G + (size_t)(k + 1) * ldg;   // one spare column: an odd order is padded with an inert zero column (letkf_eig.hip)
-  s.V1 = s.V0 + k;
-  s.SC = s.V1 + k;
-  s.X = s.SC + 16;
-  s.TT = s.X + (size_t)nv * k;
-  s.PC = s.TT + (size_t)nb * k;
-  s.QQ = s.PC + (size_t)nb * (k + 2);   // PC rows are k + 2 long (coefficients of up to k + 1 stored columns)
-  s.OUT = s.QQ + (size_t)nb * k;
-  s.W = kkout ? s.OUT + (size_t)nb * k : nullptr;
-  return s;
-}
-
-// where the point's observations come from: the obs table through the CSR lists (das_letkf body) or a dense
-// column-major hdxb(nobs, ne) block (letkf_core batch)
-struct ObsView {
-  const PointArgs* A;
-  long pt, o0;
-  int n;
-  __device__ __forceinline__ void weights(int i, double& w, double& d, double& dd, double& rl) const {
-    if (A->mode == 0) {
-      const long e = o0 + i;
-      const int iob = A->obs_idx[e];
-      rl = A->rloc_l[e];
-      w = 1.0 / A->rdiag_l[e];
-      d = A->dep[iob];
-      dd = A->det_run ? A->ensval[(long)iob * A->kld + A->k] : 0.0;
-    } else {
-      const long e = pt * (long)A->nobs + i;
-      rl = A->rloc[e];
-      w = A->rdiag_wloc ? 1.0 / A->rdiag[e] : rl / A->rdiag[e];   // common_letkf.f90:111-123
-      d = A->depv[e];
-      dd = A->depd ? A->depd[e] : 0.0;
-    }
-  }
-  // address of y_i[0] and the member stride
-  __device__ __forceinline__ const double* row(int i, long& ms) const {
-    if (A->mode == 0) {
-      ms = 1;
-      return A->ensval + (long)A->obs_idx[o0 + i] * A->kld;
-    }
-    ms = A->nobs;
-    return A->hdxb + (size_t)pt * (size_t)A->nobs * (size_t)A->k + i;
-  }
-};
 
 }  // namespace
 
-long staged_ws_per_point(int k, int nv, int kkout) {
+// hist: doubles of the eigen-free stage's residual history (stage_krylov_hist_doubles, 0 = none)
+long staged_ws_per_point(int k, int nv, int kkout, long hist) {
   const long ldg = k | 1, nb = nv + 2;
   long w = (long)(k + 1) * ldg + 2L * k + 16 + (long)nv * k + 4L * nb * k + 2L * nb;
   if (kkout) w += (long)k * ldg;
-  return (w + 1) & ~1L;
+  w = (w + 15) & ~15L;                                 // (H starts on a 128-byte boundary, slab_of)
+  return w + ((hist + 15) & ~15L);
 }
 
 // ------------------------------------------------------------------------------------------------ stage 1
@@ -362,52 +301,13 @@ __global__ void __launch_bounds__(kGBlock) letkf_stage_gram_kernel(const StagedA
       sl.SC[1] = red[1];
       sl.SC[2] = red[2];
     }
-    // ---- polynomial path (stage 3, "eigen-free"): M = S + c I with S = Z Z^T positive semi-definite, so M's spectrum
-    // lies in [c, c + |S|] for any norm bound |S| >= lambda_max(S); the smaller of the Frobenius norm and the largest
-    // absolute row sum is free here (M is in L2).  cond = (c + |S|) / c fixes the Chebyshev degree that reaches 1e-16 for
-    // functions analytic away from 0 (1/x, the T and Pa spectra): rate (sqrt(cond) - 1) / (sqrt(cond) + 1) per degree.
-    if (S.poly_max_n > 0 && m >= 2 && m <= S.poly_max_n && m <= nthr) {   // (dual: M = Z Z^T + c I, n x n; primal: A = Z^T Z + c I, k x k)
-      __syncthreads();                                // (G complete: every thread's stores; red[] read above)
-      double fs = 0.0, rs = 0.0;
-      if (tid < m) {
-        for (int c = 0; c < m; ++c) {
-          double v = sl.G[(size_t)c * ldg + tid];
-          if (c == tid) v -= shift;
-          fs = fma(v, v, fs);
-          rs += fabs(v);
-        }
-      }
-      fs = wsum(fs);
-#pragma unroll
-      for (int mk = 1; mk < 64; mk <<= 1) rs = fmax(rs, __shfl_xor(rs, mk, 64));
-      if ((tid & 63) == 0) {                          // per-wave partials (sqrt(w) in swl is no longer needed), summed in a fixed order
-        swl[tid >> 6] = fs;
-        swl[16 + (tid >> 6)] = rs;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        double f2 = 0.0, r1 = 0.0;
-        for (int w = 0; w < (nthr >> 6); ++w) {
-          f2 += swl[w];
-          r1 = fmax(r1, swl[16 + w]);
-        }
-        // (never an empty interval: all-zero weights or perturbations give S = 0)
-        const double bound = fmax(fmin(sqrt(f2), r1) * (1.0 + 1e-12), 1e-6 * shift);
-        const double sk = sqrt((shift + bound) / shift);
-        const double rate = (sk - 1.0) / (sk + 1.0);
-        int deg = 1 << 20;                             // (rate -> 1: hopeless, and log(rate) -> -0 must not reach the cast)
-        if (!(rate > 0.0)) deg = 4;
-        else if (rate < 0.999) deg = (int)ceil(log(1e-16) / log(rate)) + 1;
-        if (deg < 4) deg = 4;
-        if (f2 <= 1.7e308 && deg <= S.poly_max_deg) {   // (a NaN / Inf anywhere in M makes the sum of squares fail this test:
-                                                        //  the eigen stage then reports the point, status 1)
-          S.meta[2 * it] = (dual ? 2 : 1) | (3 << 8);
-          S.info[2 * it] = -deg;                      // no sweeps: nsweep reports -(degree) ...
-          S.info[2 * it + 1] = 1;                     // ... and nothing that could fail to converge
-          sl.SC[5] = bound;
-          sl.SC[6] = (double)deg;
-        }
-      }
+    // ---- eigen-free stage (letkf_krylov.hip): the loop body without k x k outputs needs only functions of M applied to
+    // nv + 2 vectors, which conjugate gradients + Lanczos deliver without an eigen-decomposition and without a bound on
+    // the spectrum.  Kept away from it: orders beyond what the stage holds, and matrices that are hopeless for any
+    // iteration (NaN / Inf, or a mean eigenvalue of S beyond 1e5 c: the eigen stage then reports the point).
+    if (S.poly_max_n > 0 && m >= 2 && m <= S.poly_max_n && tid == 0) {
+      const double tr = red[2];
+      if (tr == tr && tr <= 1e5 * shift * (double)m) S.meta[2 * it] = (dual ? 2 : 1) | (3 << 8);
     }
   }
 }
@@ -459,179 +359,6 @@ __device__ __forceinline__ void rows_comb(const double* __restrict__ Cm, const i
     for (int b = 0; b < kMaxNb; ++b)
       if (b < nbr) O[(size_t)b * ldo + i] = acc[b];
   }
-}
-
-// ---------------------------------------------------------------- the polynomial ("eigen-free") apply
-// Everything stage 3 takes from the eigen-decomposition M = U L U^T of the n x n matrix M = Z Z^T + c I is a FUNCTION of M
-// applied to a handful of vectors: q_b = U g(L) U^T t_b for the nb right-hand sides t_0,1 = sqrt(w) dep(_det), t_2+v = Z x'_v,
-// with g = 1/L for w-bar and g = the T spectrum -sqrt(k-1) / (sqrt(c) sqrt(L) (sqrt(c) + sqrt(L))) for the members, plus the
-// quadratic forms t^T M^-1 t of RTPS (var_a, letkf_tools.f90:1981-1990).  The shift c = (k-1)/rho keeps cond(M) small
-// (C3 / C5: 1.5 exact, ~2.3 with the free norm bound of stage 1), so a Chebyshev expansion of g on [c, c + |S|] reaches
-// 1e-16 in ~20-30 terms: 2 n^2 nb flops each -- a third of the flops of the Jacobi's ~9 sweeps, and regular, barrier-
-// per-degree work instead of a latency-bound iteration.  The functions are analytic on the interval (the nearest
-// singularity is L = 0), the coefficients come from interpolation at the Chebyshev nodes of the point's own interval.
-// The same holds in member space for a point with n >= k: functions of the k x k matrix A = Z^T Z + c I applied to r, r_det,
-// x'_v (g_T = sqrt(k-1) / sqrt(L); dual == false).  On return q_b[i] sits in qout[b * nq + i] (dual: the LDS copy that the
-// Z^T q pass reads; primal: OUT itself) and va[v] = t_v^T M^-1 t_v.
-// The product M T_d runs on the FP64 matrix cores (v_mfma_f64_16x16x4: A = a 16 x 4 tile of M straight from L2 -- lane l
-// loads M[i0 + (l & 15)][j0 + (l >> 4)], 128 contiguous bytes per 16 lanes --, B = 4 rows of T_d from LDS, lane l reads
-// T[j0 + (l >> 4)][l & 15] = 64 consecutive doubles, conflict-free; D: lane l holds rows (l >> 4) + 4 r, r < 4, of column
-// l & 15).  A wave owns the 16-row blocks w, w + 8, ... (BPW of them); the recurrence state T_d, T_d-1 and the two running
-// sums live in registers in D's layout, the new T_d goes to the other LDS buffer ([row][16], the right-hand sides padded to
-// 16 columns of which the last ones stay zero), ONE barrier per degree.  (First versions: a thread per row with broadcast
-// reads of T_d from LDS -- 62.9 ms on C3-slab with all right-hand sides per thread, 23.8 ms with the right-hand sides
-// dealt to parts of the workgroup and 8 rows of loads in flight; a fixed-degree timing twin showed 0.56 ms per degree
-// there, bound by the LDS broadcasts: 4 ds_read_b128 per row of M and wave.)
-template <int BPW>
-__device__ __forceinline__ void poly_apply(const Slab& sl, const int n, const int ldg, const int k, const int nv, const int nbr,
-                                           const double shift, const double sqc, const double sqkm1, double* fw, double* ft,
-                                           double* cw, double* ct, double* pcq, double* qout, const int nq, double* va,
-                                           const bool dual) {
-  typedef double d4 __attribute__((ext_vector_type(4)));
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
-  const double bound = sl.SC[5];
-#ifdef STAGE_POLY_TIMING_DEG   // A/B twins only (make VARIANT=...): a fixed number of terms -- timing of the recurrence, results invalid
-  const int deg = STAGE_POLY_TIMING_DEG, N = deg + 1;
-#else
-  const int deg = (int)sl.SC[6], N = deg + 1;
-#endif
-  const double lo = shift, hi = shift + bound;
-  const double half = 0.5 * (hi - lo), mid = 0.5 * (hi + lo);
-  // g at the Chebyshev nodes, then the coefficients c_i = (2 - [i = 0]) / N sum_j g(x_j) cos(pi i (j + 1/2) / N)
-  for (int j = tid; j < N; j += nthr) {
-    const double L = fma(half, cospi(((double)j + 0.5) / (double)N), mid);
-    const double sL = sqrt(L);
-    fw[j] = 1.0 / L;
-    ft[j] = dual ? -sqkm1 / (sqc * sL * (sqc + sL)) : sqkm1 / sL;   // T = sqrt(rho) I + Z^T U g U^T Z  |  T = sqrt(k-1) A^-1/2
-  }
-  __syncthreads();
-  for (int i = tid; i < N; i += nthr) {
-    double sw_ = 0.0, st_ = 0.0;
-    for (int j = 0; j < N; ++j) {
-      const double cc = cospi((double)i * ((double)j + 0.5) / (double)N);
-      sw_ = fma(fw[j], cc, sw_);
-      st_ = fma(ft[j], cc, st_);
-    }
-    const double f = (i == 0 ? 1.0 : 2.0) / (double)N;
-    cw[i] = sw_ * f;
-    ct[i] = st_ * f;
-  }
-  const int nr16 = (n + 15) & ~15;
-  const int col = lane & 15, rq = lane >> 4;
-  double* cur = pcq;
-  double* oth = pcq + (size_t)nr16 * 16;
-  double t0[BPW][4], t1[BPW][4], yw[BPW][4], yt[BPW][4];
-#pragma unroll
-  for (int bi = 0; bi < BPW; ++bi) {
-    const int i0 = (wv + bi * nwv) * 16;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = i0 + rq + 4 * r;
-      t0[bi][r] = (row < n && col < nbr) ? sl.TT[(size_t)col * k + row] : 0.0;
-      t1[bi][r] = yw[bi][r] = yt[bi][r] = 0.0;
-      if (i0 < nr16) cur[(size_t)row * 16 + col] = t0[bi][r];
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < nwv * 16; e += nthr) fw[e] = 0.0;   // (the node values are used up: per-wave partials of the quadratic forms)
-  const double inv = 1.0 / half;                        // M~ = (M - mid I) / half maps the interval to [-1, 1]
-  constexpr int KS = 16 / BPW;                          // k-steps (of 4 rows of M^T = columns j) whose loads go out together
-  // The first RS k-steps of a wave's A operands stay in registers across the degrees (the stream of M from L2 / MALL is
-  // what bounds the recurrence: 320 KB per degree and CU at n = 200)
-  constexpr int RS = BPW <= 2 ? STAGE_POLY_RES / BPW : 0;
-  double ares[BPW][RS > 0 ? RS : 1];
-#pragma unroll
-  for (int s = 0; s < RS; ++s) {
-    const int j = 4 * s + rq;
-#pragma unroll
-    for (int bi = 0; bi < BPW; ++bi) {
-      const int row = (wv + bi * nwv) * 16 + col;
-      ares[bi][s] = (j < n && row < n) ? sl.G[(size_t)j * ldg + row] : 0.0;
-    }
-  }
-  const int jres = 4 * RS < nr16 ? 4 * RS : nr16;       // columns [0, jres) come from the registers
-  for (int d = 1; d <= deg; ++d) {
-    d4 acc[BPW];
-#pragma unroll
-    for (int bi = 0; bi < BPW; ++bi) acc[bi] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < RS; ++s) {
-      if (4 * s < nr16) {                               // (wave-uniform)
-        const double bq = cur[(size_t)(4 * s) * 16 + lane];
-#pragma unroll
-        for (int bi = 0; bi < BPW; ++bi) acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ares[bi][s], bq, acc[bi], 0, 0, 0);
-      }
-    }
-    for (int j0 = jres; j0 < nr16; j0 += 4 * KS) {
-      double av[BPW][KS], bq[KS];
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int j = j0 + 4 * s + rq;
-#pragma unroll
-        for (int bi = 0; bi < BPW; ++bi) {
-          const int row = (wv + bi * nwv) * 16 + col;    // (A's row sits on lane & 15)
-          av[bi][s] = (j < n && row < n) ? sl.G[(size_t)j * ldg + row] : 0.0;
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < KS; ++s) bq[s] = j0 + 4 * s < nr16 ? cur[(size_t)(j0 + 4 * s) * 16 + lane] : 0.0;
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int bi = 0; bi < BPW; ++bi) acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[bi][s], bq[s], acc[bi], 0, 0, 0);
-    }
-    const double cwd = cw[d], ctd = ct[d], cw0 = cw[0], ct0 = ct[0];
-#pragma unroll
-    for (int bi = 0; bi < BPW; ++bi) {
-      const int i0 = (wv + bi * nwv) * 16;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double tn;
-        if (d == 1) {
-          tn = (acc[bi][r] - mid * t0[bi][r]) * inv;   // T_1 = M~ t
-          yw[bi][r] = cw0 * t0[bi][r];
-          yt[bi][r] = ct0 * t0[bi][r];
-        } else {
-          tn = fma(2.0 * inv, acc[bi][r] - mid * t1[bi][r], -t0[bi][r]);   // T_d = 2 M~ T_d-1 - T_d-2
-          t0[bi][r] = t1[bi][r];
-        }
-        t1[bi][r] = tn;
-        yw[bi][r] = fma(cwd, tn, yw[bi][r]);
-        yt[bi][r] = fma(ctd, tn, yt[bi][r]);
-        if (i0 < nr16) oth[(size_t)(i0 + rq + 4 * r) * 16 + col] = tn;
-      }
-    }
-    __syncthreads();
-    double* sw2 = cur;
-    cur = oth;
-    oth = sw2;
-  }
-  // (every read of the two T buffers lies behind the loop's last barrier: pcq is free)
-  // q_b, and the quadratic forms t_v^T M^-1 t_v: a lane's rows, then the four lanes of a column, per-wave partials
-  // summed in a fixed order
-  double p = 0.0;
-#pragma unroll
-  for (int bi = 0; bi < BPW; ++bi) {
-    const int i0 = (wv + bi * nwv) * 16;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = i0 + rq + 4 * r;
-      if (row < n && col < nbr) {
-        p = fma(sl.TT[(size_t)col * k + row], yw[bi][r], p);
-        qout[(size_t)col * nq + row] = col < 2 ? yw[bi][r] : yt[bi][r];
-      }
-    }
-  }
-  p += __shfl_xor(p, 16, 64);
-  p += __shfl_xor(p, 32, 64);
-  if (lane < 16) fw[wv * 16 + lane] = p;
-  __syncthreads();
-  for (int v = tid; v < nv; v += nthr) {
-    double s_ = 0.0;
-    for (int w = 0; w < nwv; ++w) s_ += fw[w * 16 + 2 + v];
-    va[v] = s_;
-  }
-  __syncthreads();
 }
 
 }  // namespace
@@ -691,7 +418,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
       continue;
     }
     const bool dual = mode == 2;
-    const bool poly = solver == 3;                     // eigen-free: sl.G still holds M itself
+    const bool poly = solver == 3;                     // eigen-free (letkf_krylov.hip has left q and the quadratic forms): sl.G still holds M itself
     const int ldg = m | 1;
     // the workgroup Jacobi pads an odd order with a zero column that ends up anywhere among the stored columns
     const int mc = solver == 1 ? (m + 1) & ~1 : m;
@@ -702,8 +429,9 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     const bool qq_lds = pc_lds && (long)nb * (mq + nq) <= pcq_doubles;
     double* PCp = pc_lds ? pcq : sl.PC;
     const int kq = pc_lds ? mq : k + 2;                 // row length of PC
-    double* QQp = poly ? pcq : qq_lds ? pcq + (size_t)nb * mq : sl.QQ;
-    const int qld = (poly || qq_lds) ? nq : k;
+    const bool pq_lds = poly && (long)nb * nq <= pcq_doubles;   // eigen-free: q [nb][nq] alone
+    double* QQp = poly ? (pq_lds ? pcq : sl.QQ) : qq_lds ? pcq + (size_t)nb * mq : sl.QQ;
+    const int qld = poly ? (pq_lds ? nq : k) : qq_lds ? nq : k;
     const double shift = sl.SC[3], infl_old = sl.SC[4];
     ObsView ov;
     ov.A = &A;
@@ -783,7 +511,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     // ---------------- stage the perturbations X[v][mm]; right-hand sides in the solver's space TT[b][.]
     // (dual: a second copy of X in LDS -- the pcq region is free until the coefficients / the T buffers move in -- for the
     //  Z x'_v pass below, which reads all of X once per observation row)
-    const bool x_lds = das && dual && (long)nv * k <= pcq_doubles;
+    const bool x_lds = das && dual && !poly && (long)nv * k <= pcq_doubles;
     if (das) {
       for (int e = tid; e < nv * k; e += nthr) {
         const int v = e / k, mm = e - v * k;
@@ -798,7 +526,9 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     }
     __syncthreads();
     const int nbr = das ? nb : 2;                      // letkf_core batch: only w-bar (and w-bar_det)
-    if (!dual) {
+    if (poly) {
+      // (the eigen-free stage built its own right-hand sides)
+    } else if (!dual) {
       // TT[0] = r, TT[1] = r_det (already in V0 / V1), TT[2 + v] = x'_v
       for (int e = tid; e < 2 * k; e += nthr) sl.TT[e] = e < k ? sl.V0[e] : sl.V1[e - k];
       if (das)
@@ -843,10 +573,14 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
       }
     __syncthreads();
     if (poly) {
-      const int nblk = (m + 15) >> 4, per = (nblk + nwv - 1) / nwv;   // 16-row blocks per wave
-      if (per <= 1) poly_apply<1>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
-      else if (per <= 2) poly_apply<2>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
-      else poly_apply<4>(sl, m, ldg, k, nv, nbr, shift, sqc, sqkm1, lam, tau, om, pis, pcq, dual ? pcq : sl.OUT, dual ? nq : k, xsm + 7 * nv, dual);
+      // q_b (dual: obs space, read as broadcasts by the Z^T q pass below -> LDS when it fits) and va_v = t_v^T M^-1 t_v
+      if (dual && pq_lds)
+        for (int e = tid; e < nb * n; e += nthr) {
+          const int b = e / n, i = e - b * n;
+          pcq[(size_t)b * nq + i] = sl.QQ[(size_t)b * k + i];
+        }
+      for (int v = tid; v < nv; v += nthr) xsm[7 * nv + v] = sl.PC[v];
+      __syncthreads();
     }
 
     // ---------------- relaxation scalars per variable (letkf_tools.f90:457-469, :1953-2002)
@@ -885,9 +619,9 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
 
     // ---------------- back to member space: OUT[b][mm]
     if (!dual) {
-      if (!poly) rows_comb(sl.G, ldg, k, mc, PCp, kq, nbr, sl.OUT, k);   // (poly_apply has written OUT)
+      if (!poly) rows_comb(sl.G, ldg, k, mc, PCp, kq, nbr, sl.OUT, k);   // (eigen-free: OUT is written)
     } else {
-      if (!poly) rows_comb(sl.G, ldg, n, mc, PCp, kq, nbr, QQp, qld);      // q_b = U c_b  (obs space; poly_apply left q there)
+      if (!poly) rows_comb(sl.G, ldg, n, mc, PCp, kq, nbr, QQp, qld);      // q_b = U c_b  (obs space; eigen-free: q is there)
       __syncthreads();
       // OUT[b][mm] = sum_i Z[i][mm] q_b[i]: one thread per member, the obs rows streamed (coalesced along mm)
       for (int mm = tid; mm < k; mm += nthr) {
@@ -1077,24 +811,13 @@ hipError_t launch_stage_gram(const StagedArgs& s, size_t lds_max, hipStream_t st
 }
 
 // LDS doubles of stage 3 beyond its fixed part: room for P / C (primal: up to k + 2 columns) and, while it fits, for q as
-// well (dual: two matrices of ~n columns); the polynomial path keeps its two [n][nb] buffers there
+// well (dual: two matrices of ~n columns); an eigen-free point keeps only q there
 int stage_apply_pcq_doubles(int k, int nv) {
   const int nb = nv + 2;
   const size_t fixed = (size_t)5 * (k + 2) + 8 * (size_t)nv + 32;
   size_t pcq = (size_t)2 * nb * (k + 4);
-  const size_t pcq_poly = (size_t)2 * 16 * (size_t)(((k < kABlock ? k : kABlock) + 15) & ~15);   // poly_apply: two [rows to 16][16] buffers, any order <= min(k, 512)
-  if (pcq < pcq_poly) pcq = pcq_poly;
   while ((fixed + pcq) * sizeof(double) > STAGE_APPLY_LDSCAP && pcq > 0) pcq = pcq > (size_t)nb * 64 ? pcq - (size_t)nb * 64 : 0;
   return (int)pcq;
-}
-
-// largest order the polynomial path takes: two [n to 16][16] buffers, then q [nb][n + 2], in that room
-int stage_poly_max_n(int k, int nv) {
-  const int nb = nv + 2;
-  long n = (stage_apply_pcq_doubles(k, nv) / 32) & ~15L;   // two [n to 16][16] buffers
-  if (n > kABlock) n = kABlock;                            // (4 blocks of 16 rows per wave)
-  while (n > 0 && (long)nb * ((n + 2) & ~1L) > stage_apply_pcq_doubles(k, nv)) n -= 16;
-  return (int)(n > 0 ? n : 0);
 }
 
 hipError_t launch_stage_apply(const StagedArgs& s, hipStream_t st) {
