@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LETKF_AMD_ABI_VERSION 4
+#define LETKF_AMD_ABI_VERSION 5
 
 /* host-side errors (function return values) */
 #define LETKF_OK 0
@@ -60,11 +60,17 @@ int letkf_ctx_destroy(letkf_ctx *ctx);
  * default (null) stream.  A fresh context runs on its own non-blocking stream until this is called. */
 int letkf_ctx_set_stream(letkf_ctx *ctx, void *hip_stream);
 int letkf_ctx_synchronize(letkf_ctx *ctx);
-/* Options of a context.  LETKF_OPT_STAGED_POLY (default 1): on the staged path (k > 100) a grid point with fewer local
- * observations than members whose loop body returns no k x k matrix is analysed without an eigen-decomposition -- the
- * transform and w-bar are Chebyshev expansions in the n x n matrix Z Z^T + (k-1)/rho I applied to the right-hand sides
- * (same result to rounding); 0: every such point goes through the Jacobi eigen stage (what replaces
- * common/common_mtx.f90:41 mtx_eigen), as points with n >= k or with trans / Pa outputs always do. */
+/* Options of a context.  LETKF_OPT_STAGED_POLY (default 1): a loop-body call (letkf_das_points_dev with lists) with
+ * k >= 63, or with nv != 11 at any k, that returns no k x k matrix analyses its grid points WITHOUT an eigen-decomposition:
+ * w-bar, the transform applied to the perturbations and the RTPS quadratic forms come from conjugate gradients and the
+ * Lanczos tridiagonal of the point's matrix -- Z Z^T + (k-1)/rho I in observation space for a point with fewer local
+ * observations than members, Z^T Z + (k-1)/rho I in member space otherwise, any order up to 512 -- applied to the nv + 2
+ * right-hand sides on the matrix cores (same result to rounding).  No spectral bound and no degree cap
+ * are involved: a point that does not converge within 128 iterations (cond(A) beyond ~1e3 with a flat spectrum, or a
+ * matrix that is not positive definite to rounding) goes through the Jacobi eigen stage inside the same call.  nsweep
+ * reports -(iterations) for a point analysed this way, the Jacobi's sweep count (> 0) otherwise.
+ * 0: every point goes through the Jacobi (what replaces common/common_mtx.f90:41 mtx_eigen) -- 63 <= k <= 100 on the
+ * two-wave register kernel, larger k on the staged path's eigen stage -- as calls with trans / Pa outputs always do. */
 #define LETKF_OPT_STAGED_POLY 1
 int letkf_ctx_set_option(letkf_ctx *ctx, int option, int value);
 
@@ -150,7 +156,8 @@ typedef struct {
                                 S = nij1 makes the runs go up a column -- vertical neighbours, whose local observations
                                 are the same rows with slowly changing weights: a better starting point than the
                                 horizontal neighbour (C2: off-diagonal norm of Q'AQ 0.013 against 0.023).  Same results
-                                to rounding either way.  (This field was reserved0 = 0 up to ABI 4.) */
+                                to rounding either way.  (reserved0 = 0 in ABI <= 3; ABI 4 libraries already read it as described here, the
+                                version number followed in 5.) */
   double relax_alpha;        /* RELAX_ALPHA (RTPP), 0 = off */
   double relax_alpha_spread; /* RELAX_ALPHA_SPREAD (RTPS), 0 = off; RTPP wins when both set (:457) */
   double q_update_top;       /* Q_UPDATE_TOP, <= 0 = off */
@@ -467,9 +474,6 @@ int letkf_relax_beta_dev(letkf_ctx *ctx, const letkf_beta_params *p, int64_t nij
  * read in (INFL_MUL_IN_BASENAME); then work3d = max(work3d, INFL_MUL_MIN) when infl_mul_min > 0.  n = nij1*nlev*nv3d. */
 int letkf_infl_init_dev(letkf_ctx *ctx, int64_t n, double *work3d, double infl_mul, double infl_mul_min);
 
-/* Kernel timing helper for bench.py: average duration (ms) of the last
- * letkf_das_points_dev / letkf_core_batch_dev launches measured with HIP events on the
- * context's stream since the previous reset; *nlaunch receives the count. */
 /*---------------------------------------------------------------------------
  * (8) The path's one exchange: MPI_ALLGATHERV of the sorted observation buffers (and, with the same call, of the
  *     mesh-cell counts) over the subdomain ranks, scale/letkf/letkf_obs.f90:1036-1046 / :826-831, on an RCCL
@@ -486,6 +490,9 @@ int letkf_obs_allgatherv_dev(letkf_ctx *ctx, void *nccl_comm, int32_t nranks, in
 /* Name(s) of the kernel(s) the context's last letkf_das_points*_dev / letkf_core_batch_dev call went through, as a
  * NUL-terminated string (truncated to len): what bench.py reports as roofline.kernel. */
 int letkf_ctx_last_path(letkf_ctx *ctx, char *buf, int32_t len);
+/* Kernel timing helper for bench.py: average duration (ms) of the last
+ * letkf_das_points_dev / letkf_core_batch_dev launches measured with HIP events on the
+ * context's stream since the previous reset; *nlaunch receives the count. */
 int letkf_ctx_timing_enable(letkf_ctx *ctx, int enable);
 int letkf_ctx_timing_read(letkf_ctx *ctx, double *avg_ms, int64_t *nlaunch, int reset);
 

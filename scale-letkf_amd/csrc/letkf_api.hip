@@ -172,14 +172,10 @@ struct EventPair {   // timing events that do not outlive a failed launch
 
 int launch_staged(letkf_ctx* c, letkf::PointArgs& a);
 
-int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, long warm_stride = 1) {
-  a.ldg = p.ldg;
-  a.ldy = p.ldy;
-  a.tn = p.tn;
-  a.ws = c->ws;
-  a.ws_per_block = p.ws_per_block;
+int launch(letkf_ctx* c, letkf::PointArgs& a, int warm_run = 0, long warm_stride = 1) {
+  if (a.k < 2) return fail(LETKF_E_INVALID, "ensemble size must be >= 2");
+  if (a.nv < 0 || a.npts < 0) return fail(LETKF_E_INVALID, "negative size");
   a.max_sweep = 60;
-  a.big_block = (p.lp.big && !LETKF_KNOB("LETKF_AMD_BIG_STREAM")) ? 1 : 0;   // PROF knob: the older streaming Jacobi
   if (const char* e = LETKF_KNOB("LETKF_AMD_MAX_SWEEP")) {   // PROF knob: time the non-eigensolve phases
     int v = std::atoi(e);
     if (v >= 0 && v < 60) a.max_sweep = v;   // 0: skip the eigensolve entirely (timing only, results invalid)
@@ -201,6 +197,18 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, const Plan& p, int warm_run = 0, l
   // beyond the register kernels: the staged three-kernel path (the monolithic workgroup kernel below stays reachable
   // through the PROF twin's LETKF_AMD_FORCE_BLOCK / LETKF_AMD_MONOLITHIC knobs for A/B measurements)
   if (!wave && !force_block && a.mode != 2 && a.nv + 2 <= 16 && !LETKF_KNOB("LETKF_AMD_MONOLITHIC")) return launch_staged(c, a);
+  // the route is decided: only now the plan (and, for large k, the workspace) of the monolithic workgroup kernel -- the
+  // staged path above has its own slabs and serves ensemble sizes whose vectors this kernel's LDS carve would refuse
+  Plan p;
+  if (int rc = make_plan(c, a.k, a.nv, a.npts, &p)) return rc;
+  if (!wave)
+    if (int rc = ensure_ws(c, p)) return rc;
+  a.ldg = p.ldg;
+  a.ldy = p.ldy;
+  a.tn = p.tn;
+  a.ws = c->ws;
+  a.ws_per_block = p.ws_per_block;
+  a.big_block = (p.lp.big && !LETKF_KNOB("LETKF_AMD_BIG_STREAM")) ? 1 : 0;   // PROF knob: the older streaming Jacobi
   if (wave) {
     int run_req = warm_run;
     if (const char* e = LETKF_KNOB("LETKF_AMD_RUN_LEN")) run_req = std::atoi(e);   // PROF knob: 1 = all cold
@@ -411,7 +419,7 @@ int letkf_ctx_destroy(letkf_ctx* c) {
 }
 
 int letkf_ctx_set_option(letkf_ctx* c, int option, int value) {
-  if (!c) return fail(LETKF_E_INVALID, "null context");
+  if (int rc = check_ctx(c)) return rc;
   switch (option) {
     case LETKF_OPT_STAGED_POLY: c->staged_poly = value != 0; return LETKF_OK;
     default: return fail(LETKF_E_INVALID, "unknown option");
@@ -476,9 +484,6 @@ int letkf_core_batch_dev(letkf_ctx* c, const letkf_core_batch_args* g) {
   if (g->ne < 2 || g->nobs < 1 || g->nbatch < 0) return fail(LETKF_E_INVALID, "bad ne/nobs/nbatch");
   if (!g->nobsl || !g->hdxb || !g->rdiag || !g->rloc || !g->dep || !g->parm_infl || !g->trans)
     return fail(LETKF_E_INVALID, "a required device pointer is NULL");
-  Plan p;
-  if (int rc = make_plan(c, g->ne, 0, g->nbatch, &p)) return rc;
-  if (int rc = ensure_ws(c, p)) return rc;
   letkf::PointArgs a;
   std::memset(&a, 0, sizeof(a));
   a.k = g->ne;
@@ -504,7 +509,7 @@ int letkf_core_batch_dev(letkf_ctx* c, const letkf_core_batch_args* g) {
   a.add_wbar_to_trans = g->transm ? 0 : 1;                    // common_letkf.f90:218-226
   a.status = g->status;
   a.nsweep = g->nsweep;
-  return launch(c, a, p);
+  return launch(c, a);
 }
 
 namespace {
@@ -536,9 +541,6 @@ int das_points_impl(letkf_ctx* c, const letkf_das_args* g, const letkf_search_ta
   if (g->iv_p < 0 || g->iv_p >= g->nv) {
     if (g->q_update_top > 0.0) return fail(LETKF_E_INVALID, "iv_p out of range");
   }
-  Plan p;
-  if (int rc = make_plan(c, g->k, g->nv, g->npts, &p)) return rc;
-  if (int rc = ensure_ws(c, p)) return rc;
   letkf::PointArgs a;
   std::memset(&a, 0, sizeof(a));
   a.k = g->k;
@@ -597,7 +599,7 @@ int das_points_impl(letkf_ctx* c, const letkf_das_args* g, const letkf_search_ta
     a.prz = rz;
     a.nobs_out = nobs_out;
   }
-  return launch(c, a, p, g->warm_run < 0 ? 0 : g->warm_run, g->warm_stride);
+  return launch(c, a, g->warm_run < 0 ? 0 : g->warm_run, g->warm_stride);
 }
 
 }  // namespace

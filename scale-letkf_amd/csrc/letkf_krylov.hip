@@ -36,6 +36,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "letkf_jacobi_dev.h"
 #include "letkf_staged_dev.h"
 
@@ -48,7 +50,7 @@ namespace {
 
 constexpr int kKBlock = 512;
 constexpr int kMmax = 128;        // CG iterations (rows of the Lanczos tridiagonal: two per lane)
-constexpr int kDcap = 1022;       // highest Chebyshev degree of the tridiagonal function (cond ~ 3000)
+constexpr int kDcap = 4094;       // highest Chebyshev degree of the tridiagonal function (cond ~ 47000); its coefficients overlay ha | hb
 constexpr double kTol2 = 1e-30;   // |r_j|^2 <= 1e-30 |t|^2
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -59,7 +61,7 @@ struct KryLds {
   double* hb;      // [kMmax][16]     beta_j
   double* hr;      // [kMmax][16]     rho_j = |r_j|^2; later the combination coefficients
   double* red;     // [2][8][16]      per-wave partial sums
-  double* cT;      // [kDcap + 2]     Chebyshev coefficients of g_T on the tridiagonals' interval
+  double* cT;      // [kDcap + 2]     Chebyshev coefficients of g_T on the tridiagonals' interval: OVERLAYS ha | hb (read into registers by then)
   double* fT;      // [kDcap + 2]     g_T at the nodes
   double* swl;     // [512]           sqrt(w_i) (dual)
   double* misc;    // [32]
@@ -73,6 +75,9 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
   const int nr16 = (n + 15) & ~15, nblk = nr16 >> 4;
   const int col = lane & 15, rq = lane >> 4;
   double rr[BPW][4], pp[BPW][4], qq[BPW][4], xx[BPW][4];
+  // The residual block in LDS is stored with its rows PERMUTED inside every group of 8: row j = 8 t + 2 q + o sits at
+  // position 8 t + 4 o + q, so that the four rows of a matrix-core step (see the product) are consecutive
+  auto rpos = [](int row) { return (row & ~7) + 4 * (row & 1) + ((row & 7) >> 1); };
   // ---- r_0 = t, rho_0
   {
     double ps = 0.0;
@@ -85,7 +90,7 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
         rr[bi][r] = (row < n && col < nbr) ? sl.TT[(size_t)col * k + row] : 0.0;
         pp[bi][r] = qq[bi][r] = xx[bi][r] = 0.0;
         ps = fma(rr[bi][r], rr[bi][r], ps);
-        if (i0 < nr16) L.rbuf[(size_t)row * 16 + col] = rr[bi][r];
+        if (i0 < nr16) L.rbuf[(size_t)rpos(row) * 16 + col] = rr[bi][r];
       }
     }
     ps += __shfl_xor(ps, 16, 64);
@@ -93,16 +98,30 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
     if (lane < 16) L.red[wv * 16 + lane] = ps;
   }
   __syncthreads();
-  // A operand addresses: row i0 + col of M's column j (M is symmetric: column j of the slab = row j), clamped into the
-  // matrix -- padding rows / columns meet zero rows of the residual block or are dropped at the use
-  const double* arow[BPW];
+  // ---- the product's A operands.  M is symmetric: row i0 + c of M is column i0 + c of the slab, so lane (c, q) fetches
+  // M[i0 + c][8 t + 2 q .. + 1] as ONE 16-byte load per block and 8 columns -- the A operands of two matrix-core steps
+  // whose four contraction rows are 8 t + 2 q' + o, q' < 4 (o = 0: first step, 1: second): 64 contiguous bytes per 4 lanes
+  // of a row.  A ring of PF such loads per block is in flight; it wraps around into the NEXT iteration (M is the same
+  // every time), so the latency of L2 / Infinity Cache is paid once per point, not once per iteration.  Rows beyond n are
+  // clamped to row n - 1 (dropped at the use), columns beyond n read the neighbouring slab words (finite: zeroed by the
+  // caller) against zero rows of the residual block.
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+  constexpr int PF = BPW == 1 ? 16 : BPW == 2 ? 8 : 2;
+  const int nact_ = (nblk - wv + nwv - 1) / nwv;           // this wave's active blocks (wave-uniform), <= BPW
+  const int nact = __builtin_amdgcn_readfirstlane(nact_ < 0 ? 0 : nact_ > BPW ? BPW : nact_);
+  const int T = nr16 >> 3, Tp = (T + PF - 1) / PF * PF;
+  const double* abase[BPW];
 #pragma unroll
   for (int bi = 0; bi < BPW; ++bi) {
     const int row = (wv + bi * nwv) * 16 + col;
-    arow[bi] = sl.G + (row < n ? row : n - 1);
+    abase[bi] = sl.G + (size_t)(row < n ? row : n - 1) * ldg + 2 * rq;
   }
-  constexpr int KS = 8 / BPW > 1 ? 8 / BPW : 2;            // k-steps (4 columns of M each) per group of loads
-  const int ngrp = (nr16 / 4 + KS - 1) / KS;
+  d2u ring[PF][BPW];
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+#pragma unroll
+    for (int bi = 0; bi < BPW; ++bi)
+      ring[u][bi] = *reinterpret_cast<const d2u*>(abase[bi] + 8 * (u < T ? u : 0));   // (unconditional: hipcc counts the loads in flight only in straight-line code)
   double rho_old = 1.0, alpha_old = 1.0, tn2 = 0.0;
   bool frozen = false, failed = false;
   int mj = 0, j = 0;
@@ -124,48 +143,57 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
     d4 acc[BPW];
 #pragma unroll
     for (int bi = 0; bi < BPW; ++bi) acc[bi] = (d4){0.0, 0.0, 0.0, 0.0};
-    double av[2][BPW][KS];
-    auto fetch = [&](int g, double (&dst)[BPW][KS]) {
+    auto product = [&](auto na_) {
+      constexpr int NA = decltype(na_)::value;
+      for (int t0 = 0; t0 < Tp; t0 += PF) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int jj = (g * KS + s) * 4 + rq;
-        const size_t off = (size_t)(jj < n ? jj : n - 1) * ldg;
+        for (int u = 0; u < PF; ++u) {
+          const int t = t0 + u;
+          if (t < T) {                                      // (wave-uniform)
+            const double b0 = L.rbuf[(size_t)(8 * t) * 16 + lane], b1 = L.rbuf[(size_t)(8 * t + 4) * 16 + lane];
 #pragma unroll
-        for (int bi = 0; bi < BPW; ++bi) dst[bi][s] = arow[bi][off];
-      }
-    };
-    auto mma = [&](int g, const double (&src)[BPW][KS]) {
-      double bq[KS];
+            for (int bi = 0; bi < NA; ++bi) {
+              acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][bi].x, b0, acc[bi], 0, 0, 0);
+              acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][bi].y, b1, acc[bi], 0, 0, 0);
+            }
+          }
+          // refill the slot -- ALWAYS: with a branch around a load hipcc can no longer count the loads in flight and waits
+          // for all of them (vmcnt(0)) in front of every matrix-core step; a padding step fetches step 0 again
+          int tn = t + PF;
+          if (tn >= Tp) tn -= Tp;                           // the next iteration's first steps
+          if (tn >= T) tn = 0;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int j0 = (g * KS + s) * 4;
-        bq[s] = j0 < nr16 ? L.rbuf[(size_t)j0 * 16 + lane] : 0.0;
-      }
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        if ((g * KS + s) * 4 < nr16) {                      // (wave-uniform)
-#pragma unroll
-          for (int bi = 0; bi < BPW; ++bi)
-            if ((wv + bi * nwv) * 16 < nr16) acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(src[bi][s], bq[s], acc[bi], 0, 0, 0);
+          for (int bi = 0; bi < NA; ++bi) ring[u][bi] = *reinterpret_cast<const d2u*>(abase[bi] + 8 * tn);
         }
       }
     };
-    fetch(0, av[0]);
-    for (int g = 0; g < ngrp; g += 2) {
-      if (g + 1 < ngrp) fetch(g + 1, av[1]);
-      mma(g, av[0]);
-      if (g + 2 < ngrp) fetch(g + 2, av[0]);
-      if (g + 1 < ngrp) mma(g + 1, av[1]);
+    if constexpr (BPW == 1) {
+      product(std::integral_constant<int, 1>());
+    } else if constexpr (BPW == 2) {
+      if (nact == 2) product(std::integral_constant<int, 2>());
+      else product(std::integral_constant<int, 1>());
+    } else {
+      if (nact == 4) product(std::integral_constant<int, 4>());
+      else if (nact == 3) product(std::integral_constant<int, 3>());
+      else if (nact == 2) product(std::integral_constant<int, 2>());
+      else product(std::integral_constant<int, 1>());
     }
-    // ---- mu = r . w per column
+    // ---- r_j to the history (lane-private; issued here, behind the product's loads, so that the next product's first
+    // wait does not sit on these stores), mu = r . w per column
     double wreg[BPW][4];
     double pm = 0.0;
 #pragma unroll
     for (int bi = 0; bi < BPW; ++bi) {
-      const int i0 = (wv + bi * nwv) * 16;
+      const int blk = wv + bi * nwv;
+      const int i0 = blk * 16;
+      if (blk < nblk) {
+        double* hj = sl.H + (((size_t)j * nblk + blk) * 4) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hj[r * 64] = rr[bi][r];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        wreg[bi][r] = (i0 + rq + 4 * r < n) ? acc[bi][r] : 0.0;
+        wreg[bi][r] = (blk < nblk && i0 + rq + 4 * r < n) ? acc[bi][r] : 0.0;
         pm = fma(rr[bi][r], wreg[bi][r], pm);
       }
     }
@@ -190,22 +218,20 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
       L.hb[j * 16 + lane] = beta;
       L.hr[j * 16 + lane] = rho;
     }
-    // ---- r_j to the history (lane-private), then the updates
+    // ---- the updates
     double ps = 0.0;
 #pragma unroll
     for (int bi = 0; bi < BPW; ++bi) {
       const int blk = wv + bi * nwv;
       if (blk < nblk) {
-        double* hj = sl.H + (((size_t)j * nblk + blk) * 4) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          hj[r * 64] = rr[bi][r];
           pp[bi][r] = fma(beta, pp[bi][r], rr[bi][r]);
           qq[bi][r] = fma(beta, qq[bi][r], wreg[bi][r]);
           xx[bi][r] = fma(alpha, pp[bi][r], xx[bi][r]);
           rr[bi][r] = fma(-alpha, qq[bi][r], rr[bi][r]);
           ps = fma(rr[bi][r], rr[bi][r], ps);
-          L.rbuf[(size_t)(blk * 16 + rq + 4 * r) * 16 + col] = rr[bi][r];
+          L.rbuf[(size_t)rpos(blk * 16 + rq + 4 * r) * 16 + col] = rr[bi][r];
         }
       }
     }
@@ -342,11 +368,20 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
     for (int bi = 0; bi < BPW; ++bi) {
       const int blk = wv + bi * nwv;
       if (blk < nblk) {
-        for (int jj = 0; jj < iters; ++jj) {
-          const double cf = L.hr[jj * 16 + col];
-          const double* hj = sl.H + (((size_t)jj * nblk + blk) * 4) * 64 + lane;
+        for (int j0 = 0; j0 < iters; j0 += 4) {              // four iterations' loads ahead of their multiply-adds
+          double hv[4][4], cf[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) xt[bi][r] = fma(cf, hj[r * 64], xt[bi][r]);
+          for (int u = 0; u < 4; ++u) {
+            const int jj = j0 + u < iters ? j0 + u : iters - 1;
+            cf[u] = j0 + u < iters ? L.hr[jj * 16 + col] : 0.0;
+            const double* hj = sl.H + (((size_t)jj * nblk + blk) * 4) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[u][r] = hj[r * 64];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xt[bi][r] = fma(cf[u], hv[u][r], xt[bi][r]);
         }
       }
     }
@@ -380,7 +415,7 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
 
 }  // namespace
 
-// LDS: rbuf [16 nr16cap] | ha | hb | hr [kMmax 16 each] | red [256] | cT | fT [kDcap + 2 each] | swl [512] | misc [32]
+// LDS: rbuf [16 nr16cap] | ha | hb | hr [kMmax 16 each] | red [256] | fT [kDcap + 2] | swl [512] | misc [32]; cT = ha | hb
 // (the staging copy of X' for the Z x' pass of an observation-space point overlays rbuf .. hr)
 // BPW: 16-row blocks per wave = the orders the instantiation takes (1: m <= 128, 2: <= 256, 4: <= 512); a launch passes over
 // the points of the other classes, so that each class has the registers of its own kernel
@@ -396,8 +431,8 @@ __global__ void __launch_bounds__(kKBlock, 1) letkf_stage_krylov_kernel(const St
   L.hb = L.ha + kMmax * 16;
   L.hr = L.hb + kMmax * 16;
   L.red = smem + r0;                                         // (r0 >= 16 nr16cap + 3 kMmax 16)
-  L.cT = L.red + 256;
-  L.fT = L.cT + (kDcap + 2);
+  L.cT = L.ha;                                               // (2 kMmax 16 = kDcap + 2 doubles)
+  L.fT = L.red + 256;
   L.swl = L.fT + (kDcap + 2);
   L.misc = L.swl + 512;
   double* xl = smem;                                         // [nv k] when it fits (xcap doubles)
@@ -464,8 +499,9 @@ __global__ void __launch_bounds__(kKBlock, 1) letkf_stage_krylov_kernel(const St
           }
       }
     }
-    __syncthreads();
     const int ldg = m | 1;
+    if (tid < 16) sl.G[(size_t)m * ldg + tid] = 0.0;         // (read as padding columns of the last rows: must be finite)
+    __syncthreads();
     int iters = 0;
     const bool ok = krylov_point<BPW>(sl, L, m, ldg, k, nv, nb, shift, dual, &iters);
     if (tid == 0) {
@@ -487,7 +523,8 @@ long stage_krylov_hist_doubles(int k) { return (long)kMmax * 16 * stage_krylov_m
 hipError_t launch_stage_krylov(const StagedArgs& s, size_t lds_max, hipStream_t st) {
   const int k = s.A.k;
   const int nr16cap = stage_krylov_max_n(k);
-  const size_t fixed = (size_t)256 + 2 * (kDcap + 2) + 512 + 32;
+  const size_t fixed = (size_t)256 + (kDcap + 2) + 512 + 32;
+  static_assert(kDcap + 2 <= 2 * kMmax * 16, "the Chebyshev coefficients overlay ha | hb");
   const size_t over = (size_t)16 * nr16cap + 3 * (size_t)kMmax * 16;   // rbuf .. hr: what the staging copy of X' may overlay
   const size_t budget = (lds_max > 160 * 1024 ? 160 * 1024 : lds_max) - 1024;
   size_t xcap = (size_t)s.A.nv * k;

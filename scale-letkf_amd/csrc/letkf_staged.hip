@@ -470,20 +470,24 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     int st = 0;
     if (!poly) {
       double lmx = 0.0, lmn = 1e300;
+      bool nan = false;                               // (a NaN in the point's observations: every comparison of the Jacobi is
+                                                      //  false, it "converges" at once -- fmax / fmin would drop the NaN here)
       for (int j = lane; j < mc; j += 64) {
         lmx = fmax(lmx, lam[j]);
         if (lam[j] > 0.0 || mc == m) lmn = fmin(lmn, lam[j]);
+        nan = nan || !(lam[j] == lam[j]);
       }
 #pragma unroll
       for (int mk = 1; mk < 64; mk <<= 1) {
         lmx = fmax(lmx, __shfl_xor(lmx, mk, 64));
         lmn = fmin(lmn, __shfl_xor(lmn, mk, 64));
       }
+      const bool any_nan = __ballot(nan) != 0ull;     // reported below as "not converged"
       if (dual) {                                     // A's spectrum = {lambda_j} and k - n copies of c
         lmx = fmax(lmx, shift);
         lmn = fmin(lmn, shift);
       }
-      const bool conv = solver == 0 || S.info[2 * it + 1] != 0;
+      const bool conv = (solver == 0 || S.info[2 * it + 1] != 0) && !any_nan;
       if (!conv) st = 1;
       else if (!(lmx > 0.0)) st = 2;
       else if (lmn < lmx * 1.4901161193847656e-08) st = 3;       // sqrt(DBL_EPSILON)
