@@ -53,8 +53,6 @@ constexpr int kMmax = 128;        // CG iterations (rows of the Lanczos tridiago
 constexpr int kDcap = 4094;       // highest Chebyshev degree of the tridiagonal function (cond ~ 47000); its coefficients overlay ha | hb
 constexpr double kTol2 = 1e-30;   // |r_j|^2 <= 1e-30 |t|^2
 
-typedef double d4 __attribute__((ext_vector_type(4)));
-
 struct KryLds {
   double* rbuf;    // [nr16cap][16]   the residual block, B operand of the product
   double* ha;      // [kMmax][16]     alpha_j per column
@@ -67,6 +65,73 @@ struct KryLds {
   double* misc;    // [32]
 };
 
+// The products of this file have one shape: D (16 rows per block x 16 right-hand sides) += A (rows x contraction) B, A a
+// matrix whose ROWS are contiguous in memory (M through its symmetric view, or the observation table's rows), B a block in
+// LDS ([contraction index permuted in groups of 8, see rpos][16]).  Lane (c, q) fetches row c's elements 8 t + 2 q, + 1 as
+// ONE 16-byte load per block and step t -- the A operands of two matrix-core instructions whose four contraction rows
+// are 8 t + 2 q' + o, q' < 4 (o = 0, then 1): 64 contiguous bytes per 4 lanes of a row.  A ring of PF loads per block is
+// in flight.  Every refill is unconditional: with a branch around a load hipcc can no longer count the loads in flight
+// and waits for all of them (vmcnt(0)) in front of every matrix-core step (found in the ISA); a padding step fetches
+// step 0 again.  wrap: the last refills fetch the FIRST steps again (the same product is repeated: CG on one matrix).
+// olim: largest element offset a lane may fetch from its row (clamped beyond: such columns meet zero rows of B).
+template <int BPW, int PF, int NA>
+__device__ __forceinline__ void ring_steps(d2u (&ring)[PF][BPW], const double* const (&abase)[BPW], const int olim, const int T,
+                                           const bool wrap, const double* __restrict__ bbuf, const int lane, d4 (&acc)[BPW]) {
+  const int Tp = (T + PF - 1) / PF * PF;
+  for (int t0 = 0; t0 < Tp; t0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int t = t0 + u;
+      if (t < T) {                                          // (wave-uniform)
+        const double b0 = bbuf[(size_t)(8 * t) * 16 + lane], b1 = bbuf[(size_t)(8 * t + 4) * 16 + lane];
+#pragma unroll
+        for (int bi = 0; bi < NA; ++bi) {
+          acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][bi].x, b0, acc[bi], 0, 0, 0);
+          acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][bi].y, b1, acc[bi], 0, 0, 0);
+        }
+      }
+      int tn = t + PF;
+      if (tn >= Tp) tn = wrap ? tn - Tp : 0;
+      if (tn >= T) tn = 0;
+      int off = 8 * tn;
+      off = off < olim ? off : olim;
+#pragma unroll
+      for (int bi = 0; bi < NA; ++bi) ring[u][bi] = *reinterpret_cast<const d2u*>(abase[bi] + off);
+    }
+  }
+}
+template <int BPW, int PF>
+__device__ __forceinline__ void ring_fill(d2u (&ring)[PF][BPW], const double* const (&abase)[BPW], const int olim, const int T) {
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    int off = 8 * (u < T ? u : 0);
+    off = off < olim ? off : olim;
+#pragma unroll
+    for (int bi = 0; bi < BPW; ++bi) ring[u][bi] = *reinterpret_cast<const d2u*>(abase[bi] + off);
+  }
+}
+// nact (wave-uniform) of the BPW blocks are real: the instantiation without the idle ones
+template <int BPW, int PF>
+__device__ __forceinline__ void ring_product(const int nact, d2u (&ring)[PF][BPW], const double* const (&abase)[BPW], const int olim,
+                                             const int T, const bool wrap, const double* __restrict__ bbuf, const int lane, d4 (&acc)[BPW]) {
+  if constexpr (BPW == 1) {
+    ring_steps<BPW, PF, 1>(ring, abase, olim, T, wrap, bbuf, lane, acc);
+  } else if constexpr (BPW == 2) {
+    if (nact == 2) ring_steps<BPW, PF, 2>(ring, abase, olim, T, wrap, bbuf, lane, acc);
+    else ring_steps<BPW, PF, 1>(ring, abase, olim, T, wrap, bbuf, lane, acc);
+  } else {
+    if (nact == 4) ring_steps<BPW, PF, 4>(ring, abase, olim, T, wrap, bbuf, lane, acc);
+    else if (nact == 3) ring_steps<BPW, PF, 3>(ring, abase, olim, T, wrap, bbuf, lane, acc);
+    else if (nact == 2) ring_steps<BPW, PF, 2>(ring, abase, olim, T, wrap, bbuf, lane, acc);
+    else ring_steps<BPW, PF, 1>(ring, abase, olim, T, wrap, bbuf, lane, acc);
+  }
+}
+__device__ __forceinline__ int rpos(int row) { return (row & ~7) + 4 * (row & 1) + ((row & 7) >> 1); }
+template <int BPW>
+struct RingDepth {
+  static constexpr int value = BPW == 1 ? 16 : BPW == 2 ? 8 : 2;
+};
+
 // One point.  Returns false when the point has to go to the eigen stage.
 template <int BPW>
 __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, const int n, const int ldg, const int k,
@@ -75,9 +140,7 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
   const int nr16 = (n + 15) & ~15, nblk = nr16 >> 4;
   const int col = lane & 15, rq = lane >> 4;
   double rr[BPW][4], pp[BPW][4], qq[BPW][4], xx[BPW][4];
-  // The residual block in LDS is stored with its rows PERMUTED inside every group of 8: row j = 8 t + 2 q + o sits at
-  // position 8 t + 4 o + q, so that the four rows of a matrix-core step (see the product) are consecutive
-  auto rpos = [](int row) { return (row & ~7) + 4 * (row & 1) + ((row & 7) >> 1); };
+  // (the residual block in LDS is stored with its rows permuted inside every group of 8: rpos, ring_steps)
   // ---- r_0 = t, rho_0
   {
     double ps = 0.0;
@@ -98,18 +161,14 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
     if (lane < 16) L.red[wv * 16 + lane] = ps;
   }
   __syncthreads();
-  // ---- the product's A operands.  M is symmetric: row i0 + c of M is column i0 + c of the slab, so lane (c, q) fetches
-  // M[i0 + c][8 t + 2 q .. + 1] as ONE 16-byte load per block and 8 columns -- the A operands of two matrix-core steps
-  // whose four contraction rows are 8 t + 2 q' + o, q' < 4 (o = 0: first step, 1: second): 64 contiguous bytes per 4 lanes
-  // of a row.  A ring of PF such loads per block is in flight; it wraps around into the NEXT iteration (M is the same
-  // every time), so the latency of L2 / Infinity Cache is paid once per point, not once per iteration.  Rows beyond n are
-  // clamped to row n - 1 (dropped at the use), columns beyond n read the neighbouring slab words (finite: zeroed by the
-  // caller) against zero rows of the residual block.
-  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-  constexpr int PF = BPW == 1 ? 16 : BPW == 2 ? 8 : 2;
+  // ---- the product's A operands (ring_steps): row i0 + c of M is column i0 + c of the slab (M is symmetric).  The ring
+  // wraps around into the NEXT iteration -- M is the same every time --, so the latency of L2 / Infinity Cache is paid once
+  // per point, not once per iteration.  Rows beyond n are clamped to row n - 1 (dropped at the use), columns beyond n read
+  // the neighbouring slab words (finite: zeroed by the caller) against zero rows of the residual block.
+  constexpr int PF = RingDepth<BPW>::value;
   const int nact_ = (nblk - wv + nwv - 1) / nwv;           // this wave's active blocks (wave-uniform), <= BPW
   const int nact = __builtin_amdgcn_readfirstlane(nact_ < 0 ? 0 : nact_ > BPW ? BPW : nact_);
-  const int T = nr16 >> 3, Tp = (T + PF - 1) / PF * PF;
+  const int T = nr16 >> 3;
   const double* abase[BPW];
 #pragma unroll
   for (int bi = 0; bi < BPW; ++bi) {
@@ -117,11 +176,7 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
     abase[bi] = sl.G + (size_t)(row < n ? row : n - 1) * ldg + 2 * rq;
   }
   d2u ring[PF][BPW];
-#pragma unroll
-  for (int u = 0; u < PF; ++u)
-#pragma unroll
-    for (int bi = 0; bi < BPW; ++bi)
-      ring[u][bi] = *reinterpret_cast<const d2u*>(abase[bi] + 8 * (u < T ? u : 0));   // (unconditional: hipcc counts the loads in flight only in straight-line code)
+  ring_fill<BPW, PF>(ring, abase, 1 << 30, T);
   double rho_old = 1.0, alpha_old = 1.0, tn2 = 0.0;
   bool frozen = false, failed = false;
   int mj = 0, j = 0;
@@ -143,41 +198,7 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
     d4 acc[BPW];
 #pragma unroll
     for (int bi = 0; bi < BPW; ++bi) acc[bi] = (d4){0.0, 0.0, 0.0, 0.0};
-    auto product = [&](auto na_) {
-      constexpr int NA = decltype(na_)::value;
-      for (int t0 = 0; t0 < Tp; t0 += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          const int t = t0 + u;
-          if (t < T) {                                      // (wave-uniform)
-            const double b0 = L.rbuf[(size_t)(8 * t) * 16 + lane], b1 = L.rbuf[(size_t)(8 * t + 4) * 16 + lane];
-#pragma unroll
-            for (int bi = 0; bi < NA; ++bi) {
-              acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][bi].x, b0, acc[bi], 0, 0, 0);
-              acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][bi].y, b1, acc[bi], 0, 0, 0);
-            }
-          }
-          // refill the slot -- ALWAYS: with a branch around a load hipcc can no longer count the loads in flight and waits
-          // for all of them (vmcnt(0)) in front of every matrix-core step; a padding step fetches step 0 again
-          int tn = t + PF;
-          if (tn >= Tp) tn -= Tp;                           // the next iteration's first steps
-          if (tn >= T) tn = 0;
-#pragma unroll
-          for (int bi = 0; bi < NA; ++bi) ring[u][bi] = *reinterpret_cast<const d2u*>(abase[bi] + 8 * tn);
-        }
-      }
-    };
-    if constexpr (BPW == 1) {
-      product(std::integral_constant<int, 1>());
-    } else if constexpr (BPW == 2) {
-      if (nact == 2) product(std::integral_constant<int, 2>());
-      else product(std::integral_constant<int, 1>());
-    } else {
-      if (nact == 4) product(std::integral_constant<int, 4>());
-      else if (nact == 3) product(std::integral_constant<int, 3>());
-      else if (nact == 2) product(std::integral_constant<int, 2>());
-      else product(std::integral_constant<int, 1>());
-    }
+    if (nact > 0) ring_product<BPW, PF>(nact, ring, abase, 1 << 30, T, true, L.rbuf, lane, acc);
     // ---- r_j to the history (lane-private; issued here, behind the product's loads, so that the next product's first
     // wait does not sit on these stores), mu = r . w per column
     double wreg[BPW][4];
@@ -420,7 +441,7 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
 // BPW: 16-row blocks per wave = the orders the instantiation takes (1: m <= 128, 2: <= 256, 4: <= 512); a launch passes over
 // the points of the other classes, so that each class has the registers of its own kernel
 template <int BPW>
-__global__ void __launch_bounds__(kKBlock, 1) letkf_stage_krylov_kernel(const StagedArgs S, const int nr16cap, const int r0, const int xcap) {
+__global__ void __launch_bounds__(kKBlock, 1) letkf_stage_krylov_kernel(const StagedArgs S, const int nr16cap, const int r0) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const PointArgs& A = S.A;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
@@ -435,7 +456,7 @@ __global__ void __launch_bounds__(kKBlock, 1) letkf_stage_krylov_kernel(const St
   L.fT = L.red + 256;
   L.swl = L.fT + (kDcap + 2);
   L.misc = L.swl + 512;
-  double* xl = smem;                                         // [nv k] when it fits (xcap doubles)
+  double* xl = smem;                                         // X' block of the Z x' product: overlays rbuf .. hr (r0 doubles)
 
   for (long it = blockIdx.x; it < S.nbatch; it += gridDim.x) {
     const long pt = S.pt0 + it;
@@ -464,39 +485,60 @@ __global__ void __launch_bounds__(kKBlock, 1) letkf_stage_krylov_kernel(const St
         sl.TT[2 * k + e] = g0[mm * A.sm + v * A.sv];
       }
     } else {
-      const bool x_lds = (long)nv * k <= xcap;
       for (int i = tid; i < n; i += nthr) {
         double w, d, dd, rl;
         ov.weights(i, w, d, dd, rl);
         L.swl[i] = sqrt(w);
       }
-      if (x_lds)
-        for (int e = tid; e < nv * k; e += nthr) {
-          const int v = e / k, mm = e - v * k;
-          xl[e] = g0[mm * A.sm + v * A.sv];
-        }
       for (int e = tid; e < 2 * n; e += nthr) sl.TT[(size_t)(e < n ? 0 : 1) * k + (e < n ? e : e - n)] = e < n ? sl.V0[e] : sl.V1[e - n];
-      __syncthreads();
-      // TT[2 + v][i] = (Z x'_v)_i: one wave per observation row
-      for (int i = wv; i < n; i += nwv) {
+      // TT[2 + v][i] = sqrt(w_i) sum_mm Y[i][mm] x'_v[mm] on the matrix cores (ring_steps): A = the local observations'
+      // rows of the table (members contiguous), B = X' in LDS, [member, permuted][16] with x'_v in column 2 + v, KC members
+      // at a time (the block overlays the iteration's LDS arrays).  (First version: a wave per observation row with 11 wave
+      // reductions each and nothing in flight behind the row being summed: ~60 us of a point's ~200 us outside the
+      // iterations at n = 200, k = 320.)
+      constexpr int PF = RingDepth<BPW>::value;
+      const int col = lane & 15, rq = lane >> 4;
+      const int nblk = (n + 15) >> 4;
+      const int nact_ = (nblk - wv + nwv - 1) / nwv;
+      const int nact = __builtin_amdgcn_readfirstlane(nact_ < 0 ? 0 : nact_ > BPW ? BPW : nact_);
+      const double* zrow[BPW];
+#pragma unroll
+      for (int bi = 0; bi < BPW; ++bi) {
+        const int row = (wv + bi * nwv) * 16 + col;
         long ms;
-        const double* yr = ov.row(i, ms);
-        double acc[kMaxNb];
+        zrow[bi] = ov.row(row < n ? row : n - 1, ms) + 2 * rq;
+      }
+      int KC = (r0 / 16) & ~15;
+      if (KC > ((k + 15) & ~15)) KC = (k + 15) & ~15;
+      d4 zacc[BPW];
 #pragma unroll
-        for (int v = 0; v < kMaxNb; ++v) acc[v] = 0.0;
-        for (int mm = lane; mm < k; mm += 64) {
-          const double y = yr[(long)mm * ms];
-#pragma unroll
-          for (int v = 0; v < kMaxNb; ++v)
-            if (v < nv) acc[v] = fma(y, x_lds ? xl[(size_t)v * k + mm] : g0[mm * A.sm + v * A.sv], acc[v]);
+      for (int bi = 0; bi < BPW; ++bi) zacc[bi] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int c0 = 0; c0 < k; c0 += KC) {
+        const int kc = k - c0 < KC ? k - c0 : KC, kc16 = (kc + 15) & ~15;
+        __syncthreads();                                     // (the previous chunk's readers; swl / TT writes above)
+        for (int e = tid; e < kc16 * 16; e += nthr) {
+          const int c = e / kc16, row = e - c * kc16;        // consecutive threads walk down the members of one variable
+          xl[(size_t)rpos(row) * 16 + c] = (row < kc && c >= 2 && c < nb) ? g0[(long)(c0 + row) * A.sm + (c - 2) * A.sv] : 0.0;
         }
-        const double sw = L.swl[i];
+        __syncthreads();
+        if (nact > 0) {
+          const double* zb[BPW];
 #pragma unroll
-        for (int v = 0; v < kMaxNb; ++v)
-          if (v < nv) {
-            const double s = wsum(acc[v]);
-            if (lane == 0) sl.TT[(size_t)(2 + v) * k + i] = s * sw;
-          }
+          for (int bi = 0; bi < BPW; ++bi) zb[bi] = zrow[bi] + c0;
+          const int olim = k - 1 - c0 - 2 * rq;              // (a row holds k + 1 doubles: the last pair fetched is [k - 1, k])
+          d2u zring[PF][BPW];
+          ring_fill<BPW, PF>(zring, zb, olim, kc16 >> 3);
+          ring_product<BPW, PF>(nact, zring, zb, olim, kc16 >> 3, false, xl, lane, zacc);
+        }
+      }
+#pragma unroll
+      for (int bi = 0; bi < BPW; ++bi) {
+        const int i0 = (wv + bi * nwv) * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + rq + 4 * r;
+          if (row < n && col >= 2 && col < nb) sl.TT[(size_t)col * k + row] = zacc[bi][r] * L.swl[row];
+        }
       }
     }
     const int ldg = m | 1;
@@ -527,16 +569,15 @@ hipError_t launch_stage_krylov(const StagedArgs& s, size_t lds_max, hipStream_t 
   static_assert(kDcap + 2 <= 2 * kMmax * 16, "the Chebyshev coefficients overlay ha | hb");
   const size_t over = (size_t)16 * nr16cap + 3 * (size_t)kMmax * 16;   // rbuf .. hr: what the staging copy of X' may overlay
   const size_t budget = (lds_max > 160 * 1024 ? 160 * 1024 : lds_max) - 1024;
-  size_t xcap = (size_t)s.A.nv * k;
-  if ((fixed + (xcap > over ? xcap : over)) * sizeof(double) > budget) xcap = 0;   // X' straight from the state then
-  const size_t r0 = xcap > over ? xcap : over;
+  const size_t r0 = over;
   const size_t lds = (fixed + r0) * sizeof(double);
+  if (lds > budget) return hipErrorInvalidValue;
   auto go = [&](auto kern) -> hipError_t {
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)s.nbatch), dim3(kKBlock), lds, st, s, nr16cap, (int)r0, (int)xcap);
+    hipLaunchKernelGGL(kern, dim3((unsigned)s.nbatch), dim3(kKBlock), lds, st, s, nr16cap, (int)r0);
     return hipGetLastError();
   };
   hipError_t e = go(&letkf_stage_krylov_kernel<1>);

@@ -577,12 +577,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
       }
     __syncthreads();
     if (poly) {
-      // q_b (dual: obs space, read as broadcasts by the Z^T q pass below -> LDS when it fits) and va_v = t_v^T M^-1 t_v
-      if (dual && pq_lds)
-        for (int e = tid; e < nb * n; e += nthr) {
-          const int b = e / n, i = e - b * n;
-          pcq[(size_t)b * nq + i] = sl.QQ[(size_t)b * k + i];
-        }
+      // va_v = t_v^T M^-1 t_v (q_b itself is fetched by the Z^T q pass below)
       for (int v = tid; v < nv; v += nthr) xsm[7 * nv + v] = sl.PC[v];
       __syncthreads();
     }
@@ -625,33 +620,100 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     if (!dual) {
       if (!poly) rows_comb(sl.G, ldg, k, mc, PCp, kq, nbr, sl.OUT, k);   // (eigen-free: OUT is written)
     } else {
-      if (!poly) rows_comb(sl.G, ldg, n, mc, PCp, kq, nbr, QQp, qld);      // q_b = U c_b  (obs space; eigen-free: q is there)
+      if (!poly) rows_comb(sl.G, ldg, n, mc, PCp, kq, nbr, QQp, qld);      // q_b = U c_b  (obs space; eigen-free: q is in the slab)
       __syncthreads();
-      // OUT[b][mm] = sum_i Z[i][mm] q_b[i]: one thread per member, the obs rows streamed (coalesced along mm)
-      for (int mm = tid; mm < k; mm += nthr) {
-        double acc[kMaxNb];
+      // OUT[b][mm] = sum_i Z[i][mm] q_b[i] (+ f_T(c) x'_v[mm]).  On the matrix cores when the operands fit: the contraction
+      // runs over the observation rows; for a group of 32 members lane (c, q) fetches Y[row 4 s + q][mm0 + 2 c, + 1] as one
+      // 16-byte load per step s -- 256 contiguous bytes per observation row -- whose halves are the A operands of TWO 16-row
+      // blocks (the group's even and odd members); B = sqrt(w_i) q_b[i] in LDS ([i][16]); 8 loads in flight per wave, every
+      // one unconditional (see letkf_krylov.hip ring_steps).  (Before: a thread per member with four rows of loads ahead of
+      // 52 multiply-adds -- 3.2 ms per 3456 points of C3-slab, as much as the Gram stage.)
+      const int n4 = (n + 3) & ~3;
+      const long qb_off = poly ? 0 : qq_lds ? (long)nb * (mq + nq) : pc_lds ? (long)nb * mq : 0;
+      const bool zq_mfma = das && qb_off + 16L * n4 <= pcq_doubles;
+      if (zq_mfma) {
+        double* qb = pcq + qb_off;
+        long* roff = reinterpret_cast<long*>(lam);        // (the spectra's arrays are used up; n < k)
+        const double* qsrc = poly ? sl.QQ : QQp;
+        const int qsld = poly ? k : qld;
+        for (int e = tid; e < n4 * 16; e += nthr) {
+          const int i = e >> 4, b = e & 15;
+          qb[e] = (i < n && b < nbr) ? qsrc[(size_t)b * qsld + i] * swl[i] : 0.0;
+        }
+        for (int i = tid; i < n4; i += nthr) roff[i] = (long)A.obs_idx[ov.o0 + (i < n ? i : n - 1)] * A.kld;
+        __syncthreads();
+        const int col = lane & 15, rq = lane >> 4;
+        const int T = n4 >> 2, ng = (k + 31) >> 5;
+        constexpr int ZR = 8;
+        const int Tp = (T + ZR - 1) / ZR * ZR;
+        for (int g = wv; g < ng; g += nwv) {
+          const int mm0 = 32 * g;
+          int eo = mm0 + 2 * col;
+          if (eo > k - 1) eo = k - 1;                     // (a row holds k + 1 doubles; such members are dropped below)
+          const double* ebase = A.ensval + eo;
+          d2u ring[ZR];
 #pragma unroll
-        for (int b = 0; b < kMaxNb; ++b) acc[b] = 0.0;
-        for (int i0 = 0; i0 < n; i0 += 4) {               // four observation rows of loads ahead of their FMAs
-          double z[4];
+          for (int u = 0; u < ZR; ++u) ring[u] = *reinterpret_cast<const d2u*>(ebase + roff[4 * (u < T ? u : 0) + rq]);
+          d4 ae = (d4){0.0, 0.0, 0.0, 0.0}, ao = (d4){0.0, 0.0, 0.0, 0.0};
+          for (int s0 = 0; s0 < Tp; s0 += ZR) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u < n ? i0 + u : n - 1;
-            long ms;
-            const double* yr = ov.row(i, ms);
-            z[u] = i0 + u < n ? yr[(long)mm * ms] * swl[i] : 0.0;
+            for (int u = 0; u < ZR; ++u) {
+              const int s_ = s0 + u;
+              if (s_ < T) {
+                const double bq = qb[(size_t)(4 * s_) * 16 + lane];
+                ae = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u].x, bq, ae, 0, 0, 0);
+                ao = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u].y, bq, ao, 0, 0, 0);
+              }
+              int sn = s_ + ZR;
+              if (sn >= T) sn = 0;
+              ring[u] = *reinterpret_cast<const d2u*>(ebase + roff[4 * sn + rq]);
+            }
           }
+          if (col < nbr) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u < n ? i0 + u : n - 1;
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int b = 0; b < kMaxNb; ++b)
-              if (b < nbr) acc[b] = fma(z[u], QQp[(size_t)b * qld + i], acc[b]);
+              for (int o = 0; o < 2; ++o) {
+                const int mm = mm0 + 2 * (rq + 4 * r) + o;
+                const double v_ = o ? ao[r] : ae[r];
+                if (mm < k) sl.OUT[(size_t)col * k + mm] = col >= 2 ? fma(tau0, sl.X[(size_t)(col - 2) * k + mm], v_) : v_;
+              }
           }
         }
+      } else {
+        if (poly && pq_lds) {                             // (q_b is read as broadcasts below: LDS when it fits)
+          for (int e = tid; e < nb * n; e += nthr) {
+            const int b = e / n, i = e - b * n;
+            pcq[(size_t)b * nq + i] = sl.QQ[(size_t)b * k + i];
+          }
+          __syncthreads();
+        }
+        // one thread per member, the obs rows streamed (coalesced along mm)
+        for (int mm = tid; mm < k; mm += nthr) {
+          double acc[kMaxNb];
 #pragma unroll
-        for (int b = 0; b < kMaxNb; ++b)
-          if (b < nbr) sl.OUT[(size_t)b * k + mm] = (b >= 2) ? fma(tau0, sl.X[(size_t)(b - 2) * k + mm], acc[b]) : acc[b];
+          for (int b = 0; b < kMaxNb; ++b) acc[b] = 0.0;
+          for (int i0 = 0; i0 < n; i0 += 4) {               // four observation rows of loads ahead of their FMAs
+            double z[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int i = i0 + u < n ? i0 + u : n - 1;
+              long ms;
+              const double* yr = ov.row(i, ms);
+              z[u] = i0 + u < n ? yr[(long)mm * ms] * swl[i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int i = i0 + u < n ? i0 + u : n - 1;
+#pragma unroll
+              for (int b = 0; b < kMaxNb; ++b)
+                if (b < nbr) acc[b] = fma(z[u], QQp[(size_t)b * qld + i], acc[b]);
+            }
+          }
+#pragma unroll
+          for (int b = 0; b < kMaxNb; ++b)
+            if (b < nbr) sl.OUT[(size_t)b * k + mm] = (b >= 2) ? fma(tau0, sl.X[(size_t)(b - 2) * k + mm], acc[b]) : acc[b];
+        }
       }
     }
     __syncthreads();
