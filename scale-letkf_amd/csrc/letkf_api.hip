@@ -312,6 +312,7 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
   s.kkout = kkout;
   s.wg_max_order = letkf::eig_wg_max_order();
   s.poly_max_n = krylov ? letkf::stage_krylov_max_n(a.k) : 0;
+  s.gram_mfma = a.mode == 0 ? 1 : 0;   // stage 1 on the matrix cores (letkf_gram.hip); the older kernel takes what that one leaves
   s.A.max_sweep = 60;
   EventPair ev;
   if (c->timing) {
@@ -326,7 +327,8 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
   for (long p0 = 0; p0 < a.npts; p0 += nb) {
     s.pt0 = p0;
     s.nbatch = (a.npts - p0 < nb) ? a.npts - p0 : nb;
-    HIP_TRY(letkf::launch_stage_gram(s, c->lds_max, c->stream));
+    if (s.gram_mfma) HIP_TRY(letkf::launch_stage_gram_mfma(s, c->stream));
+    if (!s.gram_mfma || a.k > 512) HIP_TRY(letkf::launch_stage_gram(s, c->lds_max, c->stream));   // (k <= 512: every point is the first kernel's)
     if (s.poly_max_n > 0) HIP_TRY(letkf::launch_stage_krylov(s, c->lds_max, c->stream));   // (points it gives up: eigen stage, next)
     letkf::EigArgs e;
     e.ws = s.A.ws;
@@ -345,7 +347,7 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
     c->events.emplace_back(ev.e0, ev.e1);
     ev.e0 = ev.e1 = nullptr;
   }
-  c->last_path = std::string("staged: letkf_stage_gram_kernel + ") + (s.poly_max_n > 0 ? "letkf_stage_krylov_kernel (CG + Lanczos; points it gives up: " : "") +
+  c->last_path = std::string(s.gram_mfma ? "staged: letkf_stage_gram_mfma_kernel + " : "staged: letkf_stage_gram_kernel + ") + (s.poly_max_n > 0 ? "letkf_stage_krylov_kernel (CG + Lanczos; points it gives up: " : "") +
                  (a.k <= 128 ? "letkf_eig_wg_kernel<4,32,32,1>" : "letkf_eig_wg_kernel<4,52,16,2>") +
                  (a.k > s.wg_max_order ? " / letkf_eig_block_kernel" : "") + (s.poly_max_n > 0 ? ")" : "") + " + letkf_stage_apply_kernel";
   return LETKF_OK;

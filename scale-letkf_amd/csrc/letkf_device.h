@@ -105,6 +105,7 @@ struct StagedArgs {
   int* info;
   int kkout;           // slab carries W (k x k outputs requested)
   int wg_max_order;    // largest order the workgroup Jacobi takes
+  int gram_mfma;       // the matrix-core Gram stage (letkf_gram.hip) runs in front: letkf_stage_gram_kernel takes only what that one leaves
   int poly_max_n;      // eigen-free points (letkf_krylov.hip: conjugate gradients + Lanczos instead of an eigen-decomposition): largest order, 0 = off
 };
 int stage_apply_pcq_doubles(int k, int nv);
@@ -118,6 +119,7 @@ hipError_t launch_eig_wg(const EigArgs& e, int mcap, int num_cu, hipStream_t st)
 hipError_t launch_eig_block(const EigArgs& e, int kmax, int num_cu, hipStream_t st);
 long staged_ws_per_point(int k, int nv, int kkout, long hist);
 hipError_t launch_stage_gram(const StagedArgs& s, size_t lds_max, hipStream_t st);
+hipError_t launch_stage_gram_mfma(const StagedArgs& s, hipStream_t st);
 hipError_t launch_stage_apply(const StagedArgs& s, hipStream_t st);
 
 struct LaunchPlan {

@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(kGBlock) letkf_stage_gram_kernel(const StagedA
     }
     const int n = ov.n;
     __syncthreads();
+    if (S.gram_mfma && !(n > 0 && beta != 0.0 && !gram_mfma_takes(n, k))) continue;   // (letkf_gram.hip has done this point)
     if (A.skip_trivial && (n == 0 || beta == 0.0)) {  // done by the streaming pass (letkf_trivial.hip): no stage touches it
       if (tid == 0) {
         S.meta[2 * it] = 255;

@@ -20,6 +20,9 @@ constexpr int kMaxNb = 16;     // right-hand sides: nv + 2 <= 16
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));   // two doubles fetched as one 16-byte load from an 8-byte aligned address
 
+// the points letkf_gram.hip's matrix-core Gram stage takes (loop body with lists): orders up to 512 (32 blocks of 16)
+__host__ __device__ inline bool gram_mfma_takes(int n, int k) { return n >= 1 && (n < k ? n <= 512 : k <= 512); }
+
 // Slab of one point of a batch (doubles; ldg = k | 1, nb = nv + 2):
 //   G [(k + 1) ldg] | V0 [k] | V1 [k] | SC [16] | X [nv k] | TT [nb k] | PC [nb (k + 2)] | QQ [nb k] | OUT [nb k] | (W [k ldg]) | (H [hist])
 // H: the residual history of the eigen-free stage (letkf_krylov.hip), lane-private layout.
