@@ -53,6 +53,14 @@ def main():
                     help="scale the obs-space perturbations so that their standard deviation is this many observation "
                          "errors (0: as generated -- 0.67 for iid, 0.81 for correlated); 2-3 is ordinary for radar "
                          "reflectivity in convection")
+    ap.add_argument("--level-slab", type=int, default=0,
+                    help="analyse the domain L levels at a time (the reference's level loop, scale/letkf/letkf_tools.f90:313): "
+                         "per step and slab obs_local (column search) for the slab's points, then the loop body -- the local-"
+                         "observation lists exist for one slab only (C4-gpu: 10 M points x ~4900 x 20 B do not fit at once)")
+    ap.add_argument("--state-slab", action="store_true",
+                    help="with --level-slab: the ensemble state of a slab is copied into a compact slab buffer before its loop body "
+                         "and the analysis is written to a slab buffer (the state streamed by level: C5-gpu's first guess + analysis "
+                         "are 2 x 152 GB; the copy stands for the transfer and is inside the timed step)")
     ap.add_argument("--max-nobs", type=int, default=0,
                     help="MAX_NOBS_PER_GRID: two radar ctypes on the lattice, each limited to this many observations")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -155,7 +163,10 @@ def main():
         return None
     if args.max_nobs > 0 and args.lists not in ("columns", "search"):
         sys.exit("--max-nobs needs --lists columns or search (the device obs_local)")
-    w = bw.build(args.workload, dev, rank=rank, world=world, ensval_kind=args.ensval)
+    slab_mode = args.level_slab > 0
+    if slab_mode and (args.lists != "columns" or args.no_search_in_step or world > 1 or args.state_layout != "ref"):
+        sys.exit("--level-slab: the column search inside the step, one GPU, the reference's state layout")
+    w = bw.build(args.workload, dev, rank=rank, world=world, ensval_kind=args.ensval, lists=not slab_mode)
     k, nv, npts = w["k"], w["nv"], w["npts"]
     bw.relayout_state(w, args.state_layout)
     # the streaming passes either side of the loop: mean into slot k, members -> perturbations
@@ -175,7 +186,10 @@ def main():
         t_s, keep_s, order_s, pts_s = bw.search_tables(w, pkg, dev, max_nobs=args.max_nobs)
         w["ensval"] = w["ensval"][order_s].contiguous()
         w["dep"] = w["dep"][order_s].contiguous()
-    if args.lists in ("search", "columns"):
+    if args.lists in ("search", "columns") and slab_mode:
+        nij_s = w["cfg"]["nx"] * w["cfg"]["ny"]
+        rig_s, rjg_s = pts_s[0][:nij_s].contiguous(), pts_s[1][:nij_s].contiguous()
+    elif args.lists in ("search", "columns"):
         n_torch = int(w["obs_off"][-1].item())
         nij_s = w["cfg"]["nx"] * w["cfg"]["ny"]
         rig_s, rjg_s = pts_s[0][:nij_s].contiguous(), pts_s[1][:nij_s].contiguous()
@@ -196,8 +210,18 @@ def main():
         w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"] = off_s, idx_s, rd_s, rl_s
         cnt = (off_s[1:] - off_s[:-1])
         w["n_mean"], w["n_max"] = float(cnt.double().mean()), int(cnt.max())
-    anal = torch.empty_like(w["gues"])
-    infl = torch.ones(npts * nv, dtype=torch.float64, device=dev)
+    nens = w["nens"]
+    slabs, slab_stat = [], {"nnz": 0, "n_max": 0, "last": None}
+    if slab_mode:
+        nz_ = w["cfg"]["nz"]
+        slabs = [(l0, min(l0 + args.level_slab, nz_)) for l0 in range(0, nz_, args.level_slab)]
+        npmax = nij_s * args.level_slab
+        infl_slab = torch.ones(npmax * nv, dtype=torch.float64, device=dev)
+        if args.state_slab:
+            gbuf = torch.empty(nv * nens * npmax, dtype=torch.float64, device=dev)
+            abuf = torch.empty_like(gbuf)
+    anal = torch.empty_like(w["gues"]) if not (slab_mode and args.state_slab) else None
+    infl = torch.ones(npts * nv, dtype=torch.float64, device=dev) if not slab_mode else None
     status = torch.zeros(npts, dtype=torch.int32, device=dev)
     nsweep = torch.zeros(npts, dtype=torch.int32, device=dev)
     relax = dict(rtps=dict(relax_alpha_spread=0.95), rtpp=dict(relax_alpha=0.7), none=dict())[args.relax]
@@ -238,7 +262,29 @@ def main():
             counts_x = [cuts[r + 1] - cuts[r] for r in range(world)]
             gathered = torch.empty_like(w["ensval"])
 
+    def step_slabs():
+        # the reference's level loop: per slab of levels obs_local for its points, then the loop body
+        slab_stat["nnz"], slab_stat["n_max"] = 0, 0
+        for (l0, l1) in slabs:
+            p0, p1 = l0 * nij_s, l1 * nij_s
+            np_ = p1 - p0
+            off_, idx_, rd_, rl_ = ctx.obs_search_columns(t_s, nij_s, l1 - l0, rig_s, rjg_s, pts_s[2][p0:p1], pts_s[3][p0:p1])
+            slab_stat["nnz"] += int(idx_.numel())
+            ws_ = dict(warm_run=args.warm_run, warm_stride=nij_s if (warm["warm_stride"] and l1 - l0 > 1) else 0)
+            if args.state_slab:
+                gs, as_ = gbuf[: nv * nens * np_], abuf[: nv * nens * np_]
+                gs.view(nv, nens, np_).copy_(bw.state_view(w, w["gues"])[:, :, p0:p1])     # the slab's state "arrives"
+                ssp, ssm, ssv = 1, np_, np_ * nens
+            else:
+                gs, as_ = w["gues"][p0:], anal[p0:]
+                ssp, ssm, ssv = w["sp"], w["sm"], w["sv"]
+            ctx.das_points(k, nv, off_, idx_, rd_, rl_, w["ensval"], w["kld"], w["dep"], infl_slab[: np_ * nv], gs, as_,
+                           ssp, ssm, ssv, status=status[p0:p1], nsweep=nsweep[p0:p1], **ws_, **relax)
+            slab_stat["last"] = (p0, p1, off_, idx_, rd_, rl_, gs, as_, ssp, ssm, ssv)
+
     def step():
+        if slab_mode:
+            return step_slabs()
         ens = w["ensval"]
         if world > 1:
             if args.exchange == "lib":
@@ -289,6 +335,18 @@ def main():
 
     out = None
     rc = 0
+    if slab_mode:
+        w["n_mean"] = slab_stat["nnz"] / npts
+        p0, p1, off_, idx_, rd_, rl_, gs, as_, ssp, ssm, ssv = slab_stat["last"]
+        cnt_ = off_[1:] - off_[:-1]
+        w["n_max"] = int(cnt_.max())
+        # the CPU baseline / parity sample is drawn from the last slab (the only lists and -- with --state-slab -- the only
+        # analysis that exist at the end of a step)
+        w_chk = dict(w, npts=p1 - p0, obs_off=off_, obs_idx=idx_, rdiag=rd_, rloc=rl_, gues=gs, sp=ssp, sm=ssm, sv=ssv,
+                     n_mean=float(cnt_.double().mean()))
+        anal_chk = as_
+    else:
+        w_chk, anal_chk = w, anal
     if rank == 0:
         n_mean = w["n_mean"]
         b_alg = bw.alg_bytes_per_solve(n_mean, k, nv)
@@ -300,6 +358,9 @@ def main():
         if cheb_deg_mean is not None and npoly == npts:
             # the eigen-free formulation needs fewer flops still (no 9 n^3): price the kernel with what it executes
             f_alg = min(f_alg, bw.alg_flops_poly(n_mean, k, nv, cheb_deg_mean))
+        # (the loop body may be several launches per step: one per level slab)
+        kern_launch_ms = kern_ms
+        kern_ms = kern_ms * nlaunch / max(args.steps, 1)
         kern_s = kern_ms * 1e-3
         achieved = b_alg * npts / kern_s / 1e9 if kern_s > 0 else None
         traffic = None
@@ -321,19 +382,19 @@ def main():
         main_ = fp64 if compute_bound else hbm
         roofline = {"bound": "mfma" if compute_bound else "hbm", "achieved": main_["achieved"], "peak": main_["peak"],
                     "unit": main_["unit"], "frac": main_["frac"], "traffic": traffic,
-                    "kernel": ctx.last_path(), "kernel_ms": kern_ms,
+                    "kernel": ctx.last_path(), "kernel_ms": kern_ms, "kernel_ms_per_launch": kern_launch_ms,
                     "launches": nlaunch, "alg_bytes_per_solve": b_alg, "alg_flops_per_solve": f_alg,
                     "alg_flops_kxk_nominal": f_kxk,
                     "arithmetic_intensity": f_alg / b_alg, "fp64": fp64, "hbm": hbm,
-                    "note": "bound = the roof the algorithmic intensity puts the kernel under; 'mfma' stands for the "
+                    "note": "kernel_ms = loop-body time per step (all its launches: one per level slab); bound = the roof the algorithmic intensity puts the kernel under; 'mfma' stands for the "
                             "FP64 peak (78.6 TFLOP/s, same for v_fma_f64 and v_mfma_f64): the Gram runs on the matrix "
                             "cores, the eigensolve on the vector ALUs; kernel_ms = the loop-body launch(es) only "
                             "(HIP events), ms_per_step also holds obs_local when search_in_step"}
         cpu = cpu_ref = None
         parity = None
         if n_gpus == 1 and not args.no_cpu_baseline:
-            cpu, parity = cpu_baseline(w, relax, args.cpu_seconds, args.cpu_threads, anal)
-            cpu_ref = cpu_baseline_reference(w, args.cpu_threads, min(args.cpu_seconds, 10.0))
+            cpu, parity = cpu_baseline(w_chk, relax, args.cpu_seconds, args.cpu_threads, anal_chk)
+            cpu_ref = cpu_baseline_reference(w_chk, args.cpu_threads, min(args.cpu_seconds, 10.0))
             if parity is not None and not (parity <= 1e-10):
                 rc = 3
         out = {"metric": "grid-point LETKF solves/sec", "value": value, "unit": "solves/s", "n_gpus": n_gpus,
@@ -343,7 +404,9 @@ def main():
                "config": {"workload": f"{args.workload}: {w['cfg']['nx']}x{w['cfg']['ny']}x{w['cfg']['nz']} grid, "
                                       f"k={k} members, nv={nv}, mean {n_mean:.1f} (max {w['n_max']}) local obs/point, "
                                       f"relax={args.relax}, ensval={args.ensval}, obs-space spread {obs_spread:.2f} obs errors" + (", state member-fastest" if args.state_layout == "member" else "")
-                                      + (f", MAX_NOBS_PER_GRID={args.max_nobs} x 2 ctypes" if args.max_nobs else ""),
+                                      + (f", MAX_NOBS_PER_GRID={args.max_nobs} x 2 ctypes" if args.max_nobs else "")
+                                      + (f"; analysed in slabs of {args.level_slab} level(s): obs_local + loop body per slab"
+                                         + (", state streamed per slab" if args.state_slab else "") if slab_mode else ""),
                           "points_per_gpu": npts, "obs_table_rows": int(w["ensval"].shape[0]),
                           "parallelism": f"grid-point shard x{n_gpus}" + ((" + RCCL obs all-gather (" + args.exchange + ")") if world > 1 else "")},
                "warm_runs": ("columns (warm_stride = nij1)" if warm["warm_stride"] else "along ij"),
@@ -417,8 +480,9 @@ def cpu_baseline(w, relax, seconds, threads, anal):
             worst = max(worst, float(np.abs(got[v] - exp[v]).max() / scale))
         return ns / dt, worst
 
-    rate0, p0 = run(min(npts, 64 * ncores))
-    ns = int(min(npts, max(64 * ncores, rate0 * seconds)))
+    first = (64 if k <= 100 else 8 if k <= 400 else 2) * ncores
+    rate0, p0 = run(min(npts, first))
+    ns = int(min(npts, max(first, rate0 * seconds)))
     rate, p1 = run(ns)
     return ({"value": rate, "unit": "solves/s", "cores": ncores, "kind": "port",
              "sample": f"{ns} randomly chosen grid points of the same workload (all {nv} variables, same relaxation), "

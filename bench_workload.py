@@ -57,6 +57,18 @@ CONFIGS = {
     # few local observations per point (n ~ 20 < k): the rim of a radar disc
     "C2-mini-sparse": dict(nx=48, ny=48, nz=12, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=6000.0, err=3.0,
                            ztop=18000.0, seed=20240622, halo=True),
+    # ---- the BASELINE configurations at their size (one GPU's share of the 8-GPU ones: a 4 x 2 tiling, the tile with
+    # the localisation halo of observations around it).  Run with bench.py --level-slab (the lists of C4-gpu do not
+    # fit at once: 10 M points x ~4900 x 20 B; the state of C5-gpu does not: 2 x 152 GB).
+    "C3": dict(nx=240, ny=240, nz=60, k=320, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2900.0, err=3.0,
+               ztop=18000.0, seed=20240630),
+    "C4-gpu": dict(nx=250, ny=500, nz=80, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=1100.0, err=3.0,
+                   ztop=18000.0, seed=20240631, halo=True),
+    "C5-gpu": dict(nx=120, ny=240, nz=60, k=1000, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
+                   ztop=18000.0, seed=20240632, halo=True),
+    # C2's grid at k = 20 (the memory-bound regime of configs[0]: arithmetic intensity ~5 flop/B)
+    "C2-k20": dict(nx=240, ny=240, nz=60, k=20, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2900.0, err=3.0,
+                   ztop=18000.0, seed=20240633),
     "C1": dict(nx=40, ny=40, nz=30, k=20, dx=15000.0, hloc=120000.0, vloc=4000.0, spacing=30000.0, err=3.0,
                ztop=18000.0, seed=20240608),
 }
@@ -88,7 +100,9 @@ def disc_mask(cfg, ox, oy):
     return ((ox[None, :] - cx) ** 2 + (oy[:, None] - cy) ** 2) <= cfg["disc"] ** 2
 
 
-def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval_kind="iid"):
+def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval_kind="iid", lists=True):
+    """lists = False: no torch-built local-observation lists (the full-size configurations: the lists come from the
+    device search, one level slab at a time)."""
     cfg = CONFIGS[cfg_name]
     nx, ny, nz, k = cfg["nx"], cfg["ny"], cfg["nz"], cfg["k"]
     dx, hloc, vloc, sp_o, err = cfg["dx"], cfg["hloc"], cfg["vloc"], cfg["spacing"], cfg["err"]
@@ -119,7 +133,7 @@ def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval_kind="
     cix = torch.floor(px / sp_o).long() + nh
     ciy = torch.floor(py / sp_o).long() + nh
     counts_all, idx_all, rloc_all = [], [], []
-    for lev in range(nz):
+    for lev in range(nz if lists else 0):
         ciz = int(math.floor(float(zlev[lev]) / sp_o)) + nhz
         ix = cix[:, None] + offs[None, :]                                   # [nij, nh]
         iy = ciy[:, None] + offs[None, :]
@@ -145,12 +159,16 @@ def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval_kind="
         idx_all.append(oidx.reshape(-1)[sel].to(torch.int32))
         rloc_all.append(torch.exp(-0.5 * nd2.reshape(-1)[sel]))
         del d2h, ndh, nd2, ok, oidx, okf, sel
-    counts = torch.cat(counts_all)
-    obs_off = torch.zeros(nij * nz + 1, dtype=torch.int64, device=device)
-    obs_off[1:] = torch.cumsum(counts, 0)
-    obs_idx = torch.cat(idx_all)
-    rloc = torch.cat(rloc_all)
-    rdiag = (err * err) / rloc                                              # letkf_tools.f90:1903
+    if lists:
+        counts = torch.cat(counts_all)
+        obs_off = torch.zeros(nij * nz + 1, dtype=torch.int64, device=device)
+        obs_off[1:] = torch.cumsum(counts, 0)
+        obs_idx = torch.cat(idx_all)
+        rloc = torch.cat(rloc_all)
+        rdiag = (err * err) / rloc                                          # letkf_tools.f90:1903
+    else:
+        counts = torch.zeros(1, dtype=torch.int64, device=device)
+        obs_off = obs_idx = rloc = rdiag = None
     del counts_all, idx_all, rloc_all
     # ---- ensemble state gues3d(nij*nz, nens, nv): members, then mean slot k, det slot k+1
     npts = nij * nz
