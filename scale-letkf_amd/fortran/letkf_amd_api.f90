@@ -1,8 +1,9 @@
 !===============================================================================
-! letkf_amd_api.f90 -- ISO_C_BINDING view of the batched entry points of include/letkf_amd.h, for a das_letkf that is
-! restructured into "search, then one call per level slab" (INTEGRATION.md, level 2).  TYPE letkf_das_args mirrors the
-! C struct field by field (same order, same kinds); device buffers are C pointers obtained from hipMalloc (bound
-! below straight from libamdhip64 -- hipfort is not needed).
+! letkf_amd_api.f90 -- ISO_C_BINDING view of EVERY device entry point of include/letkf_amd.h (sections 1b - 8), for a
+! das_letkf that runs "search, then one call per level slab" on the device (letkf_tools_amd.f90 is that routine;
+! INTEGRATION.md, level 2).  The derived types mirror the C structs field by field (same order, same kinds:
+! tests/test_fortran_shim.py reads every field back through C); device buffers are C pointers obtained from hipMalloc
+! (bound below straight from libamdhip64 -- hipfort is not needed).
 !===============================================================================
 MODULE letkf_amd_api
   USE, INTRINSIC :: iso_c_binding
@@ -29,6 +30,55 @@ MODULE letkf_amd_api
     INTEGER(c_int32_t) :: radar_only, ihalo, jhalo, nlong, nlatg, reserved0
     REAL(c_double)     :: radar_zmax, vert_local_radar, boundary_buffer_width, dx, dy
   END TYPE letkf_beta_params
+
+
+  ! include/letkf_amd.h section 1b
+  TYPE, BIND(C) :: letkf_core_batch_args
+    INTEGER(c_int32_t) :: ne, nobs
+    INTEGER(c_int64_t) :: nbatch
+    TYPE(c_ptr)        :: nobsl, hdxb, rdiag, rloc, dep, depd, parm_infl, trans, transm, pao, transmd
+    INTEGER(c_int32_t) :: rdiag_wloc, infl_update
+    TYPE(c_ptr)        :: status, nsweep
+  END TYPE letkf_core_batch_args
+
+  ! section 3: what set_letkf_obs leaves behind (scale/letkf/letkf_obs.f90:35-72); every pointer is a DEVICE pointer, the
+  ! struct itself is passed by reference from the host
+  TYPE, BIND(C) :: letkf_search_tables
+    INTEGER(c_int32_t) :: nctype, ngroup, criterion, nlon, nlat, limit_hint
+    REAL(c_double)     :: dx, dy, i_org, j_org, rain_base
+    TYPE(c_ptr)        :: group_start, group_member
+    TYPE(c_ptr)        :: vmode, hori_loc, vert_loc, varloc, max_nobs
+    TYPE(c_ptr)        :: ngrd_i, ngrd_j, ngrdsch_i, ngrdsch_j, ngrdext_i, ngrdext_j
+    TYPE(c_ptr)        :: ac_off, ac_ext
+    TYPE(c_ptr)        :: ob_ri, ob_rj, ob_lev, ob_dat, ob_err
+  END TYPE letkf_search_tables
+
+  ! section 4
+  TYPE, BIND(C) :: letkf_state_consts
+    REAL(c_double)     :: rdry, rvap, cvdry, pre00
+    REAL(c_double)     :: tracer_cv(8)
+    INTEGER(c_int32_t) :: iv_rho, iv_rhou, iv_rhov, iv_rhow, iv_rhot
+    INTEGER(c_int32_t) :: iv_u, iv_v, iv_w, iv_t, iv_p
+    INTEGER(c_int32_t) :: iv_q
+    INTEGER(c_int32_t) :: positive_definite_q, positive_definite_qhyd
+    INTEGER(c_int32_t) :: reserved0
+  END TYPE letkf_state_consts
+
+  ! section 5
+  TYPE, BIND(C) :: letkf_qc_params
+    INTEGER(c_int32_t) :: member, det_run, use_radar_ref, use_radar_vr, min_radar_ref_member, min_radar_ref_member_obsref
+    REAL(c_double)     :: radar_ref_thres_dbz
+    REAL(c_double)     :: gross_error, gross_error_rain, gross_error_radar_ref, gross_error_radar_vr, gross_error_radar_prh, &
+                          gross_error_tcx, gross_error_tcy, gross_error_tcp
+  END TYPE letkf_qc_params
+  TYPE, BIND(C) :: letkf_mesh
+    INTEGER(c_int32_t) :: nctype, nlon, nlat, ihalo, jhalo, rank_i, rank_j, fix_ij_obsgrd
+    TYPE(c_ptr)        :: ngrd_i, ngrd_j                 ! HOST [nctype]
+  END TYPE letkf_mesh
+  TYPE, BIND(C) :: letkf_halo_layout
+    INTEGER(c_int32_t) :: nctype, nprocs, prc_num_x, myrank
+    TYPE(c_ptr)        :: ngrd_i, ngrd_j, ngrdsch_i, ngrdsch_j   ! HOST [nctype]
+  END TYPE letkf_halo_layout
 
   INTERFACE
     ! das_letkf set-up (scale/letkf/letkf_tools.f90:130-267, relax_beta :1911-1948); the first three are host functions
@@ -127,6 +177,142 @@ MODULE letkf_amd_api
       TYPE(c_ptr), VALUE :: ctx, x
       INTEGER(c_int32_t), VALUE :: k, nv
       INTEGER(c_int64_t), VALUE :: npts, sp, sm, sv
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    ! ---- section 1b: batched letkf_core on device pointers
+    FUNCTION letkf_core_batch_dev(ctx, args) BIND(C, name='letkf_core_batch_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, letkf_core_batch_args
+      TYPE(c_ptr), VALUE :: ctx
+      TYPE(letkf_core_batch_args), INTENT(IN) :: args
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_ctx_set_stream(ctx, hip_stream) BIND(C, name='letkf_ctx_set_stream') RESULT(rc)
+      IMPORT :: c_int, c_ptr
+      TYPE(c_ptr), VALUE :: ctx, hip_stream
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    ! ---- section 3: obs_local on the device (scale/letkf/letkf_tools.f90:1325-1759).  Two-phase CSR build: fill = 0 ->
+    ! counts; scan them into obs_off (npts + 1, int64); fill = 1 -> obs_idx / rdiag_l / rloc_l
+    FUNCTION letkf_obs_search_dev(ctx, tables, npts, ri, rj, rlev, rz, fill, counts, obs_off, obs_idx, rdiag_l, rloc_l) &
+        BIND(C, name='letkf_obs_search_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t, letkf_search_tables
+      TYPE(c_ptr), VALUE :: ctx, ri, rj, rlev, rz, counts, obs_off, obs_idx, rdiag_l, rloc_l
+      TYPE(letkf_search_tables), INTENT(IN) :: tables
+      INTEGER(c_int64_t), VALUE :: npts
+      INTEGER(c_int32_t), VALUE :: fill
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    ! points p = ij + nij1*lev (gues3d's order): rig / rjg [nij1], rlev / rz [nij1*nlev]; nobs_ctype / cutd_ctype: the
+    ! NOBS_OUT inputs [nij1*nlev][nctype] or c_null_ptr
+    FUNCTION letkf_obs_search_columns_dev(ctx, tables, nij1, nlev, rig, rjg, rlev, rz, fill, counts, obs_off, obs_idx, &
+                                          rdiag_l, rloc_l, nobs_ctype, cutd_ctype) &
+        BIND(C, name='letkf_obs_search_columns_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t, letkf_search_tables
+      TYPE(c_ptr), VALUE :: ctx, rig, rjg, rlev, rz, counts, obs_off, obs_idx, rdiag_l, rloc_l, nobs_ctype, cutd_ctype
+      TYPE(letkf_search_tables), INTENT(IN) :: tables
+      INTEGER(c_int64_t), VALUE :: nij1
+      INTEGER(c_int32_t), VALUE :: nlev, fill
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_das_points_fused_dev(ctx, args, tables, ri, rj, rlev, rz, nobs_out) &
+        BIND(C, name='letkf_das_points_fused_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, letkf_das_args, letkf_search_tables
+      TYPE(c_ptr), VALUE :: ctx, ri, rj, rlev, rz, nobs_out
+      TYPE(letkf_das_args), INTENT(IN) :: args
+      TYPE(letkf_search_tables), INTENT(IN) :: tables
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    ! ---- section 4: the steps either side of the loop (row f3)
+    FUNCTION letkf_state_trans_dev(ctx, c, nlev, nlon, nlat, nv3d, v3dg, inverse) &
+        BIND(C, name='letkf_state_trans_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, letkf_state_consts
+      TYPE(c_ptr), VALUE :: ctx, v3dg
+      TYPE(letkf_state_consts), INTENT(IN) :: c
+      INTEGER(c_int32_t), VALUE :: nlev, nlon, nlat, nv3d, inverse
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_member_points_dev(ctx, dir, nlev, nlon, nlat, nv3d, np, rank, m, v3dg, x, nij1, sp, sm, sv) &
+        BIND(C, name='letkf_member_points_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t
+      TYPE(c_ptr), VALUE :: ctx, v3dg, x
+      INTEGER(c_int32_t), VALUE :: dir, nlev, nlon, nlat, nv3d, np, rank, m
+      INTEGER(c_int64_t), VALUE :: nij1, sp, sm, sv
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_ens_spread_dev(ctx, k, nv, npts, x, sp, sm, sv, sprd) BIND(C, name='letkf_ens_spread_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t
+      TYPE(c_ptr), VALUE :: ctx, x, sprd
+      INTEGER(c_int32_t), VALUE :: k, nv
+      INTEGER(c_int64_t), VALUE :: npts, sp, sm, sv
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    ! ---- section 5: set_letkf_obs on the device (row f2)
+    FUNCTION letkf_obs_departure_dev(ctx, p, nobs, elm, dat, err, ensval, kld, val, qc) &
+        BIND(C, name='letkf_obs_departure_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int64_t, letkf_qc_params
+      TYPE(c_ptr), VALUE :: ctx, elm, dat, err, ensval, val, qc
+      TYPE(letkf_qc_params), INTENT(IN) :: p
+      INTEGER(c_int64_t), VALUE :: nobs, kld
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_obs_mesh_sort_dev(ctx, mesh, nobs, ctype, ri, rj, qc, n_cell, key, nsorted) &
+        BIND(C, name='letkf_obs_mesh_sort_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int64_t, letkf_mesh
+      TYPE(c_ptr), VALUE :: ctx, ctype, ri, rj, qc, n_cell, key
+      TYPE(letkf_mesh), INTENT(IN) :: mesh
+      INTEGER(c_int64_t), VALUE :: nobs
+      INTEGER(c_int64_t), INTENT(OUT) :: nsorted
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_obs_halo_plan_dev(ctx, layout, n_all, ac_ext, src_row, cap, nobstotal) &
+        BIND(C, name='letkf_obs_halo_plan_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int64_t, letkf_halo_layout
+      TYPE(c_ptr), VALUE :: ctx, n_all, ac_ext, src_row
+      TYPE(letkf_halo_layout), INTENT(IN) :: layout
+      INTEGER(c_int64_t), VALUE :: cap
+      INTEGER(c_int64_t), INTENT(OUT) :: nobstotal
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_obs_gather_rows_dev(ctx, nrows, src_row, ncols, src, ld_src, dst, ld_dst) &
+        BIND(C, name='letkf_obs_gather_rows_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t
+      TYPE(c_ptr), VALUE :: ctx, src_row, src, dst
+      INTEGER(c_int64_t), VALUE :: nrows, ld_src, ld_dst
+      INTEGER(c_int32_t), VALUE :: ncols
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_obs_gather_i32_dev(ctx, nrows, src_row, src, dst) BIND(C, name='letkf_obs_gather_i32_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int64_t
+      TYPE(c_ptr), VALUE :: ctx, src_row, src, dst
+      INTEGER(c_int64_t), VALUE :: nrows
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    ! ---- section 6: after the loop (row f4); elem_uid is a HOST array
+    FUNCTION letkf_monit_dep_dev(ctx, nid, elem_uid, nn, elm, dep, qc, nobs, bias, rmse) &
+        BIND(C, name='letkf_monit_dep_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t
+      TYPE(c_ptr), VALUE :: ctx, elm, dep, qc, nobs, bias, rmse
+      INTEGER(c_int32_t), VALUE :: nid
+      INTEGER(c_int32_t), INTENT(IN) :: elem_uid(nid)
+      INTEGER(c_int64_t), VALUE :: nn
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_additive_inflation_dev(ctx, k, nv, npts, nij1, anal, add, sp, sm, sv, infl_add, weight, qmean, q_sp, &
+                                          q_sv, iv_q_first, iv_q_last, ishuf) &
+        BIND(C, name='letkf_additive_inflation_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t, c_double
+      TYPE(c_ptr), VALUE :: ctx, anal, add, weight, qmean, ishuf
+      INTEGER(c_int32_t), VALUE :: k, nv, iv_q_first, iv_q_last
+      INTEGER(c_int64_t), VALUE :: npts, nij1, sp, sm, sv, q_sp, q_sv
+      REAL(c_double), VALUE :: infl_add
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_addinfl_weight_dev(ctx, nij1, rig, rjg, nob, ob_ri, ob_rj, dx, dy, hori_loc, weight) &
+        BIND(C, name='letkf_addinfl_weight_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int64_t, c_double
+      TYPE(c_ptr), VALUE :: ctx, rig, rjg, ob_ri, ob_rj, weight
+      INTEGER(c_int64_t), VALUE :: nij1, nob
+      REAL(c_double), VALUE :: dx, dy, hori_loc
       INTEGER(c_int) :: rc
     END FUNCTION
     ! device memory, straight from the HIP runtime
