@@ -1662,7 +1662,7 @@ bool wave_kernel_supports(int k, int nv, int mode) {
 int wave_kernel_kr(int k);
 static int wave_kr(int k) { return wave_kernel_kr(k); }
 int wave_kernel_kr(int k) {
-  return k <= 16 ? 16 : k <= 32 ? 32 : k <= 48 ? 48 : k <= 50 ? 50 : k <= 62 ? 64 : k <= 64 ? 64 : k <= 80 ? 80 : 100;
+  return k <= 16 ? 16 : k <= 20 ? 20 : k <= 32 ? 32 : k <= 48 ? 48 : k <= 50 ? 50 : k <= 62 ? 64 : k <= 64 ? 64 : k <= 80 ? 80 : 100;
 }
 
 // Launch shape of the wave kernel: run length of the warm-started runs, grid, and the bytes of warm-start workspace
@@ -1720,6 +1720,7 @@ hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st) {
   const int k = a.k;
   const bool kkout = a.trans_out || a.pa_out;
   LETKF_WAVE_CASE(16, 1)
+  LETKF_WAVE_CASE(20, 1)   // MEMBER = 20: the reference's test configuration (BASELINE configs[0]); in the 32-row instantiation a third of the rows were padding
   LETKF_WAVE_CASE(32, 1)
   LETKF_WAVE_CASE(48, 1)
   LETKF_WAVE_CASE(50, 1)
