@@ -167,10 +167,17 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
     }
   }
   int sweep = 0, pairs_done = 0, conv = 0;
-  // (NW = 2: the loop below holds workgroup barriers inside `if (slot < S)`.  Both waves always enter it -- lane 0 of
-  // either wave is slot 0 < S -- and s_barrier counts waves, not lanes, so the barrier counts of the two waves agree.)
-  if (slot < S) {
-    const bool hasL = slot > 0, hasR = slot + 1 < S;
+  // Lanes of unused slots (slot >= S) hold zero columns.  NW = 1: they sit out the whole iteration (nothing below
+  // synchronises more than the wave).  NW = 2: the iteration holds WORKGROUP barriers (slot_sum_nw, the vote), and a
+  // barrier must not sit in divergent code -- so every lane runs the loop, the scalar arithmetic of an unused slot works on
+  // zeros (no rotation, no vote), and only the barrier-free ROW loops are switched off for it (`rows`): there a DPP read
+  // from a disabled lane returns 0 (bound_ctrl), which is exactly the "no partner" case at the end of the line, and the
+  // unused slot's own registers are never written.  (Rounds 1 and 2 had the barriers inside `if (slot < S)`, relying on
+  // s_barrier counting waves; same instructions in the row loops, same results.)
+  const bool act = slot < S;
+  const bool rows = NW == 1 || act;
+  if (NW == 2 || act) {
+    const bool hasL = act && slot > 0, hasR = act && slot + 1 < S;
     double alA = 0.0, alB = 0.0, isA = 1.0, isB = 1.0, scA = 1.0, scB = 1.0;
     // `quiet` counts consecutive step pairs in which no visited column pair exceeded the tolerance; S of them in a
     // row are one full cycle of the ordering (every column pair seen once) whatever step it started at, so the
@@ -180,12 +187,14 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
     for (; sweep < max_sweep && !done; ++sweep) {
       // refresh: fold the scales back, recompute the squared norms
       double a0 = 0.0, b0 = 0.0;
+      if (rows) {
 #pragma unroll
-      for (int rr = 0; rr < H; ++rr) {
-        xa[rr] *= isA;
-        xb[rr] *= isB;
-        a0 = fma(xa[rr], xa[rr], a0);
-        b0 = fma(xb[rr], xb[rr], b0);
+        for (int rr = 0; rr < H; ++rr) {
+          xa[rr] *= isA;
+          xb[rr] *= isB;
+          a0 = fma(xa[rr], xa[rr], a0);
+          b0 = fma(xb[rr], xb[rr], b0);
+        }
       }
       alA = slot_sum_nw<NW>(a0, lds, ph);
       alB = slot_sum_nw<NW>(b0, lds, ph);
@@ -195,10 +204,12 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
         // ---------------- even step: the slot's own two columns (A at the lower position)
         {
           double p0 = 0.0, p1 = 0.0;
+          if (rows) {
 #pragma unroll
-          for (int rr = 0; rr < H; ++rr) {
-            if (rr & 1) p1 = fma(xa[rr], xb[rr], p1);
-            else p0 = fma(xa[rr], xb[rr], p0);
+            for (int rr = 0; rr < H; ++rr) {
+              if (rr & 1) p1 = fma(xa[rr], xb[rr], p1);
+              else p0 = fma(xa[rr], xb[rr], p0);
+            }
           }
           const double ga = slot_sum_nw<NW>(p0 + p1, lds, ph) * (isA * isB);
           const double a = alA, b = alB;
@@ -225,7 +236,9 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           scB = nscB;
           // the new A goes to the spare array xf, the new B is accumulated in place in xa[] (every FMA adds into the
           // register its result stays in: no copies)
-          if constexpr (INPLACE) {
+          if (!rows) {
+            // (an unused slot of a two-wave point: its columns stay the zeros they are)
+          } else if constexpr (INPLACE) {
             // A stays in xa[], B in xb[]: xa <- xb + cA xa, xb <- xa_old + cB xb, as one instruction sequence per row
             // (from C++ hipcc renames the whole column per step)
 #pragma unroll
@@ -251,7 +264,8 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
         // ---------------- odd step: own B (now in xa[]) with the right slot's A; own A (in xf[]) with the left slot's B
         {
           double p0 = 0.0, p1 = 0.0;
-          if constexpr (INPLACE) {
+          if (!rows) {
+          } else if constexpr (INPLACE) {
 #pragma unroll
             for (int rr = 0; rr < H; ++rr) {
               // (register-only fences keep the rows in order: without them hipcc fetches all rows of the neighbour
@@ -307,7 +321,8 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           // new B into xb[] (on top of the fetched column); then the old B of the LEFT slot is pulled into xa[] --
           // every lane reads its neighbour's xa[rr] and overwrites its own in the same instruction -- and the new A
           // accumulated on top of it: A is back in xa[], B in xb[], xf[] is spare again
-          if constexpr (INPLACE) {
+          if (!rows) {
+          } else if constexpr (INPLACE) {
             // own B (xb) takes the right slot's A on top: xb <- A_r + coefR xb; own A (xa) the left slot's old B:
             // xa <- B_l + coefL xa -- both neighbours' elements are read before either own element of the row changes
 #pragma unroll
@@ -351,10 +366,12 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
     sweep = (pairs + S - 1) / S;
     pairs_done = pairs;
     conv = done ? 1 : 0;
+    if (rows) {
 #pragma unroll
-    for (int rr = 0; rr < H; ++rr) {
-      xa[rr] *= isA;
-      xb[rr] *= isB;
+      for (int rr = 0; rr < H; ++rr) {
+        xa[rr] *= isA;
+        xb[rr] *= isB;
+      }
     }
   }
   sweep = __builtin_amdgcn_readfirstlane(sweep);
