@@ -37,14 +37,25 @@ constexpr double kRotTol2W = 1e-30;   // rotate when cos^2 > 1e-30
 #ifndef LETKF_EARLY_T2
 #define LETKF_EARLY_T2 1e-12
 #endif
-constexpr double kStopTol2W = 1e-20;  // sweep counts as converged when every visited pair had |cos| <= 1e-10 (all of them were
-                                      // still rotated away in that sweep, so what is left is second order)
+#ifndef LETKF_STOP_TOL2
+#define LETKF_STOP_TOL2 1e-24
+#endif
+// The iteration counts as converged when every pair visited in a full cycle had |cos| <= 1e-12 (all of them were still
+// rotated away in that cycle, so what is left is second order).  Round 3: 1e-12 instead of 1e-10.  The interior points of
+// a workload never saw the difference -- they end on the early-stop rule below, or overshoot by the quadratic convergence
+// (C2: 4.856 sweeps either way, same time) -- but a point with fewer local observations than members has the eigenvalue
+// (k-1)/rho with multiplicity k - n, pairs inside that cluster are rotated by 45 degrees at rounding-level cosines (no
+// quadratic phase, no early stop), and the couplings of up to 1e-10 that the old rule left between the cluster and the
+// other columns showed up as 5e-12 .. 1.5e-11 in the analysis members (tools/r3_sparse_margin.py: only points with
+// 1 <= n < k, 1000 x the interior's error, 8 x inside the tolerance).  With 1e-12: 1.5e-14 on the same points for
+// +0.4 sweeps there (C2-mini-sparse 6.85 -> 7.24 sweeps, +4 % time); pinned by tests/test_gpu_sparse_margin.py.
+constexpr double kStopTol2W = LETKF_STOP_TOL2;
 // Early stop: a full cycle in which every pair had |cos| <= 1e-8 AND every applied rotation a tangent |t| <= 1e-6 ends the
 // iteration as well -- each coupling was annihilated once in that cycle and re-filled by at most k products t * cos
 // <= 1e-14.  The tangent condition matters: with (near-)multiple eigenvalues a pair of almost equal columns is rotated
 // by a large angle at a tiny cosine, which shuffles the couplings of size 1e-8 of those two columns to all others
 // after they were visited -- without it the result is only first-order accurate (measured: 8e-10 on T for n < k,
-// tools/parity_margin.py).  Such points simply fall back to the 1e-10 rule.
+// tools/parity_margin.py).  Such points simply fall back to the rule above (1e-12).
 constexpr double kEarlyTol2W = LETKF_EARLY_TOL2;
 constexpr double kEarlyT2W = LETKF_EARLY_T2;
 
