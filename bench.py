@@ -40,10 +40,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--relax", default="rtps", choices=["rtps", "rtpp", "none"])
-    ap.add_argument("--lists", default="columns", choices=["columns", "search", "torch", "fused"],
+    ap.add_argument("--list-gb", type=float, default=8.0, help="--lists pipeline: list workspace of the library in GiB")
+    ap.add_argument("--lists", default="columns", choices=["columns", "search", "torch", "fused", "pipeline"],
                     help="where the local-obs lists come from: letkf_obs_search_columns_dev (default), the per-point "
                          "letkf_obs_search_dev, the torch workload builder (no search on the device), or obs_local "
-                         "fused into the loop-body kernel")
+                         "fused into the loop-body kernel; pipeline = letkf_das_columns_dev: ONE call per step, column search + loop "
+                         "body by slabs of levels whose lists fit --list-gb of library workspace (no lists on the host side)")
     ap.add_argument("--no-search-in-step", action="store_true",
                     help="build the lists once, outside the timed region (times the loop body alone)")
     ap.add_argument("--ensval", default="iid", choices=["iid", "correlated"],
@@ -57,6 +59,9 @@ def main():
                     help="analyse the domain L levels at a time (the reference's level loop, scale/letkf/letkf_tools.f90:313): "
                          "per step and slab obs_local (column search) for the slab's points, then the loop body -- the local-"
                          "observation lists exist for one slab only (C4-gpu: 10 M points x ~4900 x 20 B do not fit at once)")
+    ap.add_argument("--no-torch-lists", action="store_true",
+                    help="with --lists fused: do not build the local-observation lists in torch either (workloads whose lists do "
+                         "not fit: the fused loop body never needs them; the mean list length is taken from its nobs_out)")
     ap.add_argument("--state-slab", action="store_true",
                     help="with --level-slab: the ensemble state of a slab is copied into a compact slab buffer before its loop body "
                          "and the analysis is written to a slab buffer (the state streamed by level: C5-gpu's first guess + analysis "
@@ -166,7 +171,9 @@ def main():
     slab_mode = args.level_slab > 0
     if slab_mode and (args.lists != "columns" or args.no_search_in_step or world > 1 or args.state_layout != "ref"):
         sys.exit("--level-slab: the column search inside the step, one GPU, the reference's state layout")
-    w = bw.build(args.workload, dev, rank=rank, world=world, ensval_kind=args.ensval, lists=not slab_mode)
+    if args.no_torch_lists and args.lists not in ("fused", "pipeline"):
+        sys.exit("--no-torch-lists goes with --lists fused / pipeline")
+    w = bw.build(args.workload, dev, rank=rank, world=world, ensval_kind=args.ensval, lists=not (slab_mode or args.no_torch_lists))
     k, nv, npts = w["k"], w["nv"], w["npts"]
     bw.relayout_state(w, args.state_layout)
     # the streaming passes either side of the loop: mean into slot k, members -> perturbations
@@ -224,6 +231,10 @@ def main():
     infl = torch.ones(npts * nv, dtype=torch.float64, device=dev) if not slab_mode else None
     status = torch.zeros(npts, dtype=torch.int32, device=dev)
     nsweep = torch.zeros(npts, dtype=torch.int32, device=dev)
+    nobs_fused = torch.zeros(npts, dtype=torch.int32, device=dev) if args.lists in ("fused", "pipeline") else None
+    if args.lists == "pipeline":
+        nij_s = w["cfg"]["nx"] * w["cfg"]["ny"]
+        rig_s, rjg_s = pts_s[0][:nij_s].contiguous(), pts_s[1][:nij_s].contiguous()
     relax = dict(rtps=dict(relax_alpha_spread=0.95), rtpp=dict(relax_alpha=0.7), none=dict())[args.relax]
     nij1 = w["cfg"]["nx"] * w["cfg"]["ny"]                    # points are p = ij + nij1 * lev (gues3d's order)
     zdir = args.warm_runs == "z"
@@ -295,9 +306,13 @@ def main():
         if in_step:
             # the whole das_letkf-equivalent call: obs_local for every point, then the batched loop body
             w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"] = do_search()
-        if args.lists == "fused":
+        if args.lists == "pipeline":
+            ctx.das_columns(k, nv, t_s, nij_s, w["cfg"]["nz"], rig_s, rjg_s, pts_s[2], pts_s[3], ens, w["kld"], w["dep"], infl,
+                            w["gues"], anal, w["sp"], w["sm"], w["sv"], list_bytes=int(args.list_gb * 2 ** 30), nobs_out=nobs_fused,
+                            status=status, nsweep=nsweep, warm_run=args.warm_run, **relax)
+        elif args.lists == "fused":
             ctx.das_points(k, nv, None, None, None, None, ens, w["kld"], w["dep"], infl, w["gues"], anal, w["sp"],
-                           w["sm"], w["sv"], status=status, nsweep=nsweep, fused=(t_s, *pts_s), **warm, **relax)
+                           w["sm"], w["sv"], status=status, nsweep=nsweep, fused=(t_s, *pts_s), nobs_out=nobs_fused, **warm, **relax)
         else:
             ctx.das_points(k, nv, w["obs_off"], w["obs_idx"], w["rdiag"], w["rloc"], ens, w["kld"], w["dep"], infl,
                            w["gues"], anal, w["sp"], w["sm"], w["sv"], status=status, nsweep=nsweep, **warm, **relax)
@@ -335,6 +350,8 @@ def main():
 
     out = None
     rc = 0
+    if args.lists in ("fused", "pipeline"):
+        w["n_mean"], w["n_max"] = float(nobs_fused.double().mean().item()), int(nobs_fused.max().item())
     if slab_mode:
         w["n_mean"] = slab_stat["nnz"] / npts
         p0, p1, off_, idx_, rd_, rl_, gs, as_, ssp, ssm, ssv = slab_stat["last"]
@@ -392,7 +409,7 @@ def main():
                             "(HIP events), ms_per_step also holds obs_local when search_in_step"}
         cpu = cpu_ref = None
         parity = None
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and not args.no_torch_lists:
             cpu, parity = cpu_baseline(w_chk, relax, args.cpu_seconds, args.cpu_threads, anal_chk)
             cpu_ref = cpu_baseline_reference(w_chk, args.cpu_threads, min(args.cpu_seconds, 10.0))
             if parity is not None and not (parity <= 1e-10):

@@ -192,6 +192,9 @@ typedef struct {
                                 one call per class with the class's local lists (its var_local factors enter rloc /
                                 rdiag through letkf_search_tables.varloc); variables outside the mask, their infl and
                                 rtps_infl_out entries are not touched */
+  int64_t infl_sv;           /* stride between the variables of infl and rtps_infl_out: element (p, v) at p + infl_sv*v.
+                                0 = npts (the call covers the whole field work3d(nij1*nlev, nv3d)); a call for a slab of
+                                levels of a larger field passes infl + p0 and the FIELD's nij1*nlev here (ABI 5) */
 } letkf_das_args;
 int letkf_das_points_dev(letkf_ctx *ctx, const letkf_das_args *args);
 
@@ -296,6 +299,21 @@ int letkf_obs_search_columns_dev(letkf_ctx *ctx, const letkf_search_tables *tabl
 int letkf_das_points_fused_dev(letkf_ctx *ctx, const letkf_das_args *args, const letkf_search_tables *tables,
                                const double *ri, const double *rj, const double *rlev, const double *rz,
                                int32_t *nobs_out);
+
+/* (3c) das_letkf's main loop for a whole (sub)domain in ONE call, the local-observation lists never visible to the host:
+ * obs_local for the points p = ij + nij1*lev by the column search (3a), then the loop body (2), slab of levels by slab of
+ * levels -- the reference's level loop, scale/letkf/letkf_tools.f90:313 -- so that the lists of a slab fit `list_bytes` of
+ * library workspace (0 = 8 GiB; 20 B per list entry; a single level that exceeds it still runs, with a larger workspace).
+ * Sequence: one count pass over all levels, a device prefix sum, the level boundaries of the offsets read back (the
+ * call's one synchronisation besides the search's own), then per slab the fill pass and the loop body on the context's
+ * stream.  args: as for letkf_das_points_dev with npts = nij1*nlev; obs_off / obs_idx / rdiag_l / rloc_l are ignored;
+ * trans_out / transm_out / pa_out must be NULL (per-point k x k outputs belong to (2)); warm-start runs go up the columns
+ * of a slab.  This is the list-based route for workloads whose lists do not fit at once (BASELINE configs[3]: 10 M points x
+ * ~4900 entries), any k, any MAX_NOBS_PER_GRID; (3b) is the list-free one for k <= 62 without a limit.
+ * nobs_out: dev [npts] or NULL, receives nobsl of every point. */
+int letkf_das_columns_dev(letkf_ctx *ctx, const letkf_das_args *args, const letkf_search_tables *tables, int64_t nij1,
+                          int32_t nlev, const double *rig, const double *rjg, const double *rlev, const double *rz,
+                          int64_t list_bytes, int32_t *nobs_out);
 
 /*---------------------------------------------------------------------------
  * (4) The steps either side of the loop, all pure-bandwidth kernels:

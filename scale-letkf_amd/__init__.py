@@ -55,7 +55,7 @@ class DasArgs(C.Structure):
                 ("anal", C.c_void_p), ("sp", C.c_int64), ("sm", C.c_int64), ("sv", C.c_int64),
                 ("trans_out", C.c_void_p), ("transm_out", C.c_void_p), ("pa_out", C.c_void_p),
                 ("status", C.c_void_p), ("nsweep", C.c_void_p), ("rtps_infl_out", C.c_void_p),
-                ("warm_run", C.c_int32), ("var_mask", C.c_uint32)]
+                ("warm_run", C.c_int32), ("var_mask", C.c_uint32), ("infl_sv", C.c_int64)]
 
 
 class SearchTables(C.Structure):
@@ -131,7 +131,7 @@ class BetaParams(C.Structure):
 
 EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", "letkf_ctx_destroy",
            "letkf_ctx_set_stream", "letkf_ctx_set_option", "letkf_ctx_synchronize", "letkf_core_c", "letkf_core_batch_dev",
-           "letkf_das_points_dev", "letkf_das_points_fused_dev", "letkf_obs_search_dev", "letkf_obs_search_columns_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
+           "letkf_das_points_dev", "letkf_das_points_fused_dev", "letkf_das_columns_dev", "letkf_obs_search_dev", "letkf_obs_search_columns_dev", "letkf_ens_to_perturbations_dev", "letkf_ens_mean_dev",
            "letkf_state_trans_dev", "letkf_member_points_dev", "letkf_ens_spread_dev",
            "letkf_obs_departure_dev", "letkf_obs_mesh_sort_dev", "letkf_obs_halo_plan_dev",
            "letkf_obs_gather_rows_dev", "letkf_obs_gather_i32_dev", "letkf_monit_dep_dev",
@@ -235,7 +235,7 @@ class Context:
                    beta=None, det_run=False, infl_adaptive=False, relax_to_inflated_prior=False, relax_alpha=0.0,
                    relax_alpha_spread=0.0, q_update_top=0.0, q_sprd_max=0.0, iv_p=4, iv_q_first=5, iv_q_last=10,
                    trans_out=None, transm_out=None, pa_out=None, status=None, nsweep=None, rtps_infl_out=None,
-                   warm_run=0, var_mask=0, fused=None, nobs_out=None, warm_stride=0):
+                   warm_run=0, var_mask=0, fused=None, nobs_out=None, warm_stride=0, infl_sv=0):
         """fused = (tables, ri, rj, rlev, rz): obs_local fused into the kernel (obs_off .. rloc_l may be None)"""
         a = DasArgs()
         a.k, a.nv, a.det_run, a.infl_adaptive = k, nv, int(bool(det_run)), int(bool(infl_adaptive))
@@ -253,12 +253,34 @@ class Context:
         a.warm_run = int(warm_run)
         a.warm_stride = int(warm_stride)
         a.var_mask = int(var_mask)
+        a.infl_sv = int(infl_sv)
         if fused is None:
             self._check(self._l.letkf_das_points_dev(self._c, C.byref(a)))
         else:
             t, ri, rj, rlev, rz = fused
             self._check(self._l.letkf_das_points_fused_dev(self._c, C.byref(a), C.byref(t), _ptr(ri), _ptr(rj),
                                                            _ptr(rlev), _ptr(rz), _ptr(nobs_out)))
+
+    def das_columns(self, k, nv, tables, nij1, nlev, rig, rjg, rlev, rz, ensval, kld, dep, infl, gues, anal, sp, sm, sv,
+                    list_bytes=0, nobs_out=None, beta=None, det_run=False, infl_adaptive=False, relax_to_inflated_prior=False,
+                    relax_alpha=0.0, relax_alpha_spread=0.0, q_update_top=0.0, q_sprd_max=0.0, iv_p=4, iv_q_first=5,
+                    iv_q_last=10, status=None, nsweep=None, rtps_infl_out=None, warm_run=0, var_mask=0, infl_sv=0):
+        """letkf_das_columns_dev: column search + loop body for the points p = ij + nij1*lev, by slabs of levels whose
+        lists fit list_bytes of library workspace."""
+        a = DasArgs()
+        a.k, a.nv, a.det_run, a.infl_adaptive = k, nv, int(bool(det_run)), int(bool(infl_adaptive))
+        a.relax_to_inflated_prior = int(bool(relax_to_inflated_prior))
+        a.iv_p, a.iv_q_first, a.iv_q_last = iv_p, iv_q_first, iv_q_last
+        a.relax_alpha, a.relax_alpha_spread = relax_alpha, relax_alpha_spread
+        a.q_update_top, a.q_sprd_max = q_update_top, q_sprd_max
+        a.npts = nij1 * nlev
+        a.ensval, a.kld, a.dep, a.beta, a.infl = _ptr(ensval), kld, _ptr(dep), _ptr(beta), _ptr(infl)
+        a.gues, a.anal, a.sp, a.sm, a.sv = _ptr(gues), _ptr(anal), sp, sm, sv
+        a.status, a.nsweep, a.rtps_infl_out = _ptr(status), _ptr(nsweep), _ptr(rtps_infl_out)
+        a.warm_run, a.var_mask, a.infl_sv = int(warm_run), int(var_mask), int(infl_sv)
+        self._check(self._l.letkf_das_columns_dev(self._c, C.byref(a), C.byref(tables), C.c_int64(nij1), C.c_int32(nlev),
+                                                  _ptr(rig), _ptr(rjg), _ptr(rlev), _ptr(rz), C.c_int64(list_bytes),
+                                                  _ptr(nobs_out)))
 
     # ---- (3) obs_local on the device: two-phase CSR build (count, scan, fill)
     def obs_search(self, tables, ri, rj, rlev, rz):

@@ -7,6 +7,8 @@
 // returns LETKF_E_NO_DEVICE.
 
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
 #include <cstdio>
@@ -50,6 +52,8 @@ struct letkf_ctx {
   size_t warm_ws_bytes = 0;
   char* scratch = nullptr;    // staging for the host-pointer entry
   size_t scratch_bytes = 0;
+  char* list_ws = nullptr;    // letkf_das_columns_dev: the local-observation lists of one slab of levels
+  size_t list_ws_bytes = 0;
   char* staged_ws = nullptr;  // staged path: per-point slabs of a batch + meta / info words
   size_t staged_ws_bytes = 0;
   std::string last_path;      // kernels the last loop-body / letkf_core launch went through (bench.py reports it)
@@ -414,6 +418,7 @@ int letkf_ctx_destroy(letkf_ctx* c) {
     if (c->sched) (void)hipFree(c->sched);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->staged_ws) (void)hipFree(c->staged_ws);
+    if (c->list_ws) (void)hipFree(c->list_ws);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   }
   delete c;
@@ -568,6 +573,7 @@ int das_points_impl(letkf_ctx* c, const letkf_das_args* g, const letkf_search_ta
   a.q_sprd_max = g->q_sprd_max;
   a.beta = g->beta;
   a.infl = g->infl;
+  a.infl_sv = g->infl_sv > 0 ? g->infl_sv : g->npts;
   a.gues = g->gues;
   a.anal = g->anal;
   a.sp = g->sp;
@@ -614,6 +620,85 @@ int letkf_das_points_fused_dev(letkf_ctx* c, const letkf_das_args* g, const letk
                                const double* rj, const double* rlev, const double* rz, int32_t* nobs_out) {
   if (!t) return fail(LETKF_E_INVALID, "tables is NULL");
   return das_points_impl(c, g, t, ri, rj, rlev, rz, nobs_out);
+}
+
+// (3c) das_letkf's main loop for a whole subdomain: column search + loop body by slabs of levels whose lists fit a
+// workspace of the library (scale/letkf/letkf_tools.f90:313, the level loop)
+int letkf_das_columns_dev(letkf_ctx* c, const letkf_das_args* g, const letkf_search_tables* t, int64_t nij1, int32_t nlev,
+                          const double* rig, const double* rjg, const double* rlev, const double* rz, int64_t list_bytes,
+                          int32_t* nobs_out) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!g || !t) return fail(LETKF_E_INVALID, "args / tables is NULL");
+  if (nij1 < 1 || nlev < 1 || g->npts != nij1 * (int64_t)nlev) return fail(LETKF_E_INVALID, "npts must be nij1 * nlev");
+  if (!rig || !rjg || !rlev || !rz) return fail(LETKF_E_INVALID, "a point coordinate array is NULL");
+  if (g->trans_out || g->transm_out || g->pa_out) return fail(LETKF_E_INVALID, "per-point k x k / w-bar outputs: use letkf_das_points_dev");
+  const int64_t npts = g->npts;
+  if (list_bytes <= 0) list_bytes = (int64_t)8 << 30;
+  // workspace: counts [npts] int32 | obs_off [npts + 1] int64 | scan scratch
+  size_t scan_bytes = 0;
+  {
+    auto in = rocprim::make_transform_iterator(static_cast<const int32_t*>(nullptr), [] __device__(int32_t v) { return (int64_t)v; });
+    HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, in, static_cast<int64_t*>(nullptr), (int64_t)0, (size_t)npts + 1,
+                                    rocprim::plus<int64_t>(), c->stream));
+  }
+  const size_t off_counts = 0, off_off = ((size_t)(npts + 1) * 4 + 255) & ~(size_t)255;
+  const size_t off_scan = off_off + (((size_t)(npts + 1) * 8 + 255) & ~(size_t)255);
+  if (off_scan + scan_bytes > c->scratch_bytes) HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc = ensure_bytes(c, &c->scratch, &c->scratch_bytes, off_scan + scan_bytes + 256)) return rc;
+  int32_t* counts = reinterpret_cast<int32_t*>(c->scratch + off_counts);
+  int64_t* off = reinterpret_cast<int64_t*>(c->scratch + off_off);
+  // ---- count pass over all levels, prefix sum, level boundaries back to the host
+  HIP_TRY(hipMemsetAsync(counts + npts, 0, 4, c->stream));   // (the scan runs over npts + 1 entries: the last one is the total)
+  if (int rc = letkf_obs_search_columns_dev(c, t, nij1, nlev, rig, rjg, rlev, rz, 0, counts, nullptr, nullptr, nullptr, nullptr,
+                                            nullptr, nullptr))
+    return rc;
+  {
+    auto in = rocprim::make_transform_iterator(static_cast<const int32_t*>(counts), [] __device__(int32_t v) { return (int64_t)v; });
+    HIP_TRY(rocprim::exclusive_scan(c->scratch + off_scan, scan_bytes, in, off, (int64_t)0, (size_t)npts + 1,
+                                    rocprim::plus<int64_t>(), c->stream));
+  }
+  if (nobs_out) HIP_TRY(hipMemcpyAsync(nobs_out, counts, (size_t)npts * 4, hipMemcpyDeviceToDevice, c->stream));
+  std::vector<int64_t> lev_off((size_t)nlev + 1);
+  HIP_TRY(hipMemcpy2DAsync(lev_off.data(), 8, off, (size_t)nij1 * 8, 8, (size_t)nlev + 1, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  // ---- slabs of levels: as many as fit the list workspace (20 B per entry), at least one
+  int l0 = 0;
+  while (l0 < nlev) {
+    int l1 = l0 + 1;
+    while (l1 < nlev && (lev_off[l1 + 1] - lev_off[l0]) * 20 <= list_bytes) ++l1;
+    const int64_t nnz = lev_off[l1] - lev_off[l0], p0 = (int64_t)l0 * nij1, np = (int64_t)(l1 - l0) * nij1;
+    const size_t n1 = (size_t)(nnz > 0 ? nnz : 1);
+    const size_t o_rd = (n1 * 4 + 255) & ~(size_t)255, o_rl = o_rd + ((n1 * 8 + 255) & ~(size_t)255);
+    const size_t need = o_rl + n1 * 8 + 256;
+    if (need > c->list_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));   // (the previous slab's solve may still read the old buffer)
+    if (int rc = ensure_bytes(c, &c->list_ws, &c->list_ws_bytes, need)) return rc;
+    // the kernels address list entry e of point p as base[obs_off[p] + j] with the GLOBAL offsets: shift the bases
+    int32_t* idx = reinterpret_cast<int32_t*>(c->list_ws) - lev_off[l0];
+    double* rd = reinterpret_cast<double*>(c->list_ws + o_rd) - lev_off[l0];
+    double* rl = reinterpret_cast<double*>(c->list_ws + o_rl) - lev_off[l0];
+    if (int rc = letkf_obs_search_columns_dev(c, t, nij1, l1 - l0, rig, rjg, rlev + p0, rz + p0, 1, nullptr, off + p0, idx, rd, rl,
+                                              nullptr, nullptr))
+      return rc;
+    letkf_das_args a = *g;
+    a.npts = np;
+    a.obs_off = off + p0;
+    a.obs_idx = idx;
+    a.rdiag_l = rd;
+    a.rloc_l = rl;
+    a.gues = g->gues + p0 * g->sp;
+    a.anal = g->anal + p0 * g->sp;
+    if (g->beta) a.beta = g->beta + p0;
+    a.infl = g->infl + p0;
+    a.infl_sv = g->infl_sv > 0 ? g->infl_sv : npts;
+    if (g->status) a.status = g->status + p0;
+    if (g->nsweep) a.nsweep = g->nsweep + p0;
+    if (g->rtps_infl_out) a.rtps_infl_out = g->rtps_infl_out + p0;
+    a.warm_stride = (l1 - l0 > 1) ? (int32_t)nij1 : 0;      // runs up the columns of the slab
+    if (nij1 > 0x7fffffff) a.warm_stride = 0;
+    if (int rc = das_points_impl(c, &a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc;
+    l0 = l1;
+  }
+  return LETKF_OK;
 }
 
 int letkf_ens_to_perturbations_dev(letkf_ctx* c, int32_t k, int32_t nv, int64_t npts, double* x, int64_t sp,

@@ -54,6 +54,7 @@ struct PointArgs {
   // state
   const double* beta;
   double* infl;
+  long infl_sv;        // stride between the variables of infl / rtps_out (npts, or the whole field's size for a slab call)
   const double* gues;
   double* anal;
   long sp, sm, sv;

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
       if (A.q_update_top > 0.0) qskip = A.gues[pt * A.sp + k * A.sm + A.iv_p * A.sv] < A.q_update_top;
       int v0 = 0;
       while (v0 < A.nv && (!((A.var_mask >> v0) & 1u) || (qskip && v0 >= A.iv_q_first && v0 <= A.iv_q_last))) ++v0;
-      infl_old = v0 < A.nv ? A.infl[pt + A.npts * (long)v0] : 1.0;
+      infl_old = v0 < A.nv ? A.infl[pt + A.infl_sv * (long)v0] : 1.0;
     }
     const double shift = km1 / infl_old;              // common_letkf.f90:140-143
     const bool dual = n < k;

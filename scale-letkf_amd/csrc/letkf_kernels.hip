@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(BIG ? 768 : 256) letkf_point_kernel(const Poin
           if ((A.var_mask >> v) & 1u) a0[(k + 1) * A.sm + v * A.sv] = g0[(k + 1) * A.sm + v * A.sv];
       if (A.rtps_out)
         for (int v = tid; v < nv; v += nthr)
-          if ((A.var_mask >> v) & 1u) A.rtps_out[pt + A.npts * (long)v] = 1.0;
+          if ((A.var_mask >> v) & 1u) A.rtps_out[pt + A.infl_sv * (long)v] = 1.0;
       if (tid == 0) {
         if (A.status) A.status[pt] = 0;
         if (A.nsweep) A.nsweep[pt] = 0;
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(BIG ? 768 : 256) letkf_point_kernel(const Poin
     int v0 = 0;                                  // first variable of this class that is actually updated
     while (v0 < nv && (!((A.var_mask >> v0) & 1u) || (qskip && v0 >= A.iv_q_first && v0 <= A.iv_q_last))) ++v0;
     double* infl_p = nullptr;
-    if (A.mode == 0) infl_p = (v0 < nv) ? &A.infl[pt + A.npts * (long)v0] : nullptr;
+    if (A.mode == 0) infl_p = (v0 < nv) ? &A.infl[pt + A.infl_sv * (long)v0] : nullptr;
     else infl_p = &A.infl[pt];
     const double infl_old = infl_p ? *infl_p : 1.0;
 
@@ -750,7 +750,7 @@ __global__ void __launch_bounds__(BIG ? 768 : 256) letkf_point_kernel(const Poin
     if (A.mode == 0) {
       // RTPS needs var_g = |x'|^2 and var_a = x'^T Pa x' = sum_j U_jv^2 / lam_j (letkf_tools.f90:1982-1989)
       for (int v = tid; v < nv; v += nthr) {
-        const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391
+        const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.infl_sv * (long)v] : 1.0;   // :387-391
         double cf = 1.0, cd = 0.0;
         if (A.relax_alpha != 0.0) {              // RTPP :1960-1963
           cf = 1.0 - A.relax_alpha;
@@ -766,7 +766,7 @@ __global__ void __launch_bounds__(BIG ? 768 : 256) letkf_point_kernel(const Poin
         cdiag[v] = cd;
         if (A.rtps_out && ((A.var_mask >> v) & 1u)) {   // work3da (letkf_tools.f90:460-462)
           const bool skipv = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
-          A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cf : 1.0;
+          A.rtps_out[pt + A.infl_sv * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cf : 1.0;
         }
       }
     }
@@ -842,7 +842,7 @@ __global__ void __launch_bounds__(BIG ? 768 : 256) letkf_point_kernel(const Poin
       if (A.infl_adaptive) {                     // :396-398: every updated variable of the class gets its first slot's value
         for (int v = tid; v < nv; v += nthr) {
           const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
-          if (!skip && ((A.var_mask >> v) & 1u)) A.infl[pt + A.npts * (long)v] = infl_new;
+          if (!skip && ((A.var_mask >> v) & 1u)) A.infl[pt + A.infl_sv * (long)v] = infl_new;
         }
       }
     } else if (A.infl_adaptive && n > 0 && tid == 0) {

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(kGBlock) letkf_stage_gram_kernel(const StagedA
       if (A.q_update_top > 0.0) qskip = A.gues[pt * A.sp + k * A.sm + A.iv_p * A.sv] < A.q_update_top;
       int v0 = 0;
       while (v0 < A.nv && (!((A.var_mask >> v0) & 1u) || (qskip && v0 >= A.iv_q_first && v0 <= A.iv_q_last))) ++v0;
-      infl_old = v0 < A.nv ? A.infl[pt + A.npts * (long)v0] : 1.0;
+      infl_old = v0 < A.nv ? A.infl[pt + A.infl_sv * (long)v0] : 1.0;
     } else {
       infl_old = A.infl[pt];
     }
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
       for (int v = tid; v < nv; v += nthr)
         if ((A.var_mask >> v) & 1u) {
           if (A.det_run) a0[(k + 1) * A.sm + v * A.sv] = g0[(k + 1) * A.sm + v * A.sv];
-          if (A.rtps_out) A.rtps_out[pt + A.npts * (long)v] = 1.0;
+          if (A.rtps_out) A.rtps_out[pt + A.infl_sv * (long)v] = 1.0;
         }
       if (tid == 0) {
         if (A.status) A.status[pt] = 0;
@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     // ---------------- relaxation scalars per variable (letkf_tools.f90:457-469, :1953-2002)
     if (das)
       for (int v = tid; v < nv; v += nthr) {
-        const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391
+        const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.infl_sv * (long)v] : 1.0;   // :387-391
         double cf = 1.0, cd = 0.0;
         if (A.relax_alpha != 0.0) {                    // RTPP
           cf = 1.0 - A.relax_alpha;
@@ -767,8 +767,8 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
         if ((A.var_mask >> v) & 1u) {
           if (A.det_run) a0[(k + 1) * A.sm + v * A.sv] = skip ? xdet[v] : xdet[v] + sdotd[v] * beta;   // :489-497
           if (A.rtps_out)
-            A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skip) ? cfac[v] : 1.0;
-          if (A.infl_adaptive && !skip) A.infl[pt + A.npts * (long)v] = infl_new;   // :396-398
+            A.rtps_out[pt + A.infl_sv * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skip) ? cfac[v] : 1.0;
+          if (A.infl_adaptive && !skip) A.infl[pt + A.infl_sv * (long)v] = infl_new;   // :396-398
         }
       }
       if (clampq) {                                    // :500-513, variable iv3d_q only

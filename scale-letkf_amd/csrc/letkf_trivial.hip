@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) letkf_trivial_points_kernel(const PointAr
           if (m0 + u < k) av[(m0 + u) * sm] = xm + x[u];
       }
       if (A.det_run) av[(k + 1) * sm] = gv[(k + 1) * sm];
-      if (A.rtps_out) A.rtps_out[pt + A.npts * (long)v] = 1.0;
+      if (A.rtps_out) A.rtps_out[pt + A.infl_sv * (long)v] = 1.0;
     }
     if (v == 0) {
       if (A.status) A.status[pt] = 0;
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) letkf_trivial_points_kernel(const PointAr
   // first variable of the class that is updated: its inflation slot is the point's rho (letkf_tools.f90:387-418)
   int v0 = 0;
   while (v0 < nv && (!((A.var_mask >> v0) & 1u) || (qskip && v0 >= A.iv_q_first && v0 <= A.iv_q_last))) ++v0;
-  const double infl_old = v0 < nv ? A.infl[pt + A.npts * (long)v0] : 1.0;
+  const double infl_old = v0 < nv ? A.infl[pt + A.infl_sv * (long)v0] : 1.0;
   const double lam = km1 / infl_old;                   // every eigenvalue of A = (k-1)/rho I
   const double sc1 = sqrt(km1 / lam);                  // T = sqrt(rho) I
   const double sc2 = 1.0 / lam;                        // Pa = rho/(k-1) I
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) letkf_trivial_points_kernel(const PointAr
 
   const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
   const double xm = gv[k * sm];
-  const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391, read before the update below
+  const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.infl_sv * (long)v] : 1.0;   // :387-391, read before the update below
   double cfv = 1.0;
   if (A.relax_alpha != 0.0) {                          // RTPP (:1953-1966)
     cfv = 1.0 - A.relax_alpha;
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) letkf_trivial_points_kernel(const PointAr
       cfv = A.relax_alpha_spread * sqrt(var_g * parm / (var_a * km1)) - A.relax_alpha_spread + 1.0;
   }
   if (A.rtps_out)
-    A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skip) ? cfv : 1.0;
+    A.rtps_out[pt + A.infl_sv * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skip) ? cfv : 1.0;
   const double cdv = (!skip && A.relax_alpha != 0.0) ? A.relax_alpha * sqrt(parm) : 0.0;
   // one member's analysis value (letkf_tools.f90:472-487 with w-bar = 0)
   auto value = [&](const double x) { return skip ? xm + x : xm + beta * (cfv * (sc1 * x) + cdv * x) + (1.0 - beta) * x; };
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) letkf_trivial_points_kernel(const PointAr
   if (A.det_run) av[(k + 1) * sm] = gv[(k + 1) * sm];   // :489-497 with w-bar_det = 0
   // :396-398: the class copies its first slot (no observation: the value is unchanged); every parm of this point was
   // read by the thread that writes it
-  if (A.infl_adaptive && !skip) A.infl[pt + A.npts * (long)v] = infl_old;
+  if (A.infl_adaptive && !skip) A.infl[pt + A.infl_sv * (long)v] = infl_old;
 }
 
 // which launches may hand their trivial points to this pass: the list-driven loop body without per-point matrix outputs

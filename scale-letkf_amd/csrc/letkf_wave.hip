@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
       }
       const bool mine = lane < nv && ((A.var_mask >> lane) & 1u);
       if (A.det_run && mine) a0[(k + 1) * A.sm + lane * A.sv] = g0[(k + 1) * A.sm + lane * A.sv];
-      if (A.rtps_out && mine) A.rtps_out[pt + A.npts * (long)lane] = 1.0;
+      if (A.rtps_out && mine) A.rtps_out[pt + A.infl_sv * (long)lane] = 1.0;
       if (lane == 0) {
         if (A.status) A.status[pt] = 0;
         if (A.nsweep) A.nsweep[pt] = 0;
@@ -731,7 +731,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
     // first variable of this variable-localisation class that is actually updated: its inflation slot drives the solve
     int v0 = 0;
     while (v0 < nv && (!((A.var_mask >> v0) & 1u) || (qskip && v0 >= A.iv_q_first && v0 <= A.iv_q_last))) ++v0;
-    double* infl_p = das ? ((v0 < nv) ? &A.infl[pt + A.npts * (long)v0] : nullptr) : &A.infl[pt];
+    double* infl_p = das ? ((v0 < nv) ? &A.infl[pt + A.infl_sv * (long)v0] : nullptr) : &A.infl[pt];
     const double infl_old = infl_p ? *infl_p : 1.0;
 
     PROF_MARK(0)
@@ -1272,7 +1272,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
           if (A.relax_alpha != 0.0) {
             cfv = 1.0 - A.relax_alpha;
           } else if (A.relax_alpha_spread != 0.0) {
-            const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391
+            const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.infl_sv * (long)v] : 1.0;   // :387-391
             const double var_g = wave_sum(xv[v] * xv[v]);
             const double var_a = var_g * uniform(sc2);
             if (var_g > 0.0 && var_a > 0.0)
@@ -1281,7 +1281,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
           cf[v] = uniform(cfv);
           if (A.rtps_out && lane == 0 && ((A.var_mask >> v) & 1u)) {
             const bool skipv = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
-            A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cfv : 1.0;
+            A.rtps_out[pt + A.infl_sv * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cfv : 1.0;
           }
         }
       } else {
@@ -1380,12 +1380,12 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
         if (A.relax_alpha != 0.0) {
           cfv = 1.0 - A.relax_alpha;
         } else if (A.relax_alpha_spread != 0.0) {
-          const double parm = (A.relax_to_inflated_prior && isv) ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391
+          const double parm = (A.relax_to_inflated_prior && isv) ? A.infl[pt + A.infl_sv * (long)v] : 1.0;   // :387-391
           if (vg > 0.0 && va > 0.0) cfv = A.relax_alpha_spread * sqrt(vg * parm / (va * km1)) - A.relax_alpha_spread + 1.0;
         }
         if (A.rtps_out && q == 0 && isv && ((A.var_mask >> v) & 1u)) {   // work3da (letkf_tools.f90:460-462); skipped variables keep 1
           const bool skipv = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
-          A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cfv : 1.0;
+          A.rtps_out[pt + A.infl_sv * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cfv : 1.0;
         }
 #pragma unroll
         for (int vv = 0; vv < NV; ++vv) cf[vv] = readlane_d(cfv, 2 + vv);
@@ -1453,7 +1453,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
           if (A.relax_alpha != 0.0) {
             cfv = 1.0 - A.relax_alpha;
           } else if (A.relax_alpha_spread != 0.0) {
-            const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;   // :387-391
+            const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.infl_sv * (long)v] : 1.0;   // :387-391
             const double x = (lane < k) ? bmat[mrow_l * NBP + 2 + v] : 0.0;
             const double var_g = preduce<NW, 0>(x * x, red, rslot);
             const double var_a = preduce<NW, 0>(crow[2 + v] * crow[2 + v] * sc2, red, rslot);
@@ -1463,7 +1463,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
           cf[v] = uniform(cfv);
           if (A.rtps_out && lane == 0 && ((A.var_mask >> v) & 1u)) {   // work3da (letkf_tools.f90:460-462); skipped variables keep 1
             const bool skipv = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
-            A.rtps_out[pt + A.npts * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cfv : 1.0;
+            A.rtps_out[pt + A.infl_sv * (long)v] = (A.relax_alpha == 0.0 && A.relax_alpha_spread != 0.0 && !skipv) ? cfv : 1.0;
           }
         }
       }
@@ -1505,7 +1505,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
         } else {
           double cdv = 0.0;
           if (A.relax_alpha != 0.0) {              // RTPP diagonal term alpha*sqrt(parm), parm read before the update
-            const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.npts * (long)v] : 1.0;
+            const double parm = A.relax_to_inflated_prior ? A.infl[pt + A.infl_sv * (long)v] : 1.0;
             cdv = A.relax_alpha * sqrt(parm);
           }
           const double pert = cf[v] * out[2 + v] + cdv * x;
@@ -1527,7 +1527,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const bool skip = qskip && v >= A.iv_q_first && v <= A.iv_q_last;
-          if (!skip && lane == 0 && ((A.var_mask >> v) & 1u)) A.infl[pt + A.npts * (long)v] = infl_new;
+          if (!skip && lane == 0 && ((A.var_mask >> v) & 1u)) A.infl[pt + A.infl_sv * (long)v] = infl_new;
         }
       }
     } else if (A.infl_adaptive && n > 0 && lane == 0) {

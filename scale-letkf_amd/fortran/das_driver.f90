@@ -75,7 +75,7 @@ PROGRAM das_driver
   a%sp = 1; a%sm = npts; a%sv = INT(npts, c_int64_t)*nens
   a%trans_out = c_null_ptr; a%transm_out = c_null_ptr; a%pa_out = c_null_ptr
   a%status = d_st; a%nsweep = c_null_ptr; a%rtps_infl_out = c_null_ptr
-  a%warm_run = 0; a%var_mask = 0
+  a%warm_run = 0; a%var_mask = 0; a%infl_sv = 0
   CALL chk(letkf_das_points_dev(ctx, a), 'das_points')
   CALL chk(letkf_ctx_synchronize(ctx), 'synchronize')
 

@@ -23,6 +23,7 @@ MODULE letkf_amd_api
     TYPE(c_ptr)        :: trans_out, transm_out, pa_out, status, nsweep, rtps_infl_out
     INTEGER(c_int32_t) :: warm_run
     INTEGER(c_int32_t) :: var_mask
+    INTEGER(c_int64_t) :: infl_sv
   END TYPE letkf_das_args
 
   ! include/letkf_amd.h section 7
@@ -220,6 +221,17 @@ MODULE letkf_amd_api
       TYPE(c_ptr), VALUE :: ctx, ri, rj, rlev, rz, nobs_out
       TYPE(letkf_das_args), INTENT(IN) :: args
       TYPE(letkf_search_tables), INTENT(IN) :: tables
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    ! das_letkf's main loop for a whole subdomain in one call: column search + loop body by slabs of levels (section 3c)
+    FUNCTION letkf_das_columns_dev(ctx, args, tables, nij1, nlev, rig, rjg, rlev, rz, list_bytes, nobs_out) &
+        BIND(C, name='letkf_das_columns_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t, letkf_das_args, letkf_search_tables
+      TYPE(c_ptr), VALUE :: ctx, rig, rjg, rlev, rz, nobs_out
+      TYPE(letkf_das_args), INTENT(IN) :: args
+      TYPE(letkf_search_tables), INTENT(IN) :: tables
+      INTEGER(c_int64_t), VALUE :: nij1, list_bytes
+      INTEGER(c_int32_t), VALUE :: nlev
       INTEGER(c_int) :: rc
     END FUNCTION
     ! ---- section 4: the steps either side of the loop (row f3)

@@ -12,7 +12,7 @@
 !   :237-267  multiplicative-inflation field            letkf_infl_init_dev
 !   :1911-1948 relax_beta for every point               letkf_relax_beta_dev
 !   :313-527  main loop: obs_local + letkf_core + relaxation + transform, per variable-localisation class
-!                                                      letkf_obs_search_columns_dev (count, scan, fill) + letkf_das_points_dev
+!                                                      letkf_das_columns_dev (column search + loop body by slabs of levels)
 !   letkf.f90:207  ensmean_grd on the analysis          letkf_ens_mean_dev
 ! gues3d / anal3d keep the reference's shape and meaning: gues3d(nij1,nlev,nens,nv3d) INOUT (members 1..MEMBER come back
 ! as perturbations, slot mmean = MEMBER+1 holds the mean, mmdet = MEMBER+2 the deterministic member), anal3d OUT.
@@ -52,6 +52,7 @@ MODULE letkf_tools_amd
     INTEGER :: nlong = 0, nlatg = 0           ! global interior size
     REAL(r_size) :: i_org = 0.0d0, j_org = 0.0d0   ! ri - i_org = ril - IHALO - 0.5 of ij_obsgrd_ext (letkf_obs.f90:1221)
     INTEGER :: iv3d_p = 5, iv3d_q = 6, iv3d_qlast = 11   ! 1-based (common_scale.f90:36-51)
+    INTEGER(c_int64_t) :: list_bytes = 0                 ! device workspace for the local-observation lists of a slab of levels (0: 8 GiB)
     REAL(r_size), ALLOCATABLE :: var_local(:, :)          ! (nv3d, 9)
     INTEGER, ALLOCATABLE :: ctype_merge(:, :)             ! (nid_obs, nobtype), > 0 = merge class (:167-178)
   END TYPE letkf_das_nml
@@ -104,12 +105,11 @@ CONTAINS
     INTEGER :: k, mmean, mmdet, n, ic, icl, nclass, ngroup, npts
     INTEGER(c_int32_t), ALLOCATABLE, TARGET :: n2nc(:), n2n(:), group_start(:), group_member(:), vmode(:), elm_u(:), typ(:), &
                                                counts(:), status(:), mx(:), merge32(:, :)
-    INTEGER(c_int64_t), ALLOCATABLE, TARGET :: obs_off(:)
     REAL(r_size), ALLOCATABLE, TARGET :: varloc(:), work3d(:, :, :)
     INTEGER(c_int32_t) :: nclass32, ngroup32
-    INTEGER(c_int64_t) :: nnz, p, sm, sv
+    INTEGER(c_int64_t) :: sm, sv
     INTEGER(c_size_t) :: nb_state
-    TYPE(c_ptr) :: d_gues, d_anal, d_rig, d_rjg, d_hgt, d_beta, d_infl, d_ens, d_val, d_counts, d_off, d_idx, d_rd, d_rl, &
+    TYPE(c_ptr) :: d_gues, d_anal, d_rig, d_rjg, d_hgt, d_beta, d_infl, d_ens, d_val, d_counts, &
                    d_status, d_varloc
     TYPE(c_ptr) :: d_gs, d_gm, d_vm, d_hl, d_vl, d_mx, d_gi, d_gj, d_si, d_sj, d_ei, d_ej, d_aco, d_ace, d_ri, d_rj, d_lev, &
                    d_dat, d_err
@@ -178,9 +178,8 @@ CONTAINS
     d_err = up(c_loc(obs%ob_err), 8_c_size_t*MAX(obs%nobstotal, 1))
     CALL chk(hipMalloc(d_varloc, 8_c_size_t*MAX(obs%nctype, 1)), 'hipMalloc varloc')
     CALL chk(hipMalloc(d_counts, 4_c_size_t*npts), 'hipMalloc counts')
-    CALL chk(hipMalloc(d_off, 8_c_size_t*(npts + 1)), 'hipMalloc obs_off')
     CALL chk(hipMalloc(d_status, 4_c_size_t*npts), 'hipMalloc status')
-    ALLOCATE (counts(npts), obs_off(npts + 1), status(npts))
+    ALLOCATE (counts(npts), status(npts))
 
     ! ---- members -> perturbations (:209-230); the mean already sits in slot mmean (write_ensmean, letkf.f90:176)
     CALL chk(letkf_ens_to_perturbations_dev(ctx, INT(k, c_int32_t), INT(nv3d, c_int32_t), sm, d_gues, 1_c_int64_t, sm, sv), &
@@ -223,10 +222,11 @@ CONTAINS
     a%relax_alpha = nml%relax_alpha; a%relax_alpha_spread = nml%relax_alpha_spread
     a%q_update_top = nml%q_update_top; a%q_sprd_max = nml%q_sprd_max
     a%npts = npts
+    a%obs_off = c_null_ptr; a%obs_idx = c_null_ptr; a%rdiag_l = c_null_ptr; a%rloc_l = c_null_ptr   ! (the lists stay inside the library)
     a%ensval = d_ens; a%kld = obs%nensobs; a%dep = d_val; a%beta = d_beta; a%infl = d_infl
     a%gues = d_gues; a%anal = d_anal; a%sp = 1; a%sm = sm; a%sv = sv
     a%trans_out = c_null_ptr; a%transm_out = c_null_ptr; a%pa_out = c_null_ptr
-    a%status = d_status; a%nsweep = c_null_ptr; a%rtps_infl_out = c_null_ptr; a%warm_run = 0
+    a%status = d_status; a%nsweep = c_null_ptr; a%rtps_infl_out = c_null_ptr; a%warm_run = 0; a%infl_sv = 0
     DO icl = 1, nclass
       mask = 0
       DO n = 1, nv3d
@@ -240,37 +240,22 @@ CONTAINS
         varloc(ic) = nml%var_local(n, obs%uid_varlocal_ctype(ic))
       END DO
       CALL chk(hipMemcpy(d_varloc, c_loc(varloc), 8_c_size_t*MAX(obs%nctype, 1), hipMemcpyHostToDevice), 'upload varloc')
-      ! obs_local, two-phase CSR: count -> scan -> fill.  The pressure of the point is the ensemble mean of iv3d_p (:420)
-      CALL chk(letkf_obs_search_columns_dev(ctx, t, INT(nij1, c_int64_t), INT(nlev, c_int32_t), d_rig, d_rjg, &
-                                            off_ptr(d_gues, (mmean - 1)*sm + (nml%iv3d_p - 1)*sv), d_hgt, 0_c_int32_t, &
-                                            d_counts, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr), &
-               'letkf_obs_search_columns_dev (count)')
-      CALL chk(letkf_ctx_synchronize(ctx), 'synchronize')
-      CALL chk(hipMemcpy(c_loc(counts), d_counts, 4_c_size_t*npts, hipMemcpyDeviceToHost), 'download counts')
-      obs_off(1) = 0
-      DO p = 1, npts
-        obs_off(p + 1) = obs_off(p) + counts(p)
-      END DO
-      nnz = obs_off(npts + 1)
-      IF (icl == 1 .AND. PRESENT(nobs_point)) nobs_point = RESHAPE(counts, (/nij1, nlev/))
-      CALL chk(hipMemcpy(d_off, c_loc(obs_off), 8_c_size_t*(npts + 1), hipMemcpyHostToDevice), 'upload obs_off')
-      CALL chk(hipMalloc(d_idx, 4_c_size_t*MAX(nnz, 1_c_int64_t)), 'hipMalloc obs_idx')
-      CALL chk(hipMalloc(d_rd, 8_c_size_t*MAX(nnz, 1_c_int64_t)), 'hipMalloc rdiag')
-      CALL chk(hipMalloc(d_rl, 8_c_size_t*MAX(nnz, 1_c_int64_t)), 'hipMalloc rloc')
-      CALL chk(letkf_obs_search_columns_dev(ctx, t, INT(nij1, c_int64_t), INT(nlev, c_int32_t), d_rig, d_rjg, &
-                                            off_ptr(d_gues, (mmean - 1)*sm + (nml%iv3d_p - 1)*sv), d_hgt, 1_c_int32_t, &
-                                            c_null_ptr, d_off, d_idx, d_rd, d_rl, c_null_ptr, c_null_ptr), &
-               'letkf_obs_search_columns_dev (fill)')
-      a%obs_off = d_off; a%obs_idx = d_idx; a%rdiag_l = d_rd; a%rloc_l = d_rl
+      ! obs_local for every point + the loop body, by slabs of levels whose lists fit the library's workspace: ONE call
+      ! (letkf_das_columns_dev).  The pressure of a point is the ensemble mean of iv3d_p (:420).
       a%var_mask = MERGE(0_c_int32_t, mask, nclass == 1)
-      CALL chk(letkf_das_points_dev(ctx, a), 'letkf_das_points_dev')
+      CALL chk(letkf_das_columns_dev(ctx, a, t, INT(nij1, c_int64_t), INT(nlev, c_int32_t), d_rig, d_rjg, &
+                                     off_ptr(d_gues, (mmean - 1)*sm + (nml%iv3d_p - 1)*sv), d_hgt, nml%list_bytes, &
+                                     MERGE(d_counts, c_null_ptr, icl == 1)), 'letkf_das_columns_dev')
       CALL chk(letkf_ctx_synchronize(ctx), 'synchronize')
       CALL chk(hipMemcpy(c_loc(status), d_status, 4_c_size_t*npts, hipMemcpyDeviceToHost), 'download status')
       IF (ANY(status /= 0)) THEN                    ! the reference's behaviour: print and STOP 2 (common_mtx.f90:61-64)
         WRITE (6, '(A,I10,A)') '!!! ERROR (mtx_eigen): letkf_das_points_dev reports a non-zero status at', COUNT(status /= 0), ' points'
         STOP 2
       END IF
-      CALL chk(hipFree(d_idx), 'hipFree'); CALL chk(hipFree(d_rd), 'hipFree'); CALL chk(hipFree(d_rl), 'hipFree')
+      IF (icl == 1 .AND. PRESENT(nobs_point)) THEN
+        CALL chk(hipMemcpy(c_loc(counts), d_counts, 4_c_size_t*npts, hipMemcpyDeviceToHost), 'download counts')
+        nobs_point = RESHAPE(counts, (/nij1, nlev/))
+      END IF
     END DO
 
     ! ---- ensmean_grd on the analysis (letkf.f90:207), then everything back to the caller's arrays
@@ -280,7 +265,7 @@ CONTAINS
     CALL chk(hipMemcpy(c_loc(gues3d), d_gues, nb_state, hipMemcpyDeviceToHost), 'download gues3d')
     IF (PRESENT(work3d_out)) CALL chk(hipMemcpy(c_loc(work3d_out), d_infl, 8_c_size_t*npts*nv3d, hipMemcpyDeviceToHost), &
                                       'download work3d')
-    CALL free_all((/d_gues, d_anal, d_rig, d_rjg, d_hgt, d_beta, d_infl, d_ens, d_val, d_counts, d_off, d_status, d_varloc, &
+    CALL free_all((/d_gues, d_anal, d_rig, d_rjg, d_hgt, d_beta, d_infl, d_ens, d_val, d_counts, d_status, d_varloc, &
                     d_gs, d_gm, d_vm, d_hl, d_vl, d_mx, d_gi, d_gj, d_si, d_sj, d_ei, d_ej, d_aco, d_ace, d_ri, d_rj, d_lev, &
                     d_dat, d_err/))
   END SUBROUTINE das_letkf_amd

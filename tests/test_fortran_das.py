@@ -96,8 +96,7 @@ def test_das_letkf_amd_compiles_and_links():
     src = open(os.path.join(FDIR, "letkf_tools_amd.f90")).read()
     assert "SUBROUTINE das_letkf_amd(" in src
     for call in ("letkf_var_local_classes", "letkf_ctype_merge_groups", "letkf_radar_only", "letkf_ens_to_perturbations_dev",
-                 "letkf_infl_init_dev", "letkf_relax_beta_dev", "letkf_obs_search_columns_dev", "letkf_das_points_dev",
-                 "letkf_ens_mean_dev"):
+                 "letkf_infl_init_dev", "letkf_relax_beta_dev", "letkf_das_columns_dev", "letkf_ens_mean_dev"):
         assert call in src, call
 
 

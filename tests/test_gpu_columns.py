@@ -1,0 +1,55 @@
+"""letkf_das_columns_dev (C ABI 3c): das_letkf's main loop for a whole subdomain in one call -- the column search and the loop
+body by slabs of levels whose local-observation lists fit a workspace of the library (the reference's level loop,
+scale/letkf/letkf_tools.f90:313) -- against the two-call route (letkf_obs_search_columns_dev for all levels, then ONE
+letkf_das_points_dev): same local observations at every point, same analysis to rounding (the slabs only change which
+points warm-start from which), the adaptively updated inflation field and the RTPS diagnostic at the right places of the
+WHOLE field (letkf_das_args.infl_sv), for slab sizes from one level to all of them."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,list_mb", [("C2-mini", 0.5), ("C2-mini", 3.0), ("C2-mini", 0), ("C2-mini-k100", 2.0), ("C2-mini-disc", 1.0)])
+def test_column_pipeline_equals_search_plus_loop_body(name, list_mb):
+    import bench_workload as bw
+    from _gpu import ctx, pkg
+    dev = torch.device("cuda:0")
+    w = bw.build(name, dev, det_run=True)
+    k, nv, npts, nens = w["k"], w["nv"], w["npts"], w["nens"]
+    nij1, nlev = w["cfg"]["nx"] * w["cfg"]["ny"], w["cfg"]["nz"]
+    cx = ctx()
+    cx.ens_mean(k, nv, npts, w["gues"], 1, npts, npts * nens)
+    cx.to_perturbations(k, nv, npts, w["gues"], 1, npts, npts * nens)
+    t_s, keep, order, pts = bw.search_tables(w, pkg, dev)
+    ens, dep = w["ensval"][order].contiguous(), w["dep"][order].contiguous()
+    rig, rjg = pts[0][:nij1].contiguous(), pts[1][:nij1].contiguous()
+    sw = dict(det_run=True, infl_adaptive=True, relax_alpha_spread=0.95)
+
+    def fresh():
+        return (torch.full_like(w["gues"], float("nan")), torch.full((npts * nv,), 1.03, dtype=torch.float64, device=dev),
+                torch.full((npts,), -1, dtype=torch.int32, device=dev), torch.zeros(npts * nv, dtype=torch.float64, device=dev))
+    # two calls: all lists, then the loop body
+    a0, i0, s0, r0 = fresh()
+    off, idx, rd, rl = cx.obs_search_columns(t_s, nij1, nlev, rig, rjg, pts[2], pts[3])
+    cx.das_points(k, nv, off, idx, rd, rl, ens, w["kld"], dep, i0, w["gues"], a0, 1, npts, npts * nens, status=s0,
+                  rtps_infl_out=r0, **sw)
+    # one call, lists by slabs inside the library
+    a1, i1, s1, r1 = fresh()
+    nobs = torch.full((npts,), -7, dtype=torch.int32, device=dev)
+    cx.das_columns(k, nv, t_s, nij1, nlev, rig, rjg, pts[2], pts[3], ens, w["kld"], dep, i1, w["gues"], a1, 1, npts, npts * nens,
+                   list_bytes=int(list_mb * 2 ** 20), nobs_out=nobs, status=s1, rtps_infl_out=r1, **sw)
+    torch.cuda.synchronize()
+    assert int(s0.abs().max()) == 0 and int(s1.abs().max()) == 0
+    assert torch.equal(nobs.long(), off[1:] - off[:-1])
+    g0 = a0.view(nv, nens, npts)
+    g1 = a1.view(nv, nens, npts)
+    x = w["gues"].view(nv, nens, npts)
+    members = list(range(k)) + [k + 1]
+    for v in range(nv):
+        scale = float(max(x[v, k].abs().max(), x[v, :k].abs().max()))
+        assert float((g0[v, members] - g1[v, members]).abs().max()) <= 1e-11 * scale, v
+    assert float((i0 - i1).abs().max()) <= 1e-12
+    assert float((r0 - r1).abs().max()) <= 1e-11
+    assert bool(torch.isnan(g1[:, k]).all())              # the mean slot is not the loop body's to write
