@@ -217,3 +217,28 @@ def test_nan_in_the_observation_table_is_reported_not_iterated_away():
         scale = max(np.abs(x[v, k]).max(), np.abs(x[v, :k]).max())
         err = np.abs(a1.reshape(11, nens, npts)[v, :k][:, ~touched] - ref["anal"].reshape(11, nens, npts)[v, :k][:, ~touched]).max()
         assert err <= 1e-10 * scale
+
+
+@pytest.mark.parametrize("k,nv,n_mean", [(8, 3, 5), (8, 14, 30), (20, 7, 12), (33, 5, 50), (50, 13, 120), (62, 1, 40)])
+@pytest.mark.parametrize("name", ["rtps_adaptive_det", "rtpp"])
+def test_small_ensembles_with_another_number_of_variables(name, k, nv, n_mean):
+    """nv != 11 does not have a register-kernel instantiation: such calls take the staged path at any k, i.e. the eigen-free
+    stage on matrices of order 2 .. 62 (one 16-row block per wave, most waves idle) -- tiny orders, n = 1 points, ragged n."""
+    from test_gpu_das import CONFIGS
+    cfg = dict(CONFIGS[name])
+    det = bool(cfg.get("det_run", 0))
+    c = das_case(k=k, nv=nv, npts=40, nobs_tot=300, n_mean=n_mean, seed=6000 + 10 * k + nv, det_run=det, infl0=1.05)
+    ref = oracle(c, k, nv, cfg)
+    a1, i1, s1, w1 = run(c, k, nv, cfg, poly=True)
+    assert (s1 == 0).all(), s1
+    nens, npts = c["nens"], c["npts"]
+    x = c["gues"].reshape(nv, nens, npts)
+    members = list(range(k)) + ([k + 1] if det else [])
+    for v in range(nv):
+        scale = max(np.abs(x[v, k]).max(), np.abs(x[v, :k]).max())
+        err = np.abs(a1.reshape(nv, nens, npts)[v, members] - ref["anal"].reshape(nv, nens, npts)[v, members]).max()
+        assert err <= 1e-10 * scale, (v, err, scale)
+    assert np.abs(i1 - ref["infl"]).max() <= 1e-12
+    n = np.diff(c["obs_off"])
+    solved = (n >= 2) & (c["beta"] != 0.0)
+    assert solved.any() and (w1[solved] < 0).all(), (n[solved], w1[solved])
