@@ -32,6 +32,7 @@
 
 #include "letkf_device.h"
 #include "letkf_jacobi_dev.h"
+#include "letkf_staged_dev.h"
 
 #ifndef EIG_RBR2
 #define EIG_RBR2 50
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(64 * NP * SB, SB == 1 ? 2 : 1) letkf_eig_wg_ke
     const int m = E.meta[2 * it + 1];
     const int solver = E.meta[2 * it] >> 8;              // 1: this kernel
     if (solver != 1 || m < 2 || m > MMAX) continue;     // (uniform for the workgroup)
-    const int ldg = m | 1;
+    const int ldg = staged_dev::staged_ld(m);
     double* __restrict__ G = E.ws + (size_t)it * E.ws_per_point;
     const int ncol = (m + 1) & ~1, S = ncol >> 1;
     const bool hasL = slot > 0 && slot < S, hasR = slot + 1 < S;

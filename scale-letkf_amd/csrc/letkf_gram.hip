@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
       if (tid == 0) sl.SC[0] = sl.SC[1] = sl.SC[2] = 0.0;
       continue;
     }
-    const int ldg = m | 1;
+    const int ldg = staged_ld(m);
     // ---- per-observation scalars: the adaptive-inflation sums; dual: sqrt w, the weighted departures, the row offsets
     {
       double p1 = 0.0, p3 = 0.0;

@@ -30,6 +30,7 @@
 
 #include "letkf_device.h"
 #include "letkf_jacobi_dev.h"
+#include "letkf_staged_dev.h"
 
 namespace letkf {
 
@@ -886,7 +887,7 @@ __global__ void __launch_bounds__(768) letkf_eig_block_kernel(const EigArgs E) {
     double* G = E.ws + (size_t)it * E.ws_per_point;
     int conv = 0;
     __syncthreads();
-    const int sweeps = jacobi_block_mfma(G, m | 1, m, E.max_sweep, smem, conv);
+    const int sweeps = jacobi_block_mfma(G, staged_dev::staged_ld(m), m, E.max_sweep, smem, conv);
     if (threadIdx.x == 0) {
       E.info[2 * it] = sweeps;
       E.info[2 * it + 1] = conv;

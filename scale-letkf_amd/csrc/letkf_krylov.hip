@@ -541,8 +541,12 @@ __global__ void __launch_bounds__(kKBlock, 1) letkf_stage_krylov_kernel(const St
         }
       }
     }
-    const int ldg = m | 1;
+    const int ldg = staged_ld(m);
     if (tid < 16) sl.G[(size_t)m * ldg + tid] = 0.0;         // (read as padding columns of the last rows: must be finite)
+    if (ldg > m + 1) {                                       // rows padded to the alignment: the padding is read against zero rows of the residual block
+      const int npad = ldg - m;
+      for (int e = tid; e < m * npad; e += nthr) sl.G[(size_t)(e / npad) * ldg + m + e % npad] = 0.0;
+    }
     __syncthreads();
     int iters = 0;
     const bool ok = krylov_point<BPW>(sl, L, m, ldg, k, nv, nb, shift, dual, &iters);

@@ -55,7 +55,7 @@ constexpr int kABlock = STAGE_APPLY_BLOCK;
 
 // hist: doubles of the eigen-free stage's residual history (stage_krylov_hist_doubles, 0 = none)
 long staged_ws_per_point(int k, int nv, int kkout, long hist) {
-  const long ldg = k | 1, nb = nv + 2;
+  const long ldg = staged_ld(k), nb = nv + 2;
   long w = (long)(k + 1) * ldg + 2L * k + 16 + (long)nv * k + 4L * nb * k + 2L * nb;
   if (kkout) w += (long)k * ldg;
   w = (w + 15) & ~15L;                                 // (H starts on a 128-byte boundary, slab_of)
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(kGBlock) letkf_stage_gram_kernel(const StagedA
       if (tid == 0) sl.SC[0] = sl.SC[1] = sl.SC[2] = 0.0;
       continue;
     }
-    const int ldg = m | 1;
+    const int ldg = staged_ld(m);
     const int ld = ((m + 3) & ~3) + 4;                // tile row length (output index), b128-aligned rows
     const int T = (m + kGT - 1) / kGT;
     const long ntile = (long)T * (T + 1) / 2;         // tiles (ti <= tj)
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
     }
     const bool dual = mode == 2;
     const bool poly = solver == 3;                     // eigen-free (letkf_krylov.hip has left q and the quadratic forms): sl.G still holds M itself
-    const int ldg = m | 1;
+    const int ldg = staged_ld(m);
     // the workgroup Jacobi pads an odd order with a zero column that ends up anywhere among the stored columns
     const int mc = solver == 1 ? (m + 1) & ~1 : m;
     // P / C [nb][mc] and (dual) q [nb][n] are read as broadcasts in the innermost loops below: in LDS when they fit
@@ -824,12 +824,12 @@ __global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-              if (j0 + u < mc) sl.W[(size_t)(j0 + u) * (k | 1) + mm] = acc[u];
+              if (j0 + u < mc) sl.W[(size_t)(j0 + u) * staged_ld(k) + mm] = acc[u];
           }
         }
         __syncthreads();
         E = sl.W;
-        lde = k | 1;
+        lde = staged_ld(k);
       }
       for (long e = tid; e < (long)k * k; e += nthr) {
         const int c = (int)(e / k), r = (int)(e - (long)c * k);   // column-major, coalesced over r

@@ -23,6 +23,16 @@ typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));   // two dou
 // the points letkf_gram.hip's matrix-core Gram stage takes (loop body with lists): orders up to 512 (32 blocks of 16)
 __host__ __device__ inline bool gram_mfma_takes(int n, int k) { return n >= 1 && (n < k ? n <= 512 : k <= 512); }
 
+// Leading dimension of a point's m x m matrix in its slab (column c at c * staged_ld(m)): rows of 128-byte multiples for the
+// orders whose matrices stream from beyond L2 in the eigen-free stage (A/B r3: C3-slab +2.3 %, C5-slab +1.8 %), m | 1 -- what
+// rounds 1 and 2 used everywhere -- below that (k = 100: the padding to 112 cost 1.3 %).
+#ifndef STAGED_LD_ALIGN
+#define STAGED_LD_ALIGN 16
+#endif
+__host__ __device__ inline int staged_ld(int m) {
+  return (STAGED_LD_ALIGN && m > 128) ? ((m + STAGED_LD_ALIGN - 1) / STAGED_LD_ALIGN) * STAGED_LD_ALIGN : (m | 1);
+}
+
 // Slab of one point of a batch (doubles; ldg = k | 1, nb = nv + 2):
 //   G [(k + 1) ldg] | V0 [k] | V1 [k] | SC [16] | X [nv k] | TT [nb k] | PC [nb (k + 2)] | QQ [nb k] | OUT [nb k] | (W [k ldg]) | (H [hist])
 // H: the residual history of the eigen-free stage (letkf_krylov.hip), lane-private layout.
@@ -30,7 +40,7 @@ struct Slab {
   double *G, *V0, *V1, *SC, *X, *TT, *PC, *QQ, *OUT, *W, *H;
 };
 __device__ __forceinline__ Slab slab_of(double* base, int k, int nv, int kkout) {
-  const int ldg = k | 1, nb = nv + 2;
+  const int ldg = staged_ld(k), nb = nv + 2;
   Slab s;
   s.G = base;
   s.V0 = s.G + (size_t)(k + 1) * ldg;   // one spare column: an odd order is padded with an inert zero column (letkf_eig.hip)
