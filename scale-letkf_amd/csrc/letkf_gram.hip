@@ -52,7 +52,10 @@ struct alignas(16) d2 {
 // held 72 staging registers beside 96 accumulators and spilled the staged loads straight to scratch, i.e. waited for
 // every load in front of the matrix-core phase (found in the ISA: 2.4 ms per 3456 points of C3-slab, no faster than the
 // vector-ALU kernel).
-template <bool DUAL>
+// TC4: the instantiation for the points whose chunks hold 4 double-steps (orders <= 256: up to 17 blocks); the other one takes
+// the larger orders with the generic inner loop -- both in one kernel cost the loops 90-130 spilled registers (the k = 100 loop
+// body 1.60 -> 1.74 M solves/s with the split).
+template <bool DUAL, bool TC4>
 __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(const StagedArgs S) {
   constexpr int kGmTiles = DUAL ? 12 : 8;     // accumulator tiles per wave and pass
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -94,6 +97,10 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
       continue;
     }
     if (n > 0 && !gram_mfma_takes(n, k)) continue;    // letkf_stage_gram_kernel's point (launched behind this kernel)
+    if (n > 0) {                                      // (points without an eigenproblem: the TC4 instantiation's)
+      const int nbx = n < k ? (n + 15) >> 4 : 2 * ((k + 31) >> 5) + 1;
+      if ((kGmPanel / nbx >= 4) != TC4) continue;
+    } else if (!TC4) continue;
     // inflation slot that drives the solve (first updated variable of the class, letkf_tools.f90:387-418)
     double infl_old;
     {
@@ -148,7 +155,7 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
     const int NB = dual ? (m + 15) >> 4 : 2 * ((k + 31) >> 5);   // blocks of 16 output indices
     const int NBX = dual ? NB : NB + 1;                          // + the block column [sqrt(w) dep | sqrt(w) dep_det]
     const int Lc = dual ? k : n;                                 // contraction length
-    int Tc = kGmPanel / NBX;                                     // double-steps per chunk
+    int Tc = TC4 ? 4 : kGmPanel / NBX;                           // double-steps per chunk
     if (Tc > 4) Tc = 4;
     const int nchunk = (Lc + 8 * Tc - 1) / (8 * Tc);
     const int ntri = NB * (NB + 1) / 2, ntile = dual ? ntri : ntri + NB;
@@ -295,25 +302,56 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
         }
         __syncthreads();
         if (ch + 1 < nchunk) issue(ch + 1);           // in flight during the matrix-core phase below
-        int curI = -1;
-        d2 pI[4];
+        if constexpr (TC4) {
+          // the common shape (orders <= 256): no condition on the double-step inside a tile, and TWO tiles side by side -- the
+          // eight instructions of a tile accumulate into one register quad, a dependent chain; two chains interleave
 #pragma unroll
-        for (int ti = 0; ti < kGmTiles; ++ti) {
-          if (ti < ntw) {                             // (wave-uniform)
-            const int I = tI[ti], J = tJ[ti];
-            if (I != curI) {
+          for (int ti = 0; ti < kGmTiles; ti += 2) {
+            if (ti + 1 < ntw) {                       // (wave-uniform)
+              const int I0 = tI[ti], J0 = tJ[ti], I1 = tI[ti + 1], J1 = tJ[ti + 1];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const d2 a0 = panel[(size_t)(I0 * 4 + t) * 64 + lane];
+                const d2 b0 = panel[(size_t)(J0 * 4 + t) * 64 + lane];
+                const d2 a1 = panel[(size_t)(I1 * 4 + t) * 64 + lane];
+                const d2 b1 = panel[(size_t)(J1 * 4 + t) * 64 + lane];
+                acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, acc[ti], 0, 0, 0);
+                acc[ti + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, acc[ti + 1], 0, 0, 0);
+                acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.y, acc[ti], 0, 0, 0);
+                acc[ti + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, acc[ti + 1], 0, 0, 0);
+              }
+            } else if (ti < ntw) {
+              const int I = tI[ti], J = tJ[ti];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const d2 a = panel[(size_t)(I * 4 + t) * 64 + lane];
+                const d2 b = panel[(size_t)(J * 4 + t) * 64 + lane];
+                acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, acc[ti], 0, 0, 0);
+                acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc[ti], 0, 0, 0);
+              }
+            }
+          }
+        } else {
+          int curI = -1;
+          d2 pI[4];
+#pragma unroll
+          for (int ti = 0; ti < kGmTiles; ++ti) {
+            if (ti < ntw) {                           // (wave-uniform)
+              const int I = tI[ti], J = tJ[ti];
+              if (I != curI) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  if (t < Tc) pI[t] = panel[(size_t)(I * Tc + t) * 64 + lane];
+                curI = I;
+              }
 #pragma unroll
               for (int t = 0; t < 4; ++t)
-                if (t < Tc) pI[t] = panel[(size_t)(I * Tc + t) * 64 + lane];
-              curI = I;
+                if (t < Tc) {
+                  const d2 pJ = panel[(size_t)(J * Tc + t) * 64 + lane];
+                  acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pI[t].x, pJ.x, acc[ti], 0, 0, 0);
+                  acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pI[t].y, pJ.y, acc[ti], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              if (t < Tc) {
-                const d2 pJ = panel[(size_t)(J * Tc + t) * 64 + lane];
-                acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pI[t].x, pJ.x, acc[ti], 0, 0, 0);
-                acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pI[t].y, pJ.y, acc[ti], 0, 0, 0);
-              }
           }
         }
       }
@@ -383,8 +421,12 @@ hipError_t launch_stage_gram_mfma(const StagedArgs& s, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)s.nbatch), dim3(kGmBlock), lds, st, s);
     return hipGetLastError();
   };
-  hipError_t e = go(&letkf_stage_gram_mfma_kernel<true>);    // n < k (and every point without an eigenproblem)
-  if (e == hipSuccess) e = go(&letkf_stage_gram_mfma_kernel<false>);
+  hipError_t e = go(&letkf_stage_gram_mfma_kernel<true, true>);    // n < k (and every point without an eigenproblem)
+  if (e == hipSuccess) e = go(&letkf_stage_gram_mfma_kernel<false, true>);
+  if (e == hipSuccess && s.A.k > 256) {                             // orders beyond 17 blocks: chunks of fewer double-steps
+    e = go(&letkf_stage_gram_mfma_kernel<true, false>);
+    if (e == hipSuccess) e = go(&letkf_stage_gram_mfma_kernel<false, false>);
+  }
   return e;
 }
 
