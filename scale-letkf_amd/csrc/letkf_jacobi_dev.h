@@ -149,9 +149,11 @@ __device__ __forceinline__ double slot_sum_nw(double v, double* xs, int& ph) {
 // 1283 instructions of a step pair were v_accvgpr moves.  In place the even step needs one move per row (the old lower
 // element is an operand of both new ones) and the odd step fetches the right neighbour's column twice (inner product,
 // then update) instead of keeping it: +2 instructions per row, no AGPR traffic.
+// stop_tol2: the squared cosine of the stop rule (kStopTol2W; the block Jacobi of letkf_kernels.hip, whose 32 x 32 problems are
+// Gram matrices -- squared condition, a noise floor of eps cond^2 on their cosines -- keeps round 2's 1e-20).
 template <int KR, int NW, int RC = 24, bool EARLY = true, bool INPLACE = false>
 __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const int max_sweep, double* lds,
-                                            int* pairs_out = nullptr, int* conv_out = nullptr) {
+                                            int* pairs_out = nullptr, int* conv_out = nullptr, const double stop_tol2 = kStopTol2W) {
   static_assert(KR % 2 == 0, "row halves");
   constexpr int H = KR / 2;
   static_assert(RC % 2 == 0, "RC rows per conversion chunk: RC * 64 NW doubles of LDS");
@@ -225,7 +227,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           const double ga = slot_sum_nw<NW>(p0 + p1, lds, ph) * (isA * isB);
           const double a = alA, b = alB;
           const double g2 = ga * ga, ab = a * b;
-          notconv |= g2 > kStopTol2W * ab;
+          notconv |= g2 > stop_tol2 * ab;
           const bool rot = g2 > kRotTol2W * ab;
           const double d = b - a;
           const double x = fma(d, d, 4.0 * g2);
@@ -303,7 +305,7 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           const double ga = slot_sum_nw<NW>(p0 + p1, lds, ph) * (isB * isAr);
           const double a = alB, b = alAr;
           const double g2 = ga * ga, ab = a * b;
-          notconv |= hasR && g2 > kStopTol2W * ab;
+          notconv |= hasR && g2 > stop_tol2 * ab;
           const bool rot = hasR && g2 > kRotTol2W * ab;
           const double d = b - a;
           const double x = fma(d, d, 4.0 * g2);

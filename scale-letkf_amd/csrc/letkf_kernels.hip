@@ -338,7 +338,9 @@ __device__ __forceinline__ int jacobi_block_mfma(double* __restrict__ G, const i
         }
         // ---- 2. eigenvectors of B
         int inpairs = 0;
-        const int insw = jacobi_dev::jacobi_split<32, 1, 8, false>(g, 32, 30, scr, &inpairs);
+        // (stop rule 1e-10: this inner problem is a Gram matrix, its cosines carry eps cond(A)^2 of noise -- with the 1e-12 of
+        // the point kernels the outer iteration stopped converging at cond(A) ~ 1e2 instead of ~ 1e3, tools/r3_probe_block_jacobi.py)
+        const int insw = jacobi_dev::jacobi_split<32, 1, 8, false>(g, 32, 30, scr, &inpairs, nullptr, 1e-20);
         if (insw > 1) notconv = 1;
         // The inner solver swaps the two columns of a pair after every rotation, unconditionally: after T steps the
         // column order is a fixed permutation (odd-even transposition: reversal after 32 steps, identity after 64).
