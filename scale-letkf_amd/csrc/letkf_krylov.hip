@@ -180,8 +180,21 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
     const int row = (wv + bi * nwv) * 16 + col;
     abase[bi] = sl.G + (size_t)(row < n ? row : n - 1) * ldg + 2 * rq;
   }
+#ifdef KRYLOV_TIMING_SKIP   // A/B twin, timing only (results invalid): the first steps' operands come from nowhere
+  const int TS = T > KRYLOV_TIMING_SKIP ? KRYLOV_TIMING_SKIP : 0;
+  const double* abase_[BPW];
+#pragma unroll
+  for (int bi = 0; bi < BPW; ++bi) abase_[bi] = abase[bi] + 8 * TS;
+#define KRY_ABASE abase_
+#define KRY_T (T - TS)
+#define KRY_B (L.rbuf + (size_t)8 * TS * 16)
+#else
+#define KRY_ABASE abase
+#define KRY_T T
+#define KRY_B L.rbuf
+#endif
   d2u ring[PF][BPW];
-  ring_fill<BPW, PF>(ring, abase, 1 << 30, T);
+  ring_fill<BPW, PF>(ring, KRY_ABASE, 1 << 30, KRY_T);
   double rho_old = 1.0, alpha_old = 1.0, tn2 = 0.0;
   bool frozen = false, failed = false;
   int mj = 0, j = 0;
@@ -197,13 +210,32 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
     }
     const bool all_frozen = __ballot(frozen) == ~0ull;
     const bool any_failed = __ballot(failed) != 0ull;
+#ifdef KRYLOV_TIMING_SKIP
+    frozen = failed = false;
+    if (j == 14) break;                                     // (timing twin: a fixed number of iterations)
+#else
     if (all_frozen || any_failed || j == kMmax) break;      // (the same in every wave: all read the same sums)
+#endif
 
     // ---- w = M r_j
     d4 acc[BPW];
 #pragma unroll
     for (int bi = 0; bi < BPW; ++bi) acc[bi] = (d4){0.0, 0.0, 0.0, 0.0};
-    if (nact > 0) ring_product<BPW, PF>(nact, ring, abase, 1 << 30, T, true, L.rbuf, lane, acc);
+#ifdef KRYLOV_TIMING_SKIP
+    if (nact > 0) {
+      for (int t = 0; t < TS; ++t) {
+        const double b0 = L.rbuf[(size_t)(8 * t) * 16 + lane], b1 = L.rbuf[(size_t)(8 * t + 4) * 16 + lane];
+#pragma unroll
+        for (int bi = 0; bi < BPW; ++bi)
+          if (bi < nact) {
+            const d2u a = *reinterpret_cast<const d2u*>(L.fT + ((size_t)(bi * 16 + (t & 15)) * 64 + lane) * 2);   // (any LDS words: 16 B per lane)
+            acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0, acc[bi], 0, 0, 0);
+            acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b1, acc[bi], 0, 0, 0);
+          }
+      }
+    }
+#endif
+    if (nact > 0) ring_product<BPW, PF>(nact, ring, KRY_ABASE, 1 << 30, KRY_T, true, KRY_B, lane, acc);
     // ---- r_j to the history (lane-private; issued here, behind the product's loads, so that the next product's first
     // wait does not sit on these stores), mu = r . w per column
     double wreg[BPW][4];
@@ -268,7 +300,11 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
   }
   const int iters = j;
   *iters_out = iters;
+#ifndef KRYLOV_TIMING_SKIP
   if (__ballot(failed) != 0ull || !(__ballot(frozen) == ~0ull)) return false;
+#else
+  mj = iters;
+#endif
 
   // ================= g_T(T_m) e_1 for the columns b >= 2, m_b = mj rows each
   // (a) the tridiagonals: wave w takes the columns 2 + w and 2 + w + 8; lane l holds rows 2l and 2l + 1
