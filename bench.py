@@ -79,6 +79,9 @@ def main():
                     help="N > 1: the obs all-gather through torch.distributed (default) or through the library's own "
                          "letkf_obs_allgatherv_dev on an RCCL communicator this script creates (ncclCommInitRank); "
                          "halo (--scaling strong only): pairwise sends of just the rows each extended subdomain holds")
+    ap.add_argument("--eigen-stage-only", action="store_true",
+                    help="measurement of the fallback: LETKF_OPT_STAGED_POLY = 0, every staged point through the eigen stage "
+                         "(workgroup Jacobi at orders <= 208, block Jacobi above) instead of the eigen-free route")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(affinity, cgroup quota, 16 = the box's CPU share)")
     args = ap.parse_args()
 
@@ -132,6 +135,8 @@ def main():
         dist.barrier()
     stream = torch.cuda.current_stream()
     ctx = pkg.Context(local_rank, stream.cuda_stream)
+    if args.eigen_stage_only:
+        ctx.set_option(ctx.OPT_STAGED_POLY, 0)
 
     if args.scaling == "strong":
         import bench_tiles
@@ -422,6 +427,7 @@ def main():
                                       f"k={k} members, nv={nv}, mean {n_mean:.1f} (max {w['n_max']}) local obs/point, "
                                       f"relax={args.relax}, ensval={args.ensval}, obs-space spread {obs_spread:.2f} obs errors" + (", state member-fastest" if args.state_layout == "member" else "")
                                       + (f", MAX_NOBS_PER_GRID={args.max_nobs} x 2 ctypes" if args.max_nobs else "")
+                                      + (", eigen stage only (LETKF_OPT_STAGED_POLY = 0)" if args.eigen_stage_only else "")
                                       + (f"; analysed in slabs of {args.level_slab} level(s): obs_local + loop body per slab"
                                          + (", state streamed per slab" if args.state_slab else "") if slab_mode else ""),
                           "points_per_gpu": npts, "obs_table_rows": int(w["ensval"].shape[0]),

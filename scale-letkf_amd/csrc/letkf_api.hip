@@ -130,8 +130,8 @@ int make_plan(const letkf_ctx* c, int k, int nv, long npts, Plan* p) {
   long tn = fixed < budget ? (long)((budget - fixed) / (p->ldy + 3)) : 0;
   if (tn > 32) tn = 32;
   if (tn < 4) tn = 4;
-  // the obs tile region doubles as the per-wave scratch of the block Jacobi (512 doubles per wave)
-  while ((size_t)tn * p->ldy < (size_t)waves * 512) ++tn;
+  // the obs tile region doubles as the per-wave scratch of the block Jacobi
+  while ((size_t)tn * p->ldy < (size_t)waves * letkf::kBlockJacobiScratch) ++tn;
   p->tn = (int)tn;
   p->lp.lds_bytes = 8 * lds_doubles(true, k, nv, p->ldg, p->ldy, p->tn);
   if (p->lp.lds_bytes > c->lds_max) return fail(LETKF_E_INVALID, "ensemble size too large for the LDS vectors");

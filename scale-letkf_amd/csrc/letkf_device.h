@@ -8,6 +8,10 @@
 
 namespace letkf {
 
+// LDS scratch of the block Jacobi (letkf_kernels.hip, jacobi_block_mfma), doubles per wave: 512 of the in-register
+// 32 x 32 solver + its packed triangular factor (528).  The host sizes the obs tile region of the one-block kernel by it.
+constexpr int kBlockJacobiScratch = 512 + 528;
+
 // Plan of the solve kernel's dynamic run scheduling (letkf_wave.hip), worked out on the host for the grid that is
 // launched and read by the kernel from its arguments (scalar loads): per XCD range x of the unit ids
 //   base[x]  first unit id;  whole[x]  units handed out whole;  f[x]  units handed out in quarters (every t[x]-th of

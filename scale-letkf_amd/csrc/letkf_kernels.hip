@@ -240,8 +240,11 @@ __device__ __forceinline__ int jacobi_stream(double* __restrict__ G, const int l
 // Against the streaming version (one wave per column pair): 1/11 of the L2 traffic per sweep at k = 320, the pair
 // arithmetic on the matrix pipe, three 64-lane shuffle reductions per column pair gone, fewer outer sweeps.
 // A sweep counts as converged when none of its block pairs needed more than the verification cycle of the inner solve.
-// wscr: 512 doubles of LDS per wave.
-constexpr int kBlkScr = 512;
+// wscr: kBlkScr doubles of LDS per wave (512 of the inner solver + the packed 32 x 32 triangular factor).
+constexpr int kBlkScr = kBlockJacobiScratch;
+// (the inner solves stop at the point kernels' |cos| <= 1e-12: with round 2's 1e-10 the block iteration alone "converges" at
+// cond(A) ~ 1e2 with an analysis 180 cond eps off the oracle; at 1e-12 it hands over to the scalar iteration there: 1.6 cond eps)
+constexpr int kBlkFlat = 3, kBlkSweepCap = 16;
 __device__ __forceinline__ int jacobi_block_mfma(double* __restrict__ G, const int ldg, const int k, const int max_sweep,
                                                  double* scr_all, int& conv) {
   using jacobi_dev::v4d;
@@ -252,9 +255,9 @@ __device__ __forceinline__ int jacobi_block_mfma(double* __restrict__ G, const i
   const int nblk = (k + 15) >> 4;
   const int nbe = nblk + (nblk & 1);                     // even number of players (one phantom block if needed)
   const int ntile = nblk;                                // 16-row tiles of Y
-  int sweep = 0;
+  int sweep = 0, flat = 0;
   for (; sweep < max_sweep; ++sweep) {
-    int notconv = 0;
+    int notconv = 0, big = 0;
     for (int rnd = 0; rnd < nbe - 1; ++rnd) {
       for (int pi = wv; pi < (nbe >> 1); pi += nwv) {
         int I, J;
@@ -336,12 +339,58 @@ __device__ __forceinline__ int jacobi_block_mfma(double* __restrict__ G, const i
           for (int r = 0; r < 32; ++r)
             if (pad && r == lane) g[r] = 1.0;
         }
-        // ---- 2. eigenvectors of B
+        // ---- 2. eigenvectors of B, through its Cholesky factor.  Run on B's own columns the one-sided iteration sees the
+        // cosines of Y's columns multiplied by lambda_i / lambda_j + lambda_j / lambda_i (B is a Gram matrix: squared
+        // condition) and its stop rule drowns in rounding noise from cond(A) ~ 1e3 on (tools/r3_probe_block_jacobi.py).
+        // With B = R^T R the columns of R have exactly the inner products of Y's columns, at 32 rows instead of k: the
+        // iteration turns R into W = R V (orthogonal columns), and V = R^T W Lambda^-1, i.e. the normalised columns of
+        // R^T W -- no triangular solve.  R is kept packed in the wave's scratch (528 doubles behind the solver's 512).
+        double* rp = scr + 512;
+        {
+          double dorig = 0.0;
+#pragma unroll
+          for (int r = 0; r < 32; ++r) dorig = (r == lane) ? g[r] : dorig;
+          // (row i of the factor reaches the other lanes through v_readlane -- scalar operands of the update, no registers:
+          // fetched from an LDS row buffer instead, hipcc keeps 31 loads in flight per step and spills 670 registers)
+          auto rdl = [](const double v, const int src) {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+            const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+            return __hiloint2double(hi, lo);
+          };
+#pragma unroll
+          for (int i = 0; i < 32; ++i) {
+            // a pivot below 1e-14 of its column's squared norm is rounding noise (cond(A) beyond 1e7): floor it, the
+            // outer iteration goes on with a slightly wrong V for this pair instead of a NaN
+            const double fl = 1e-14 * rdl(dorig, i);
+            double sii = rdl(g[i], i);
+            sii = sii > fl ? sii : fl;
+            sii = sii > 1e-300 ? sii : 1e-300;
+            const double ir = 1.0 / sqrt(sii);
+            const double rij = (lane >= i && lane < 32) ? g[i] * ir : 0.0;
+            const double f = (lane > i) ? rij : 0.0;
+            g[i] = rij;
+#pragma unroll
+            for (int l = i + 1; l < 32; ++l) g[l] = fma(-rdl(rij, l), f, g[l]);
+          }
+          jacobi_dev::wave_lds_sync();
+          const int tri = (lane * (lane + 1)) >> 1;
+#pragma unroll
+          for (int l = 0; l < 32; ++l)
+            if (l <= lane && lane < 32) rp[tri + l] = g[l];
+        }
         int inpairs = 0;
-        // (stop rule 1e-10: this inner problem is a Gram matrix, its cosines carry eps cond(A)^2 of noise -- with the 1e-12 of
-        // the point kernels the outer iteration stopped converging at cond(A) ~ 1e2 instead of ~ 1e3, tools/r3_probe_block_jacobi.py)
-        const int insw = jacobi_dev::jacobi_split<32, 1, 8, false>(g, 32, 30, scr, &inpairs, nullptr, 1e-20);
+        const int insw = jacobi_dev::jacobi_split<32, 1, 8, false>(g, 32, 30, scr, &inpairs);
         if (insw > 1) notconv = 1;
+        if (insw > 2) big = 1;
+        // W -> R^T W, in place from the last row up (row i needs rows 0..i of W only)
+#pragma unroll
+        for (int i = 31; i >= 0; --i) {
+          double acc = 0.0;
+#pragma unroll
+          for (int l = 0; l <= i; ++l) acc = fma(rp[((i * (i + 1)) >> 1) + l], g[l], acc);
+          g[i] = acc;
+          asm volatile("" : "+v"(g[i])::"memory");       // (one row's reads at a time: hoisted, the 528 of them spill)
+        }
         // The inner solver swaps the two columns of a pair after every rotation, unconditionally: after T steps the
         // column order is a fixed permutation (odd-even transposition: reversal after 32 steps, identity after 64).
         // Undo it, so that V is the product of the ROTATIONS only -- close to the identity once the rotations are small.
@@ -419,6 +468,20 @@ __device__ __forceinline__ int jacobi_block_mfma(double* __restrict__ G, const i
       conv = 1;
       break;
     }
+    // Stagnation: V = R^T W Lambda^-1 is orthogonal to eps cond(A) only, and what it leaves behind in the SMALL columns of Y
+    // (an error of V times lambda_max / lambda_min) comes back as cosines above the stop rule sweep after sweep once
+    // cond(A) is large -- the inner solves then keep reporting two cycles (one rotating, one verifying) without ever
+    // reporting one.  kBlkFlat such sweeps in a row, or kBlkSweepCap sweeps in all, and the scalar one-sided iteration
+    // below finishes the job: its rotations act on Y's columns directly (high relative accuracy whatever the norms).
+    flat = __syncthreads_or(big) ? 0 : flat + 1;
+    if (flat >= kBlkFlat || sweep + 1 >= kBlkSweepCap) {
+      ++sweep;
+      break;
+    }
+  }
+  if (!conv && sweep < max_sweep) {
+    __syncthreads();
+    sweep += jacobi_stream(G, ldg, k, max_sweep - sweep, conv);
   }
   return sweep;
 }

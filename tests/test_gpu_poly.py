@@ -152,7 +152,7 @@ def test_dominant_modes_and_large_obs_space_spread(k, npts, nobs_tot, n_mean, sp
         assert (-w1[solved]).max() < 10.0 * np.sqrt(cond.max()), (cond.max(), w1)
 
 
-@pytest.mark.parametrize("k,n_mean", [(64, 60), (100, 96), (100, 140), (320, 180)])
+@pytest.mark.parametrize("k,n_mean", [(64, 60), (100, 96), (100, 140), (320, 180), (320, 260), (250, 400)])
 def test_points_the_iteration_gives_up_go_to_the_eigen_stage(k, n_mean):
     """Observation errors 100 x smaller: a flat spectrum of width cond ~ 1e4 .. 1e5 at order min(n, k) -- conjugate
     gradients cannot finish within 128 iterations where the order is well above that, the stage rewrites the point's
@@ -179,6 +179,31 @@ def test_points_the_iteration_gives_up_go_to_the_eigen_stage(k, n_mean):
             scale = max(np.abs(x[v, k]).max(), np.abs(x[v, :k]).max())
             err = np.abs(a.reshape(11, nens, npts)[v, :k] - ref["anal"].reshape(11, nens, npts)[v, :k]).max()
             assert err <= tol * scale, (v, err, scale, cond.max())
+
+
+@pytest.mark.parametrize("k,n_mean,scale", [(320, 260, 1e-2), (320, 260, 1e-6), (512, 300, 1e-3), (512, 300, 1e-5), (250, 400, 1e-2), (250, 400, 1e-6)])
+def test_block_jacobi_orders_hold_to_cond_1e6(k, n_mean, scale):
+    """Orders above 208 on the eigen stage (LETKF_OPT_STAGED_POLY = 0: every point) are the block Jacobi on the matrix cores,
+    its 32-column problems solved through their Cholesky factor, finished by the scalar one-sided iteration once the block
+    sweeps stagnate (letkf_kernels.hip, jacobi_block_mfma).  Round 2's version reported status 1 from cond(A) ~ 1e3 on
+    (tools/r3_probe_block_jacobi.py); the reference's tred2 / tql2 has no such limit.  Status 0 and cond * eps accuracy."""
+    from test_gpu_das import CONFIGS
+    cfg = CONFIGS["rtps"]
+    c = das_case(k=k, nv=11, npts=6, nobs_tot=600, n_mean=n_mean, seed=5000 + k, infl0=1.0, vary_n=False)
+    c["rdiag"] = c["rdiag"] * scale
+    cond = point_conds(c, k)
+    ref = oracle(c, k, 11, cfg)
+    a0, i0, s0, w0 = run(c, k, 11, cfg, poly=False)
+    assert (s0 == 0).all(), (s0, w0)
+    solved = c["beta"] != 0.0
+    assert (w0[solved] > 0).all() and (w0[solved] < 30).all(), w0
+    nens, npts = c["nens"], c["npts"]
+    x = c["gues"].reshape(11, nens, npts)
+    tol = max(1e-12, 8.0 * cond.max() * 2.2e-16)
+    for v in range(11):
+        sc = max(np.abs(x[v, k]).max(), np.abs(x[v, :k]).max())
+        err = np.abs(a0.reshape(11, nens, npts)[v, :k] - ref["anal"].reshape(11, nens, npts)[v, :k]).max()
+        assert err <= tol * sc, (v, err, sc, cond.max())
 
 
 def test_hopeless_matrices_are_not_iterated_on():
