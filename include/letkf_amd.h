@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LETKF_AMD_ABI_VERSION 5
+#define LETKF_AMD_ABI_VERSION 6
 
 /* host-side errors (function return values) */
 #define LETKF_OK 0
@@ -242,7 +242,9 @@ typedef struct {
   const int32_t *group_start;
   const int32_t *group_member;
   /* per ctype [nctype] */
-  const int32_t *vmode;       /* vertical coordinate: 0 |dln p| (obs lev), 1 |dz| (type 22), 2 ps (obs dat), 3 rain base */
+  const int32_t *vmode;       /* vertical coordinate: 0 |dln p| (obs lev), 1 |dz| (type 22), 2 ps (obs dat), 3 rain base.
+                                 -DH08, report type 23 (H08IRB, letkf_tools.f90:1859-1861): mode 0 with ob_lev = obsda_sort%lev
+                                 of the row (the sensitive height) instead of obs%lev (which holds the band number there) */
   const double *hori_loc;
   const double *vert_loc;     /* 0 = no vertical localisation */
   const double *varloc;       /* var_local(nvar, uid_obs_varlocal(elm)) of the variable class; < tiny rejects */
@@ -356,7 +358,8 @@ int letkf_ens_spread_dev(letkf_ctx *ctx, int32_t k, int32_t nv, int64_t npts, co
 /*---------------------------------------------------------------------------
  * (5) set_letkf_obs on the device (scale/letkf/letkf_obs.f90): the producer of the
  *     observation table the search (3) and the loop body (2) read.  Per rank (= GPU, = SCALE subdomain):
- *       departure + QC          letkf_obs.f90:361-561 (build without -DH08)
+ *       departure + QC          letkf_obs.f90:361-561 (letkf_qc_params.h08 = 0: the reference built without -DH08;
+ *                               1: its -DH08 build, Himawari-8 IR rows take the branches of :432-469, :480-487, :520-541)
  *       bucket sort on the mesh :762-822 (+ ij_obsgrd :1186-1203)
  *       [all-gather of the sorted buffers and cell counts over the ranks: RCCL, outside this library]
  *       extended-subdomain plan :922-976 and copy into obsda_sort :1036-1100
@@ -371,10 +374,22 @@ typedef struct {
   double radar_ref_thres_dbz;                                    /* RADAR_REF_THRES_DBZ */
   double gross_error, gross_error_rain, gross_error_radar_ref, gross_error_radar_vr, gross_error_radar_prh,
       gross_error_tcx, gross_error_tcy, gross_error_tcp;        /* GROSS_ERROR* */
+  /* ---- the reference's -DH08 build (ABI 6).  h08 = 0: everything below is ignored and rows with elm = id_H08IR_obs (8800) are
+   * ordinary rows (GROSS_ERROR), exactly what the default build does. */
+  int32_t h08;                    /* 1: the -DH08 branches are compiled in */
+  int32_t h08_min_cld_member;     /* H08_MIN_CLD_MEMBER: fewer cloudy members = clear sky (gross-error bound 1.0 err, :528-531) */
+  double h08_limit_lev;           /* H08_LIMIT_LEV (Pa): rows whose sensitive height obsda%lev lies above it are iqc_obs_bad (:441) */
+  double gross_error_h08;         /* GROSS_ERROR_H08 (cloudy sky; the namelist's "< 0: GROSS_ERROR" is the host's to resolve) */
+  double h08_bt_min;              /* H08_BT_MIN: observed brightness temperatures below it are iqc_gross_err (:538-540) */
+  const double *h08_lev;          /* dev [nobs]: obsda%lev -- read for elm = 8800 rows only */
+  double *h08_val2;               /* dev [nobs] INOUT or NULL: obsda%val2, clear-sky BT in, CA = (|mean - clr| + |obs - clr|) / 2 out
+                                     (:480-487; the reference computes it for EVERY live row of the -DH08 build, so does this) */
 } letkf_qc_params;
 
 /* elm[n] = obs(set)%elm(idx), dat / err likewise (gathered per local H(x) row by the caller); ensval[n*kld + m]
- * INOUT: H(x_m) -> H(x_m) - mean; val[n] OUT: y - mean; qc[n] INOUT (rows with qc > 0 are skipped). */
+ * INOUT: H(x_m) -> H(x_m) - mean; val[n] OUT: y - mean; qc[n] INOUT (rows with qc > 0 are skipped).
+ * h08 = 1, elm = 8800: cloudy members arrive as NEGATIVE brightness temperatures (the obs operator's flag); they are counted
+ * and their sign restored before the mean is taken (:448-454). */
 int letkf_obs_departure_dev(letkf_ctx *ctx, const letkf_qc_params *p, int64_t nobs, const int32_t *elm,
                             const double *dat, const double *err, double *ensval, int64_t kld, double *val,
                             int32_t *qc);

@@ -1068,7 +1068,7 @@ void orc_ens_spread(int k, int nv, int64_t npts, const double *x, int64_t sp, in
  * ---------------------------------------------------------------------------------------------- */
 enum {
   ORC_ID_RAIN = 19999, ORC_ID_RADAR_REF = 4001, ORC_ID_RADAR_REF_ZERO = 4004, ORC_ID_RADAR_VR = 4002,
-  ORC_ID_RADAR_PRH = 4003, ORC_ID_TCLON = 99991, ORC_ID_TCLAT = 99992, ORC_ID_TCMIP = 99993,   /* common_obs_scale.f90:48-72 */
+  ORC_ID_RADAR_PRH = 4003, ORC_ID_TCLON = 99991, ORC_ID_TCLAT = 99992, ORC_ID_TCMIP = 99993, ORC_ID_H08IR = 8800,   /* common_obs_scale.f90:48-72 */
   ORC_QC_GOOD = 0, ORC_QC_GROSS = 5, ORC_QC_REF_MEM = 12, ORC_QC_OBS_BAD = 50, ORC_QC_OTYPE = 90   /* :139-151 */
 };
 static const double ORC_UNDEF = -9.99e33;   /* common/common.f90:38 */
@@ -1093,9 +1093,21 @@ void orc_obs_departure(const orc_qc_params *p, int64_t nobs, const int32_t *elm,
       }
     }
     if (el == ORC_ID_RADAR_VR && !p->use_radar_vr) { qc[n] = ORC_QC_OTYPE; continue; }   /* :413-418 */
+    int mem_cld = 0;
+    if (p->h08 && el == ORC_ID_H08IR) {                                     /* #ifdef H08, :432-469 */
+      if (dat[n] == ORC_UNDEF) { qc[n] = ORC_QC_OBS_BAD; continue; }
+      if (p->h08_lev[n] < p->h08_limit_lev) { qc[n] = ORC_QC_OBS_BAD; continue; }
+      for (int i = 0; i < K; ++i)
+        if (e[i] < 0.0) {
+          mem_cld = mem_cld + 1;
+          e[i] = e[i] * (-1.0);
+        }
+    }
     double v = e[0];                                                        /* :475-479 */
     for (int i = 1; i < K; ++i) v = v + e[i];
     v = v / (double)K;
+    if (p->h08 && p->h08_val2)                                              /* #ifdef H08, :480-487 */
+      p->h08_val2[n] = (fabs(v - p->h08_val2[n]) + fabs(dat[n] - p->h08_val2[n])) * 0.5;
     for (int i = 0; i < K; ++i) e[i] = e[i] - v;                            /* :488-490 */
     v = dat[n] - v;                                                         /* :491 */
     val[n] = v;
@@ -1112,7 +1124,18 @@ void orc_obs_departure(const orc_qc_params *p, int64_t nobs, const int32_t *elm,
       case ORC_ID_TCMIP: ge = p->gross_error_tcp; break;
       default: ge = p->gross_error;
     }
-    if (fabs(v) > ge * err[n]) qc[n] = ORC_QC_GROSS;
+    if (p->h08 && el == ORC_ID_H08IR) {                                     /* case (id_H08IR_obs), :520-541.  (The case itself
+                                                                               is outside the #ifdef; in a default build mem_ref
+                                                                               is never assigned for such a row -- undefined --
+                                                                               and no default-build obs operator produces one:
+                                                                               h08 = 0 treats it as an ordinary row.) */
+      if (mem_cld < p->h08_min_cld_member) {
+        if (fabs(v) > 1.0 * err[n]) qc[n] = ORC_QC_GROSS;
+      } else {
+        if (fabs(v) > p->gross_error_h08 * err[n]) qc[n] = ORC_QC_GROSS;
+      }
+      if (dat[n] < p->h08_bt_min) qc[n] = ORC_QC_GROSS;
+    } else if (fabs(v) > ge * err[n]) qc[n] = ORC_QC_GROSS;
   }
 }
 

@@ -79,7 +79,10 @@ class QcParams(C.Structure):
                 ("min_radar_ref_member_obsref", C.c_int32), ("radar_ref_thres_dbz", C.c_double),
                 ("gross_error", C.c_double), ("gross_error_rain", C.c_double), ("gross_error_radar_ref", C.c_double),
                 ("gross_error_radar_vr", C.c_double), ("gross_error_radar_prh", C.c_double),
-                ("gross_error_tcx", C.c_double), ("gross_error_tcy", C.c_double), ("gross_error_tcp", C.c_double)]
+                ("gross_error_tcx", C.c_double), ("gross_error_tcy", C.c_double), ("gross_error_tcp", C.c_double),
+                ("h08", C.c_int32), ("h08_min_cld_member", C.c_int32), ("h08_limit_lev", C.c_double),
+                ("gross_error_h08", C.c_double), ("h08_bt_min", C.c_double), ("h08_lev", C.c_void_p),
+                ("h08_val2", C.c_void_p)]
 
 
 class Mesh(C.Structure):

@@ -23,7 +23,7 @@ namespace {
 
 // common_obs_scale.f90:48-72, :139-151; common/common.f90:38
 constexpr int kIdRain = 19999, kIdRadarRef = 4001, kIdRadarRefZero = 4004, kIdRadarVr = 4002, kIdRadarPrh = 4003,
-              kIdTclon = 99991, kIdTclat = 99992, kIdTcmip = 99993;
+              kIdTclon = 99991, kIdTclat = 99992, kIdTcmip = 99993, kIdH08IR = 8800;
 constexpr int kQcGood = 0, kQcGross = 5, kQcRefMem = 12, kQcObsBad = 50, kQcOtype = 90;
 constexpr double kUndef = -9.99e33;
 
@@ -73,10 +73,27 @@ __global__ void __launch_bounds__(64) departure_kernel(const letkf_qc_params P, 
           q = kQcOtype;
           live = false;
         }
+        int mem_cld = 0;
+        if (live && P.h08 && el == kIdH08IR) {                       // -DH08, :432-469
+          if (d == kUndef || P.h08_lev[n] < P.h08_limit_lev) {
+            q = kQcObsBad;
+            live = false;
+          } else {
+            for (int i = 0; i < K; ++i)
+              if (e[i] < 0.0) {                                      // cloudy members carry negative values
+                ++mem_cld;
+                e[i] = e[i] * (-1.0);
+              }
+          }
+        }
         if (live) {
           double v = e[0];                                             // :475-479
           for (int i = 1; i < K; ++i) v = v + e[i];
           v = v / (double)K;
+          if (P.h08 && P.h08_val2) {                                   // -DH08, :480-487: CA (Okamoto et al. 2014)
+            const double clr = P.h08_val2[n];
+            P.h08_val2[n] = (fabs(v - clr) + fabs(d - clr)) * 0.5;
+          }
           for (int i = 0; i < K; ++i) e[i] = e[i] - v;                 // :488-490
           v = d - v;                                                   // :491
           val[n] = v;
@@ -93,7 +110,13 @@ __global__ void __launch_bounds__(64) departure_kernel(const letkf_qc_params P, 
             case kIdTcmip: ge = P.gross_error_tcp; break;
             default: ge = P.gross_error;
           }
-          if (fabs(v) > ge * err[n]) q = kQcGross;
+          if (P.h08 && el == kIdH08IR) {                               // -DH08, :520-541
+            ge = mem_cld < P.h08_min_cld_member ? 1.0 : P.gross_error_h08;
+            if (fabs(v) > ge * err[n]) q = kQcGross;
+            if (d < P.h08_bt_min) q = kQcGross;
+          } else if (fabs(v) > ge * err[n]) {
+            q = kQcGross;
+          }
         }
         qc[n] = q;
       }

@@ -71,6 +71,10 @@ MODULE letkf_amd_api
     REAL(c_double)     :: radar_ref_thres_dbz
     REAL(c_double)     :: gross_error, gross_error_rain, gross_error_radar_ref, gross_error_radar_vr, gross_error_radar_prh, &
                           gross_error_tcx, gross_error_tcy, gross_error_tcp
+    ! the -DH08 build of the reference (ABI 6).  h08 = 0: compiled out -- SET IT, a derived type has no zero default
+    INTEGER(c_int32_t) :: h08, h08_min_cld_member
+    REAL(c_double)     :: h08_limit_lev, gross_error_h08, h08_bt_min
+    TYPE(c_ptr)        :: h08_lev, h08_val2
   END TYPE letkf_qc_params
   TYPE, BIND(C) :: letkf_mesh
     INTEGER(c_int32_t) :: nctype, nlon, nlat, ihalo, jhalo, rank_i, rank_j, fix_ij_obsgrd

@@ -75,7 +75,8 @@ MODULE letkf_tools_amd
 CONTAINS
 
   ! vertical coordinate of a combined type (obs_local_cal, letkf_tools.f90:1851-1865): 0 |dln p| (obs lev), 1 |dz| (type 22),
-  ! 2 ps (obs dat), 3 rain base
+  ! 2 ps (obs dat), 3 rain base.  The -DH08 build's report type 23 (H08IRB, :1859-1861) is mode 0 as well: its rows carry
+  ! obsda_sort%lev (the sensitive height) in letkf_obs_tables%lev instead of obs%lev -- the tables are per obsda_sort row.
   PURE FUNCTION letkf_vmode(elm, typ) RESULT(vm)
     INTEGER, INTENT(IN) :: elm, typ
     INTEGER(c_int32_t) :: vm

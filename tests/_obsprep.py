@@ -17,7 +17,10 @@ class QcParams(C.Structure):
                 ("min_radar_ref_member_obsref", C.c_int32), ("radar_ref_thres_dbz", C.c_double),
                 ("gross_error", C.c_double), ("gross_error_rain", C.c_double), ("gross_error_radar_ref", C.c_double),
                 ("gross_error_radar_vr", C.c_double), ("gross_error_radar_prh", C.c_double),
-                ("gross_error_tcx", C.c_double), ("gross_error_tcy", C.c_double), ("gross_error_tcp", C.c_double)]
+                ("gross_error_tcx", C.c_double), ("gross_error_tcy", C.c_double), ("gross_error_tcp", C.c_double),
+                ("h08", C.c_int32), ("h08_min_cld_member", C.c_int32), ("h08_limit_lev", C.c_double),
+                ("gross_error_h08", C.c_double), ("h08_bt_min", C.c_double), ("h08_lev", C.c_void_p),
+                ("h08_val2", C.c_void_p)]
 
 
 class Mesh(C.Structure):
@@ -100,6 +103,39 @@ def layout_struct(cls, w, myrank):
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+def h08_rows(seed, k, det_run, nobs):
+    """Rows of a -DH08 build: half Himawari-8 IR (elm 8800: brightness temperatures, cloudy members NEGATIVE, a sensitive
+    height per row, a clear-sky BT in val2), half upper-air u; undefined / too-cold observations and rows above the level
+    limit mixed in."""
+    rng = np.random.default_rng(seed)
+    kld = k + (1 if det_run else 0)
+    h08 = rng.random(nobs) < 0.5
+    elm = np.where(h08, 8800, 2819).astype(np.int32)
+    bt = 250.0 + 20.0 * rng.standard_normal((nobs, kld))
+    cloudy = rng.random((nobs, kld)) < rng.choice([0.0, 0.02, 0.3], size=(nobs, 1))
+    ens = np.where(h08[:, None], np.where(cloudy, -bt, bt), 5.0 * rng.standard_normal((nobs, kld)))
+    dat = np.where(h08, 250.0 + 25.0 * rng.standard_normal(nobs), 5.0 * rng.standard_normal(nobs))
+    dat[rng.random(nobs) < 0.05] = -9.99e33
+    dat[(rng.random(nobs) < 0.05) & h08] = 150.0                      # below H08_BT_MIN = 180
+    err = np.where(h08, 3.0, 1.0) * (0.5 + rng.random(nobs))
+    lev = np.where(h08, rng.uniform(5000.0, 90000.0, nobs), 50000.0)
+    val2 = np.where(h08, 255.0 + 10.0 * rng.standard_normal(nobs), 0.0)
+    qc = np.where(rng.random(nobs) < 0.1, 21, 0).astype(np.int32)
+    return dict(elm=elm, ens=np.ascontiguousarray(ens), dat=dat, err=err, lev=lev, val2=val2, qc=qc, kld=kld, h08=h08)
+def oracle_departure_h08(r, k, det_run, with_val2, **over):
+    """The oracle's departure + QC on rows of h08_rows.  Returns (ensval, val, qc, val2)."""
+    nobs = len(r["qc"])
+    ens, qc, v2, lev = r["ens"].copy(), r["qc"].copy(), r["val2"].copy(), r["lev"].copy()
+    val = np.zeros(nobs)
+    prm = qc_params(QcParams, k, det_run, **over)
+    prm.h08_lev = lev.ctypes.data
+    prm.h08_val2 = v2.ctypes.data if with_val2 else None
+    _oracle.oracle().orc_obs_departure(C.byref(prm), C.c_int64(nobs), _p(r["elm"], C.c_int32), _p(r["dat"], C.c_double),
+                                       _p(r["err"], C.c_double), _p(ens, C.c_double), C.c_int64(r["kld"]),
+                                       _p(val, C.c_double), _p(qc, C.c_int32))
+    return ens, val, qc, v2
 
 
 def oracle_rank_stage12(w, rk):

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from _obsprep import make_world, mesh_struct, layout_struct, oracle_plan, oracle_rank_stage12, qc_params
+from _obsprep import h08_rows, make_world, mesh_struct, layout_struct, oracle_plan, oracle_rank_stage12, oracle_departure_h08, qc_params
 
 pytestmark = pytest.mark.gpu
 
@@ -167,3 +167,33 @@ def test_f2_tables_drive_the_search():
         assert np.allclose(rl[off[p]:off[p + 1]], orl[:n], rtol=1e-14, atol=0)
         total += n
     assert total > 500
+
+
+@pytest.mark.parametrize("k,det_run,nobs,val2", [(10, True, 4000, True), (50, False, 3000, True), (20, True, 700, False)])
+def test_departure_h08_build_bit_exact(k, det_run, nobs, val2):
+    """letkf_qc_params.h08 = 1 = the reference's -DH08 build (letkf_obs.f90:432-469 level / undef rejection and the cloudy-member
+    count with the sign restored, :480-487 CA into val2, :520-541 sky-dependent gross-error bound and H08_BT_MIN) against the
+    oracle's restatement, bit for bit; h08 = 0 on the same rows = ordinary rows (the default build)."""
+    from _gpu import ctx, dev, pkg
+    r = h08_rows(77 + k, k, det_run, nobs)
+    for h08 in (1, 0):
+        over = dict(h08=h08, h08_min_cld_member=2, h08_limit_lev=20000.0, gross_error_h08=4.0, h08_bt_min=180.0)
+        ens_o, val_o, qc_o, v2_o = oracle_departure_h08(r, k, det_run, val2, **over)
+        ens_g, qc_g, v2_g, lev_g = dev(r["ens"]), dev(r["qc"]), dev(r["val2"]), dev(r["lev"])
+        val_g = torch.zeros(nobs, dtype=torch.float64, device="cuda")
+        pg = qc_params(pkg.QcParams, k, det_run, **over)
+        pg.h08_lev = lev_g.data_ptr()
+        pg.h08_val2 = v2_g.data_ptr() if val2 else None
+        ctx().obs_departure(pg, dev(r["elm"]), dev(r["dat"]), dev(r["err"]), ens_g, r["kld"], val_g, qc_g)
+        torch.cuda.synchronize()
+        assert np.array_equal(qc_g.cpu().numpy(), qc_o)
+        assert np.array_equal(ens_g.cpu().numpy(), ens_o)
+        good = qc_o == 0
+        assert np.array_equal(val_g.cpu().numpy()[good], val_o[good])
+        assert np.array_equal(v2_g.cpu().numpy(), v2_o)
+        hq = qc_o[r["h08"] & (r["qc"] == 0)]
+        if h08:
+            assert (hq == 50).sum() > 10 and (hq == 5).sum() > 10 and (hq == 0).sum() > 10     # every branch is taken
+            assert not np.array_equal(v2_o, r["val2"]) or not val2
+        else:
+            assert (hq == 50).sum() == 0 and np.array_equal(v2_o, r["val2"])

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from _obsprep import ID_RADAR_REF, ID_RADAR_VR, UNDEF, make_world, oracle_plan, oracle_rank_stage12
+from _obsprep import ID_RADAR_REF, ID_RADAR_VR, UNDEF, h08_rows, make_world, oracle_departure_h08, oracle_plan, oracle_rank_stage12
 
 
 def test_departure_and_qc_rules():
@@ -152,3 +152,41 @@ def test_monit_dep_and_additive_inflation_restatements():
                                C.c_double(0.25), p(w, C.c_double), p(q, C.c_double), C.c_int64(1), C.c_int64(npts),
                                C.c_int(5), C.c_int(6), p(sh, C.c_int32))
     assert np.allclose(got, want, rtol=1e-15, atol=0)
+
+
+def test_h08_build_rules():
+    """The -DH08 branches (letkf_obs.f90:432-469, :480-487, :520-541) written out row by row."""
+    k, det = 12, True
+    r = h08_rows(5, k, det, 3000)
+    over = dict(h08=1, h08_min_cld_member=2, h08_limit_lev=20000.0, gross_error_h08=4.0, h08_bt_min=180.0)
+    ens, val, qc, v2 = oracle_departure_h08(r, k, det, True, **over)
+    seen = set()
+    for n in range(len(qc)):
+        e0, d = r["ens"][n], r["dat"][n]
+        if r["qc"][n] > 0:
+            assert qc[n] == r["qc"][n] and np.array_equal(ens[n], e0) and v2[n] == r["val2"][n]
+            continue
+        is_h08 = r["elm"][n] == 8800
+        if is_h08 and (d == UNDEF or r["lev"][n] < 20000.0):
+            assert qc[n] == 50 and np.array_equal(ens[n], e0) and v2[n] == r["val2"][n]
+            seen.add("bad")
+            continue
+        m = e0[:k].copy()
+        cld = 0
+        if is_h08:
+            cld = int((m < 0.0).sum())
+            m = np.abs(m)
+        mean = m[0]
+        for i in range(1, k):
+            mean = mean + m[i]
+        mean = mean / k
+        assert np.array_equal(ens[n, :k], m - mean) and val[n] == d - mean and ens[n, k] == d - e0[k]
+        assert v2[n] == (abs(mean - r["val2"][n]) + abs(d - r["val2"][n])) * 0.5       # every live row of the build
+        if is_h08:
+            ge = 1.0 if cld < 2 else 4.0
+            bad = abs(d - mean) > ge * r["err"][n] or d < 180.0
+            seen.add(("clear" if cld < 2 else "cloudy") + ("_gross" if bad else "_good"))
+        else:
+            bad = abs(d - mean) > 5.0 * r["err"][n]
+        assert qc[n] == (5 if bad else 0)
+    assert seen == {"bad", "clear_gross", "clear_good", "cloudy_gross", "cloudy_good"}
