@@ -26,7 +26,7 @@ __device__ __forceinline__ void psync() {
 }
 template <int NW>
 __device__ __forceinline__ bool pany(bool v) {
-  if constexpr (NW == 1) return __any(v) != 0;
+  if constexpr (NW == 1) return __builtin_amdgcn_ballot_w64(v) != 0ull;
   else return __syncthreads_or(v) != 0;
 }
 
@@ -58,16 +58,19 @@ constexpr double kStopTol2W = LETKF_STOP_TOL2;
 // tools/parity_margin.py).  Such points simply fall back to the rule above (1e-12).
 constexpr double kEarlyTol2W = LETKF_EARLY_TOL2;
 constexpr double kEarlyT2W = LETKF_EARLY_T2;
+constexpr double kEarlyTW = 1e-6;      // sqrt(kEarlyT2W): the tangent is compared as |t| (no multiply)
+static_assert(LETKF_EARLY_T2 == 1e-12, "kEarlyTW is its square root");
 
 // 1/sqrt(x) and 1/x from the hardware seeds (v_rsq_f64 / v_rcp_f64, ~2^-23) + two Newton steps each: full
 // double precision without the IEEE division / sqrt expansions (~25 instructions each), which were 1/3 of
 // the Jacobi step's FP64 issue slots.
 __device__ __forceinline__ double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  double e = fma(-x * y, y, 1.0);
-  y = fma(y * 0.5, e, y);
-  e = fma(-x * y, y, 1.0);
-  return fma(y * 0.5, e, y);
+  // (round 3: ONE third-order step instead of two Newton steps -- x y0^2 = 1 - e, so 1/sqrt(x) = y0 (1 - e)^-1/2 =
+  // y0 (1 + e/2 + 3 e^2/8 + 5 e^3/16 ...); with the seed's e ~ 2.4e-7 the first dropped term is 4e-21.  5 instructions, was 8.)
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y, y, 1.0);
+  const double q = e * fma(0.375, e, 0.5);
+  return fma(y, q, y);
 }
 // The rotation ANGLE takes the hardware seeds as they are (~2^-23 relative): a tangent that is off by delta still gives
 // an exactly orthogonal (scaled) rotation -- the cosine and the scales below are computed from the tangent actually
@@ -191,6 +194,9 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
   const bool rows = NW == 1 || act;
   if (NW == 2 || act) {
     const bool hasL = act && slot > 0, hasR = act && slot + 1 < S;
+    // (lane masks of the votes are combined with scalar instructions: written as `hasR && (a || b)` hipcc builds short-circuit
+    // branches inside the step pair)
+    const unsigned long long hasRm = __builtin_amdgcn_ballot_w64(hasR);
     double alA = 0.0, alB = 0.0, isA = 1.0, isB = 1.0, scA = 1.0, scB = 1.0;
     // `quiet` counts consecutive step pairs in which no visited column pair exceeded the tolerance; S of them in a
     // row are one full cycle of the ordering (every column pair seen once) whatever step it started at, so the
@@ -213,7 +219,9 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
       alB = slot_sum_nw<NW>(b0, lds, ph);
       isA = isB = scA = scB = 1.0;
       for (int t = 0; t < ncol && !done; t += 2) {
-        bool notconv = false, notconv2 = false;
+        // the two votes of the step pair, kept as lane masks (scalar registers): accumulated as per-lane booleans hipcc holds
+        // them in a vector register and converts back and forth (5 vector instructions per step pair)
+        unsigned long long notconv = 0, notconv2 = 0;
         // ---------------- even step: the slot's own two columns (A at the lower position)
         {
           double p0 = 0.0, p1 = 0.0;
@@ -227,14 +235,21 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           const double ga = slot_sum_nw<NW>(p0 + p1, lds, ph) * (isA * isB);
           const double a = alA, b = alB;
           const double g2 = ga * ga, ab = a * b;
-          notconv |= g2 > stop_tol2 * ab;
+          notconv |= __builtin_amdgcn_ballot_w64(g2 > stop_tol2 * ab);
+          // tan(theta) = gamma sign(h) / (|h| + sqrt(h^2 + gamma^2)), h = (beta - alpha) / 2 (the smaller root of
+          // t^2 + 2 (h / gamma) t - 1 = 0).  Pairs with |cos| <= 1e-15 are NOT rotated: inside a cluster of equal eigenvalues
+          // (every point with fewer observations than members) h is rounding noise as well, the angle would be 45 degrees at a
+          // cosine that is noise, and such a rotation shuffles the couplings of its two columns to all others after those
+          // were visited (tried without the test: tests/test_gpu_sparse_margin.py 1.5e-14 -> 2e-12).  It also keeps the
+          // 0 * rsq(0) = NaN of two zero columns out.
           const bool rot = g2 > kRotTol2W * ab;
-          const double d = b - a;
-          const double x = fma(d, d, 4.0 * g2);
-          const double hh = x * fast_rsqrt1(x);
-          double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
+          const double h = 0.5 * (b - a);
+          const double x = fma(h, h, g2);
+          const double den = fma(x, fast_rsqrt1(x), fabs(h));
+          double tt = ga * fast_rcp1(copysign(den, h));
           tt = rot ? tt : 0.0;
-          notconv2 |= g2 > kEarlyTol2W * ab || tt * tt > kEarlyT2W;
+          if constexpr (EARLY)
+            notconv2 |= __builtin_amdgcn_ballot_w64(g2 > kEarlyTol2W * ab) | __builtin_amdgcn_ballot_w64(fabs(tt) > kEarlyTW);
           const double w = fma(tt, tt, 1.0);
           const double c = fast_rsqrt(w);
           const double tg = tt * ga, wc = w * c;
@@ -305,14 +320,15 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           const double ga = slot_sum_nw<NW>(p0 + p1, lds, ph) * (isB * isAr);
           const double a = alB, b = alAr;
           const double g2 = ga * ga, ab = a * b;
-          notconv |= hasR && g2 > stop_tol2 * ab;
+          notconv |= __builtin_amdgcn_ballot_w64(g2 > stop_tol2 * ab) & hasRm;
           const bool rot = hasR && g2 > kRotTol2W * ab;
-          const double d = b - a;
-          const double x = fma(d, d, 4.0 * g2);
-          const double hh = x * fast_rsqrt1(x);
-          double tt = (2.0 * ga) * copysign(1.0, d) * fast_rcp1(fabs(d) + hh);
+          const double h = 0.5 * (b - a);
+          const double x = fma(h, h, g2);
+          const double den = fma(x, fast_rsqrt1(x), fabs(h));
+          double tt = ga * fast_rcp1(copysign(den, h));
           tt = rot ? tt : 0.0;
-          notconv2 |= hasR && (g2 > kEarlyTol2W * ab || tt * tt > kEarlyT2W);
+          if constexpr (EARLY)
+            notconv2 |= (__builtin_amdgcn_ballot_w64(g2 > kEarlyTol2W * ab) | __builtin_amdgcn_ballot_w64(fabs(tt) > kEarlyTW)) & hasRm;
           const double w = fma(tt, tt, 1.0);
           const double c = fast_rsqrt(w);
           const double tg = tt * ga, wc = w * c;
@@ -358,14 +374,16 @@ __device__ __forceinline__ int jacobi_split(double (&g)[KR], const int k, const 
           }
         }
         ++pairs;
-        if constexpr (NW == 1 || !EARLY) {
-          quiet = pany<NW>(notconv) ? 0 : quiet + 1;
-          if constexpr (EARLY) quiet2 = pany<NW>(notconv2) ? 0 : quiet2 + 1;
+        if constexpr (NW == 1) {
+          quiet = notconv ? 0 : quiet + 1;
+          if constexpr (EARLY) quiet2 = notconv2 ? 0 : quiet2 + 1;
+        } else if constexpr (!EARLY) {
+          quiet = __syncthreads_or(notconv != 0ull) ? 0 : quiet + 1;
         } else {
           // two waves, two votes, ONE barrier: each wave leaves its two ballots in LDS (behind the 2 x 128 doubles of
           // the inner-product exchange; double-buffered like it)
           int* fl = reinterpret_cast<int*>(lds + 256);
-          const int mine = (__any(notconv) ? 1 : 0) | (__any(notconv2) ? 2 : 0);
+          const int mine = (notconv ? 1 : 0) | (notconv2 ? 2 : 0);
           if ((threadIdx.x & 63) == 0) fl[2 * vph + ((threadIdx.x >> 6) & 1)] = mine;
           __syncthreads();
           const int both = fl[2 * vph] | fl[2 * vph + 1];
