@@ -381,6 +381,8 @@ struct ColArgs {
   int* nobs_ctype;       // [npts][nctype] accepted rows per combined type (nobsl_t of obs_local), or null
 };
 
+// FILL = false is the counting pass of the two-phase CSR build: no weights are needed there, only whether a row is accepted.
+template <bool FILL>
 __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs A) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) double smem_col[];
@@ -408,6 +410,7 @@ __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs
       const double varloc = t.varloc[ic];
       if (varloc < kTiny) continue;                               // local_cal :1843
       const int vm = t.vmode[ic];
+      const bool wsafe = varloc > 1e-290;
       const double vloc = t.vert_loc[ic], hloc = t.hori_loc[ic];
       const double dzi = hloc * kDistZeroFac / t.dx, dzj = hloc * kDistZeroFac / t.dy;
       int imin, imax, jmin, jmax;
@@ -438,7 +441,7 @@ __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs
           }
           const double vconst = (vm == 3 && vloc != 0.0) ? fabs(log(t.rain_base) - vref) / vloc : 0.0;
           int emitted = cntl[lev];
-          const long out = A.fill ? A.obs_off[p] : 0;
+          const long out = FILL ? A.obs_off[p] : 0;
           for (int s0 = 0; s0 < ns; s0 += 64) {
             const int si = s0 + lane;
             bool acc = false;
@@ -456,14 +459,21 @@ __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs
               if (!(nd_v > kDistZeroFac)) {                       // :1869
                 const double nd = nd_h * nd_h + nd_v * nd_v;      // :1888
                 if (!(nd > kDistZeroFacSq)) {                     // :1891
-                  rloc = varloc * exp(-0.5 * nd);                 // :1899
-                  rdiag = b2.y * b2.y / rloc;                     // :1903
-                  acc = rloc != 0.0;                              // letkf_tools.f90:1460
+                  if (FILL || !wsafe) {
+                    rloc = varloc * exp(-0.5 * nd);               // :1899
+                    rdiag = b2.y * b2.y / rloc;                   // :1903
+                    acc = rloc != 0.0;                            // letkf_tools.f90:1460
+                  } else {
+                    // counting pass: inside the cut-off nd <= 13.3, exp(-nd / 2) >= 1.2e-3, so the weight cannot vanish
+                    // unless the variable localisation is itself at the bottom of the exponent range (wsafe): the
+                    // exponential and the division -- half of this loop's instructions -- are the fill pass's alone
+                    acc = true;
+                  }
                 }
               }
             }
             const unsigned long long mk = __ballot(acc);
-            if (A.fill && acc) {
+            if (FILL && acc) {
               const long o = out + emitted + __popcll(mk & lt_mask);
               A.obs_idx[o] = row;
               A.rdiag_l[o] = rdiag;
@@ -515,7 +525,7 @@ __global__ void __launch_bounds__(256) letkf_search_columns_kernel(const ColArgs
         for (int l = lane; l < nlev; l += 64)
           A.nobs_ctype[(col + A.nij1 * (long)l) * t.nctype + ic] = cntl[l] - cprev[l];
     }
-    if (!A.fill)
+    if (!FILL)
       for (int l = lane; l < nlev; l += 64) A.counts[col + A.nij1 * (long)l] = cntl[l];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1200,15 +1210,15 @@ hipError_t launch_search_columns(const letkf_search_tables& t, long nij1, int nl
                                  int num_cu, hipStream_t st) {
   ColArgs a{t, nij1, nlev, rig, rjg, rlev, rz, fill, counts, obs_off, obs_idx, rdiag_l, rloc_l, nobs_ctype};
   const size_t lds = (size_t)4 * (4 * kSurv + 2 * ((nlev + 1) & ~1)) * sizeof(double);
+  auto kern = fill ? &letkf_search_columns_kernel<true> : &letkf_search_columns_kernel<false>;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_search_columns_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   const long nwg = (nij1 + 3) / 4;
   const long g = (long)num_cu * 8;
   const int grid = (int)(nwg < g ? (nwg > 0 ? nwg : 1) : g);
-  hipLaunchKernelGGL(letkf_search_columns_kernel, dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
