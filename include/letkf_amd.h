@@ -72,6 +72,9 @@ int letkf_ctx_synchronize(letkf_ctx *ctx);
  * 0: every point goes through the Jacobi (what replaces common/common_mtx.f90:41 mtx_eigen) -- 63 <= k <= 100 on the
  * two-wave register kernel, larger k on the staged path's eigen stage -- as calls with trans / Pa outputs always do. */
 #define LETKF_OPT_STAGED_POLY 1
+/* LETKF_OPT_COLUMN_SURVIVORS: letkf_das_columns_dev's list-free route (see (3c)).  2 (default): where the lists of all levels would
+ * not fit `list_bytes` at once; 1: wherever the one-wave kernel serves the call; 0: never (always lists). */
+#define LETKF_OPT_COLUMN_SURVIVORS 2
 int letkf_ctx_set_option(letkf_ctx *ctx, int option, int value);
 
 /*---------------------------------------------------------------------------
@@ -310,8 +313,14 @@ int letkf_das_points_fused_dev(letkf_ctx *ctx, const letkf_das_args *args, const
  * call's one synchronisation besides the search's own), then per slab the fill pass and the loop body on the context's
  * stream.  args: as for letkf_das_points_dev with npts = nij1*nlev; obs_off / obs_idx / rdiag_l / rloc_l are ignored;
  * trans_out / transm_out / pa_out must be NULL (per-point k x k outputs belong to (2)); warm-start runs go up the columns
- * of a slab.  This is the list-based route for workloads whose lists do not fit at once (BASELINE configs[3]: 10 M points x
- * ~4900 entries), any k, any MAX_NOBS_PER_GRID; (3b) is the list-free one for k <= 62 without a limit.
+ * of a slab.  This is the list-based route: any k, any MAX_NOBS_PER_GRID.
+ * The LIST-FREE route (k <= 62, nv = 11, no combined type with a limit; LETKF_OPT_COLUMN_SURVIVORS, by default taken where
+ * the lists of all levels would not fit list_bytes at once -- BASELINE configs[3]: 10 M points x ~4900 entries = 1 TB): the
+ * horizontal half of obs_local once per COLUMN (the rows inside the horizontal cut-off, 32 B each, in batches of columns that
+ * fit list_bytes), the vertical half inside the loop body kernel, which assembles each point's list in a slot of its own wave.
+ * No count pass over the levels, nothing per (point, observation) in memory; same observations in the same order with the
+ * same weights, hence the same analysis to the last bit (tests/test_gpu_columns.py).  (3b) walks the sorting mesh per POINT
+ * instead and is superseded by this route wherever both apply.
  * nobs_out: dev [npts] or NULL, receives nobsl of every point. */
 int letkf_das_columns_dev(letkf_ctx *ctx, const letkf_das_args *args, const letkf_search_tables *tables, int64_t nij1,
                           int32_t nlev, const double *rig, const double *rjg, const double *rlev, const double *rz,

@@ -200,6 +200,7 @@ class Context:
         self._check(self._l.letkf_ctx_set_stream(self._c, C.c_void_p(stream_handle)))
 
     OPT_STAGED_POLY = 1     # include/letkf_amd.h LETKF_OPT_STAGED_POLY
+    OPT_COLUMN_SURVIVORS = 2   # LETKF_OPT_COLUMN_SURVIVORS
 
     def set_option(self, option, value):
         self._check(self._l.letkf_ctx_set_option(self._c, C.c_int(option), C.c_int(value)))
@@ -268,7 +269,8 @@ class Context:
                     list_bytes=0, nobs_out=None, beta=None, det_run=False, infl_adaptive=False, relax_to_inflated_prior=False,
                     relax_alpha=0.0, relax_alpha_spread=0.0, q_update_top=0.0, q_sprd_max=0.0, iv_p=4, iv_q_first=5,
                     iv_q_last=10, status=None, nsweep=None, rtps_infl_out=None, warm_run=0, var_mask=0, infl_sv=0):
-        """letkf_das_columns_dev: column search + loop body for the points p = ij + nij1*lev, by slabs of levels whose
+        """letkf_das_columns_dev: obs_local + loop body for the points p = ij + nij1*lev -- list-free where the one-wave kernel
+        serves the call (horizontal survivors per column, batches of columns that fit list_bytes), else by slabs of levels whose
         lists fit list_bytes of library workspace."""
         a = DasArgs()
         a.k, a.nv, a.det_run, a.infl_adaptive = k, nv, int(bool(det_run)), int(bool(infl_adaptive))

@@ -52,13 +52,16 @@ struct letkf_ctx {
   size_t warm_ws_bytes = 0;
   char* scratch = nullptr;    // staging for the host-pointer entry
   size_t scratch_bytes = 0;
-  char* list_ws = nullptr;    // letkf_das_columns_dev: the local-observation lists of one slab of levels
+  char* list_ws = nullptr;    // letkf_das_columns_dev: the local-observation lists of one slab of levels / the survivors of a batch of columns
   size_t list_ws_bytes = 0;
+  char* slot_ws = nullptr;    // ... its list-free route: one local list per resident wave
+  size_t slot_ws_bytes = 0;
   char* staged_ws = nullptr;  // staged path: per-point slabs of a batch + meta / info words
   size_t staged_ws_bytes = 0;
   std::string last_path;      // kernels the last loop-body / letkf_core launch went through (bench.py reports it)
   bool timing = false;
   bool staged_poly = true;    // LETKF_OPT_STAGED_POLY
+  int col_survivors = 2;      // LETKF_OPT_COLUMN_SURVIVORS: 0 never, 1 wherever the one-wave kernel serves the call, 2 where the lists would not fit
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 };
 
@@ -223,6 +226,19 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, int warm_run = 0, long warm_stride
     if (wbytes > c->warm_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));   // old buffer may still be in use
     if (int rc = ensure_bytes(c, &c->warm_ws, &c->warm_ws_bytes, wbytes)) return rc;
     a.warm_ws = reinterpret_cast<double*>(c->warm_ws);
+    if (a.mode == 3) {   // one local-list slot per wave of the grid (4 waves per workgroup): idx | rdiag | rloc
+      const size_t nslot = (size_t)a.wave_grid * 4, cap = (size_t)(a.sl_cap > 0 ? a.sl_cap : 4);
+      const size_t o_rd = (nslot * cap * 4 + 255) & ~(size_t)255, o_rl = o_rd + nslot * cap * 8;
+      const size_t need = o_rl + nslot * cap * 8 + 256;
+      if (need > c->slot_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));
+      if (int rc = ensure_bytes(c, &c->slot_ws, &c->slot_ws_bytes, need)) return rc;
+      a.sl_idx = reinterpret_cast<int*>(c->slot_ws);
+      a.sl_rd = reinterpret_cast<double*>(c->slot_ws + o_rd);
+      a.sl_rl = reinterpret_cast<double*>(c->slot_ws + o_rl);
+      a.obs_idx = a.sl_idx;
+      a.rdiag_l = a.sl_rd;
+      a.rloc_l = a.sl_rl;
+    }
     if (!c->sched) {
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->sched), 512));
       HIP_TRY(hipMemsetAsync(c->sched, 0, 512, c->stream));   // (later launches reset it themselves when they draw)
@@ -253,7 +269,7 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, int warm_run = 0, long warm_stride
     }
     HIP_TRY(letkf::launch_wave_kernel(a, c->num_cu, c->stream));
     c->last_path = "letkf_wave_kernel<KR=" + std::to_string(letkf::wave_kernel_kr(a.k)) + ",NV=" + std::to_string(a.nv) +
-                   ",NW=" + (a.k <= 62 ? "1" : "2") + (a.mode == 2 ? ",FUSED" : "") + ">";
+                   ",NW=" + (a.k <= 62 ? "1" : "2") + (a.mode == 2 ? ",FUSED" : a.mode == 3 ? ",FUSED: column survivors" : "") + ">";
 #ifdef LETKF_WAVE_PROF
     {
       unsigned long long h[26];
@@ -419,6 +435,7 @@ int letkf_ctx_destroy(letkf_ctx* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->staged_ws) (void)hipFree(c->staged_ws);
     if (c->list_ws) (void)hipFree(c->list_ws);
+    if (c->slot_ws) (void)hipFree(c->slot_ws);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   }
   delete c;
@@ -429,6 +446,10 @@ int letkf_ctx_set_option(letkf_ctx* c, int option, int value) {
   if (int rc = check_ctx(c)) return rc;
   switch (option) {
     case LETKF_OPT_STAGED_POLY: c->staged_poly = value != 0; return LETKF_OK;
+    case LETKF_OPT_COLUMN_SURVIVORS:
+      if (value < 0 || value > 2) return fail(LETKF_E_INVALID, "LETKF_OPT_COLUMN_SURVIVORS: 0, 1 or 2");
+      c->col_survivors = value;
+      return LETKF_OK;
     default: return fail(LETKF_E_INVALID, "unknown option");
   }
 }
@@ -536,8 +557,17 @@ int tables_limited(letkf_ctx* c, const letkf_search_tables* t, bool* limited) {
 }
 
 // shared by the list-driven and the fused-search entry
+// (mode 3, letkf_das_columns_dev's list-free route: the points are pt0 + a * pt_stride + b, b < g->warm_stride columns whose
+// horizontal survivors are sv[4 * sv_off[b] ..]; every per-point array of g is indexed by that GLOBAL point number)
+struct SurvivorView {
+  const int64_t* sv_off;
+  const double* sv;
+  int64_t pt_stride, pt0;
+  int64_t cap;               // most survivors of a column of the batch (bounds a point's local list)
+};
 int das_points_impl(letkf_ctx* c, const letkf_das_args* g, const letkf_search_tables* t, const double* ri,
-                    const double* rj, const double* rlev, const double* rz, int32_t* nobs_out) {
+                    const double* rj, const double* rlev, const double* rz, int32_t* nobs_out,
+                    const SurvivorView* sview = nullptr) {
   if (int rc = check_ctx(c)) return rc;
   if (!g) return fail(LETKF_E_INVALID, "args is NULL");
   if (g->npts == 0) return LETKF_OK;
@@ -586,7 +616,18 @@ int das_points_impl(letkf_ctx* c, const letkf_das_args* g, const letkf_search_ta
   a.nsweep = g->nsweep;
   a.rtps_out = g->rtps_infl_out;
   a.var_mask = g->var_mask ? g->var_mask : ~0u;
-  if (t) {
+  if (t && sview) {
+    a.mode = 3;
+    a.stab = *t;
+    a.prlev = rlev;
+    a.prz = rz;
+    a.nobs_out = nobs_out;
+    a.sv_off = reinterpret_cast<const long*>(sview->sv_off);
+    a.surv = sview->sv;
+    a.pt_stride = sview->pt_stride;
+    a.pt0 = sview->pt0;
+    a.sl_cap = (sview->cap + 3) & ~(int64_t)3;
+  } else if (t) {
     if (!ri || !rj || !rlev || !rz) return fail(LETKF_E_INVALID, "a point coordinate array is NULL");
     if (t->nctype < 1 || t->ngroup < 1) return fail(LETKF_E_INVALID, "bad nctype / ngroup");
     if (!letkf::wave_kernel_supports(g->k, g->nv, 2))
@@ -634,6 +675,69 @@ int letkf_das_columns_dev(letkf_ctx* c, const letkf_das_args* g, const letkf_sea
   if (g->trans_out || g->transm_out || g->pa_out) return fail(LETKF_E_INVALID, "per-point k x k / w-bar outputs: use letkf_das_points_dev");
   const int64_t npts = g->npts;
   if (list_bytes <= 0) list_bytes = (int64_t)8 << 30;
+  // ---- the list-free route: where the one-wave kernel serves the call and no combined type has a limit, the horizontal half of
+  // obs_local is done once per COLUMN (32 B per survivor) and the vertical half inside the loop body kernel -- no count pass
+  // over the levels, no 20 B per (point, observation) written and read back.  Same weights, same order, same analysis to the
+  // last bit as the lists give (tests/test_gpu_columns.py).  LETKF_OPT_COLUMN_SURVIVORS = 0 keeps the lists.
+  if (c->col_survivors && g->k >= 2 && letkf::wave_kernel_supports(g->k, g->nv, 3) && nij1 <= 0x7fffffff) {
+    if (t->nctype < 1 || t->ngroup < 1) return fail(LETKF_E_INVALID, "bad nctype / ngroup");
+    bool limited = false;
+    if (int rc = tables_limited(c, t, &limited)) return rc;
+    if (!limited) {
+      // workspace: counts [nij1 + 1] int32 | sv_off [nij1 + 1] int64 | scan scratch
+      size_t scan_b = 0;
+      {
+        auto in = rocprim::make_transform_iterator(static_cast<const int32_t*>(nullptr), [] __device__(int32_t v) { return (int64_t)v; });
+        HIP_TRY(rocprim::exclusive_scan(nullptr, scan_b, in, static_cast<int64_t*>(nullptr), (int64_t)0, (size_t)nij1 + 1,
+                                        rocprim::plus<int64_t>(), c->stream));
+      }
+      const size_t o_off = ((size_t)(nij1 + 1) * 4 + 255) & ~(size_t)255;
+      const size_t o_scan = o_off + (((size_t)(nij1 + 1) * 8 + 255) & ~(size_t)255);
+      if (o_scan + scan_b > c->scratch_bytes) HIP_TRY(hipStreamSynchronize(c->stream));
+      if (int rc = ensure_bytes(c, &c->scratch, &c->scratch_bytes, o_scan + scan_b + 256)) return rc;
+      int32_t* cnt = reinterpret_cast<int32_t*>(c->scratch);
+      int64_t* soff = reinterpret_cast<int64_t*>(c->scratch + o_off);
+      HIP_TRY(hipMemsetAsync(cnt + nij1, 0, 4, c->stream));
+      HIP_TRY(letkf::launch_survivors(*t, 0, nij1, rig, rjg, 0, cnt, nullptr, nullptr, c->num_cu, c->stream));
+      {
+        auto in = rocprim::make_transform_iterator(static_cast<const int32_t*>(cnt), [] __device__(int32_t v) { return (int64_t)v; });
+        HIP_TRY(rocprim::exclusive_scan(c->scratch + o_scan, scan_b, in, soff, (int64_t)0, (size_t)nij1 + 1, rocprim::plus<int64_t>(),
+                                        c->stream));
+      }
+      std::vector<int64_t> hoff((size_t)nij1 + 1);
+      HIP_TRY(hipMemcpyAsync(hoff.data(), soff, ((size_t)nij1 + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      // (2 = automatic: the list-free route where the lists of all levels would not fit the workspace at once -- about half
+      // of a column's horizontal survivors pass a level's vertical cut-off, 20 B each.  Where they fit, one fill pass for
+      // the whole domain is cheaper than the vertical half inside the register-bound loop body kernel: C2, 203 local
+      // observations per point, 386 against 394 ms per analysis; BASELINE configs[3], 4900 per point, 40 slabs: 7.45 against 6.26 s.)
+      const bool take = c->col_survivors == 1 || (double)hoff[nij1] * (double)nlev * 10.0 > (double)list_bytes;
+      // batches of columns whose survivors fit the workspace (32 B each), at least one column
+      int64_t c0 = take ? 0 : nij1;
+      while (c0 < nij1) {
+        int64_t c1 = c0 + 1;
+        while (c1 < nij1 && (hoff[c1 + 1] - hoff[c0]) * 32 <= list_bytes) ++c1;
+        const int64_t nsv = hoff[c1] - hoff[c0];
+        const size_t need = (size_t)(nsv > 0 ? nsv : 1) * 32 + 256;
+        if (need > c->list_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));   // (the previous batch's solve may still read the old buffer)
+        if (int rc = ensure_bytes(c, &c->list_ws, &c->list_ws_bytes, need)) return rc;
+        // entry e of column b is addressed as sv[4 * sv_off[b] + ...] with the GLOBAL offsets: shift the base
+        double* sv = reinterpret_cast<double*>(c->list_ws) - 4 * hoff[c0];
+        HIP_TRY(letkf::launch_survivors(*t, c0, c1 - c0, rig, rjg, 1, nullptr, reinterpret_cast<const long*>(soff + c0), sv, c->num_cu,
+                                        c->stream));
+        letkf_das_args a = *g;
+        a.npts = (c1 - c0) * (int64_t)nlev;
+        a.infl_sv = g->infl_sv > 0 ? g->infl_sv : npts;
+        a.warm_stride = (int32_t)(c1 - c0);                   // runs up the columns
+        int64_t cap = 0;
+        for (int64_t cc = c0; cc < c1; ++cc) cap = std::max(cap, hoff[cc + 1] - hoff[cc]);
+        SurvivorView sview{soff + c0, sv, nij1, c0, cap};
+        if (int rc = das_points_impl(c, &a, t, nullptr, nullptr, rlev, rz, nobs_out, &sview)) return rc;
+        c0 = c1;
+      }
+      if (take) return LETKF_OK;
+    }
+  }
   // workspace: counts [npts] int32 | obs_off [npts + 1] int64 | scan scratch
   size_t scan_bytes = 0;
   {

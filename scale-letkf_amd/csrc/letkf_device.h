@@ -77,7 +77,18 @@ struct PointArgs {
   // mode 2: the search tables and the points' coordinates (rig1, rjg1, p mean, hgt1)
   letkf_search_tables stab;
   const double *pri, *prj, *prlev, *prz;
-  int* nobs_out;       // [npts] local observation count (mode 2), or null
+  int* nobs_out;       // [npts] local observation count (modes 2, 3), or null
+  // mode 3: the horizontal survivors of each column (letkf_survivors_kernel): entry = 4 doubles (row | ctype << 32 as bits,
+  // nd_h, v_obs, err) in surv[], column b of this launch owns entries sv_off[b] .. sv_off[b + 1]; the points of the launch are
+  // p = pt0 + a * pt_stride + b, a < npts / warm_stride levels, b < warm_stride columns
+  const long* sv_off;
+  const double* surv;
+  long pt_stride, pt0; // (0, 0: p = a * warm_stride + b as in every other mode)
+  // ... and the per-wave slots of sl_cap entries in which a point's local list is assembled (obs_idx / rdiag_l / rloc_l point to
+  // the same arrays; slot = the wave's number in the grid)
+  int* sl_idx;
+  double *sl_rd, *sl_rl;
+  long sl_cap;
   // wave kernel: launch shape and warm-start workspace (wave_launch_shape)
   double* warm_ws;
   int run_len, wave_grid, warm_dbg;
@@ -150,6 +161,8 @@ struct SearchArgs {
   int limited;         // some max_nobs > 0 (host knowledge: sizes the LDS candidate cache)
 };
 hipError_t launch_search(const SearchArgs& a, int num_cu, hipStream_t st);
+hipError_t launch_survivors(const letkf_search_tables& t, long col0, long ncol, const double* rig, const double* rjg, int fill,
+                            int* counts, const long* sv_off, double* sv, int num_cu, hipStream_t st);
 hipError_t launch_search_columns(const letkf_search_tables& t, long nij1, int nlev, const double* rig,
                                  const double* rjg, const double* rlev, const double* rz, int fill, int* counts,
                                  const long* obs_off, int* obs_idx, double* rdiag_l, double* rloc_l, int* nobs_ctype,

@@ -1204,6 +1204,105 @@ hipError_t launch_search_columns_limited(const letkf_search_tables& t, long nij1
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ the horizontal half of obs_local, once per column
+// (the list-free route of letkf_das_columns_dev; the vertical half runs inside the loop body kernel, letkf_wave.hip mode 3).
+// One wave per column walks the rectangle of sorting-mesh cells of every combined type exactly like the column search and
+// keeps the rows inside the horizontal cut-off, in the reference's list order: entry = (row | ctype << 32 as bits, nd_h,
+// v_obs, err) with v_obs the observation's vertical coordinate in its ctype's mode (lev, ln lev, ln dat); the entries of a
+// type are padded to a multiple of 64.
+// FILL = false: counts[col] = survivors of the column; FILL = true: writes them at sv + 4 * sv_off[col].
+struct SurvArgs {
+  letkf_search_tables t;
+  long col0, ncol;       // columns col0 .. col0 + ncol of rig / rjg; counts / sv_off are indexed by the column's number in the call
+  const double *rig, *rjg;
+  int* counts;
+  const long* sv_off;
+  double* sv;
+};
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) letkf_survivors_kernel(const SurvArgs A) {
+#pragma clang fp contract(off)
+  const letkf_search_tables& t = A.t;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (long cb = (long)blockIdx.x * 4 + wv; cb < A.ncol; cb += (long)gridDim.x * 4) {
+    const long col = A.col0 + cb;
+    const double ri = A.rig[col], rj = A.rjg[col];
+    long ns = 0;
+    const long out = FILL ? A.sv_off[cb] : 0;
+    for (int m = 0; m < t.group_start[t.ngroup]; ++m) {
+      const int ic = t.group_member[m];
+      if (t.varloc[ic] < kTiny) continue;                         // local_cal :1843
+      const int vm = t.vmode[ic];
+      const double vloc = t.vert_loc[ic], hloc = t.hori_loc[ic];
+      const double dzi = hloc * kDistZeroFac / t.dx, dzj = hloc * kDistZeroFac / t.dy;
+      int imin, imax, jmin, jmax;
+      ij_obsgrd_ext(t, ic, ri - dzi, rj - dzj, imin, jmin);
+      ij_obsgrd_ext(t, ic, ri + dzi, rj + dzj, imax, jmax);
+      imin = max(imin, 1);
+      jmin = max(jmin, 1);
+      imax = min(imax, t.ngrdext_i[ic]);
+      jmax = min(jmax, t.ngrdext_j[ic]);
+      if (imin > imax || jmin > jmax) continue;
+      const long acb = t.ac_off[ic];
+      const int ld = t.ngrdext_i[ic] + 1;
+      for (int j = jmin; j <= jmax; ++j) {
+        const int lo = t.ac_ext[acb + (imin - 1) + (long)ld * (j - 1)];
+        const int hi = t.ac_ext[acb + imax + (long)ld * (j - 1)];
+        for (int base = lo; base < hi; base += 64) {
+          const int row = base + lane;
+          bool ok = false;
+          double nd_h = 0.0;
+          if (row < hi) {
+            const double rdx = (ri - t.ob_ri[row]) * t.dx;        // :1876-1878
+            const double rdy = (rj - t.ob_rj[row]) * t.dy;
+            nd_h = sqrt(rdx * rdx + rdy * rdy) / hloc;
+            ok = !(nd_h > kDistZeroFac);                          // :1881
+          }
+          const unsigned long long mk = __ballot(ok);
+          if (FILL && ok) {
+            double vobs = 0.0;
+            if (vloc != 0.0) {
+              if (vm == 1) vobs = t.ob_lev[row];
+              else if (vm == 2) vobs = log(t.ob_dat[row]);
+              else if (vm != 3) vobs = log(t.ob_lev[row]);
+            }
+            const long o = 4 * (out + ns + __popcll(mk & lt_mask));
+            const long rw = (long)row | ((long)ic << 32);
+            *reinterpret_cast<double2*>(&A.sv[o]) = double2{__longlong_as_double(rw), nd_h};
+            *reinterpret_cast<double2*>(&A.sv[o + 2]) = double2{vobs, t.ob_err[row]};
+          }
+          ns += __popcll(mk);
+        }
+      }
+      // every type's segment is padded to whole chunks of 64 entries (nd_h = 1e30: outside every cut-off), so that a chunk
+      // of the loop body kernel is of ONE type and reads the type's numbers through the scalar cache
+      const long npad = (64 - (ns & 63)) & 63;
+      if (FILL && lane < npad) {
+        const long o = 4 * (out + ns + lane);
+        *reinterpret_cast<double2*>(&A.sv[o]) = double2{__longlong_as_double((long)ic << 32), 1e30};
+        *reinterpret_cast<double2*>(&A.sv[o + 2]) = double2{0.0, 1.0};
+      }
+      ns += npad;
+    }
+    if (!FILL && lane == 0) A.counts[cb] = (int)ns;
+  }
+}
+
+hipError_t launch_survivors(const letkf_search_tables& t, long col0, long ncol, const double* rig, const double* rjg, int fill,
+                            int* counts, const long* sv_off, double* sv, int num_cu, hipStream_t st) {
+  if (ncol <= 0) return hipSuccess;
+  SurvArgs a{t, col0, ncol, rig, rjg, counts, sv_off, sv};
+  const long nwg = (ncol + 3) / 4;
+  const long g = (long)num_cu * 8;
+  const int grid = (int)(nwg < g ? nwg : g);
+  if (fill) hipLaunchKernelGGL(letkf_survivors_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(letkf_survivors_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_search_columns(const letkf_search_tables& t, long nij1, int nlev, const double* rig,
                                  const double* rjg, const double* rlev, const double* rz, int fill, int* counts,
                                  const long* obs_off, int* obs_idx, double* rdiag_l, double* rloc_l, int* nobs_ctype,

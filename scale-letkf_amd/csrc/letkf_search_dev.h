@@ -49,6 +49,30 @@ __device__ __forceinline__ CalOut local_cal_v(const letkf_search_tables& t, int 
   return o;
 }
 
+// The vertical half of obs_local_cal for an observation whose horizontal half is done (the column search: nd_h and the
+// observation's vertical coordinate v_obs -- lev, ln lev or ln dat by the ctype's mode -- are the same for every level of a
+// column).  v_z = the point's height, v_p = ln of its pressure, l_rain = ln VERT_LOCAL_RAIN_BASE.  rloc = 0: rejected.
+// Shared by the column search (lists) and the wave kernel's column-survivor mode (no lists): same weights to the last bit.
+struct ColVert {
+  double rloc, rdiag;
+};
+__device__ __forceinline__ ColVert column_vertical_cal(const int vm, const double vloc, const double varloc, const double nd_h,
+                                                const double v_obs, const double err, const double v_z, const double v_p,
+                                                const double l_rain) {
+#pragma clang fp contract(off)
+  ColVert o{0.0, 0.0};
+  double nd_v;
+  if (vloc == 0.0) nd_v = 0.0;                                 // :1851-1865
+  else if (vm == 3) nd_v = fabs(l_rain - v_p) / vloc;
+  else nd_v = fabs(v_obs - (vm == 1 ? v_z : v_p)) / vloc;
+  if (nd_v > kDistZeroFac) return o;                           // :1869
+  const double nd = nd_h * nd_h + nd_v * nd_v;                 // :1888
+  if (nd > kDistZeroFacSq) return o;                           // :1891
+  o.rloc = varloc * exp(-0.5 * nd);                            // :1899
+  o.rdiag = err * err / o.rloc;                                // :1903
+  return o;
+}
+
 __device__ __forceinline__ CalOut local_cal(const letkf_search_tables& t, int ic, double ri, double rj, double rlev,
                                             double rz, int row) {
   const int vm = t.vmode[ic];

@@ -553,7 +553,8 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
 
 // KKOUT: also materialise T / Pa (fine boundary, parity, diagnostics) -- a separate instantiation so that the
 // production kernel carries neither the code nor the registers for it.
-// FUSED: obs_local walked inside the kernel (mode 2) -- its own instantiation as well: carried by the list-driven kernel
+// FUSED = 2: obs_local walked inside the kernel (mode 2); FUSED = 3: the vertical half of obs_local on the column's horizontal
+// survivors (mode 3) -- instantiations of their own: carried by the list-driven kernel
 // the extra code cost 15 % of its speed (registers / instruction cache), measured.
 // Profiling build (make PROF=1): per-phase wave time from s_memtime, kept in SGPRs, summed over all waves.
 #ifdef LETKF_WAVE_PROF
@@ -576,7 +577,7 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
 #define PROF_UNIT
 #endif
 
-template <int KR, int NV, bool KKOUT, int NW, bool FUSED>
+template <int KR, int NV, bool KKOUT, int NW, int FUSED>
 __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER_SIMD(KR, NW)) ? 2 : 1) letkf_wave_kernel(const PointArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NB = NV + 2;
@@ -679,7 +680,10 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
    bool have_u = false;
    for (int ir = ir0; ir < ir1; ++ir) {
     if (ra0 + ir >= nA) break;
-    const long pt = (ra0 + ir) * S + rb;
+    long pt = (ra0 + ir) * S + rb;
+    if constexpr (FUSED == 3) {
+      if (A.pt_stride) pt = (ra0 + ir) * A.pt_stride + rb + A.pt0;   // mode 3: columns pt0 .. pt0 + S of a wider domain
+    }
     // Everything built from the lane number is the same for every point of the run, so hipcc hoists it out of this
     // loop -- dozens of LDS addresses -- cannot keep it in registers across the eigensolve, and reloads it from scratch
     // one dword at a time, each reload a round trip in front of its use.  Laundering the lane numbers keeps the address
@@ -690,12 +694,95 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
     long o0 = 0;
     int n = 0;
     double beta = 1.0;
-    const bool das = A.mode != 1;              // the das_letkf loop body (lists given: 0, search fused in: 2)
+    const bool das = A.mode != 1;              // the das_letkf loop body (lists given: 0, search fused in: 2, column survivors: 3)
     if (A.mode == 0) {
       o0 = A.obs_off[pt];
       n = (int)(A.obs_off[pt + 1] - o0);
       if (A.beta) beta = A.beta[pt];
-    } else if (FUSED && A.mode == 2) {
+    } else if (FUSED == 3 && A.mode == 3) {
+      if (A.beta) beta = A.beta[pt];
+      n = 0;
+      if constexpr (NW == 1 && FUSED == 3) {
+        // ---- column-survivor mode: the horizontal half of obs_local was done once per COLUMN (letkf_survivors_kernel: the
+        // rows inside the horizontal cut-off, in the reference's list order, with nd_h and their vertical coordinate); this
+        // point adds its vertical half (search_dev::column_vertical_cal -- the expressions of the column search, so the weights
+        // equal the lists' to the last bit) and leaves the accepted rows as a local list in this WAVE's slot of a small
+        // workspace (written, read back by the Gram phase below and overwritten by the next point: it lives in L2).  The
+        // lists of letkf_obs_search_columns_dev -- 20 B per (point, observation): 1 TB written and 1 TB read per analysis at
+        // BASELINE configs[3] -- never exist, nor does the count pass over the levels.  (First version: the accepted rows went
+        // straight into the Gram's staging buffer, flush and matrix-core steps inside this loop -- the four buffers and the
+        // evaluated chunks stayed live across them, 800 B/lane of scratch, slower than the lists.)
+        if (beta != 0.0) {
+          using namespace search_dev;
+          const letkf_search_tables& t = A.stab;
+          o0 = ((long)blockIdx.x * PPW + wv) * A.sl_cap;
+          const double v_z = A.prz[pt], v_p = log(A.prlev[pt]), l_rain = log(t.rain_base);
+          const unsigned long long lt_mask = (wlane == 0) ? 0ull : (~0ull >> (64 - wlane));
+          const long s_lo = A.sv_off[rb], s_hi = A.sv_off[rb + 1];
+          int ntot = 0;
+          if (s_hi > s_lo) {
+            // Four chunks of 64 entries in flight, in four buffers with STATIC names: the survivors stream from HBM (no wave
+            // reads a column's list while it is still in a cache: 320 KB per column at configs[3], 2048 columns in flight).
+            // Found in the ISA of the first versions: one chunk ahead = a full memory round trip per chunk; four ahead
+            // through a rotation of register copies (a0 = a1; ...) copies the destination of the load issued last --
+            // s_waitcnt vmcnt(0) in every iteration; and the 64-bit `entry + lane` offsets were hoisted out of the point
+            // loop, spilled, and their scratch_load -- which counts in vmcnt with the prefetches -- waited for everything in
+            // flight.  Hence: four evaluations written out, each refilling its own buffer right behind itself, 32-bit
+            // offsets from a laundered lane number, every load unconditional from a clamped address.
+            const int ns_col = (int)(s_hi - s_lo);                         // (a multiple of 64: the survivor kernel pads)
+            const double* sbase = A.surv + 4 * s_lo;
+            int wl = wlane;
+            asm volatile("" : "+v"(wl));
+            auto ld = [&](const int e0, double2& x, double2& y) {
+              int e = e0 + wl;
+              e = e < ns_col ? e : ns_col - 1;
+              x = *reinterpret_cast<const double2*>(&sbase[4 * e]);
+              y = *reinterpret_cast<const double2*>(&sbase[4 * e + 2]);
+            };
+            double2 a0, b0, a1, b1, a2, b2, a3, b3;
+            ld(0, a0, b0);
+            ld(64, a1, b1);
+            ld(128, a2, b2);
+            ld(192, a3, b3);
+            // the ctype's three numbers through the scalar cache (a chunk is of ONE type: the survivor kernel pads every type's
+            // entries to whole chunks with rows outside every cut-off)
+            int ic_s = -1, vm_s = 0;
+            double vloc_s = 0.0, varloc_s = 0.0;
+            auto eval = [&](const double2& ca, const double2& cb, const bool live) {
+              const long rw = __double_as_longlong(ca.x);
+              const int ic0 = __builtin_amdgcn_readfirstlane((int)(rw >> 32));
+              if (ic0 != ic_s) {
+                ic_s = ic0;
+                vm_s = t.vmode[ic0];
+                vloc_s = t.vert_loc[ic0];
+                varloc_s = t.varloc[ic0];
+              }
+              const ColVert vo = column_vertical_cal(vm_s, vloc_s, varloc_s, ca.y, cb.x, cb.y, v_z, v_p, l_rain);
+              const bool acc_ = live && vo.rloc != 0.0;                      // :1460
+              const unsigned long long mk = __ballot(acc_);
+              if (acc_) {
+                const long j = o0 + ntot + __popcll(mk & lt_mask);
+                A.sl_idx[j] = (int)(rw & 0xffffffffL);
+                A.sl_rd[j] = vo.rdiag;
+                A.sl_rl[j] = vo.rloc;
+              }
+              ntot += __popcll(mk);
+            };
+            for (int g0 = 0; g0 < ns_col; g0 += 256) {
+              eval(a0, b0, true);
+              ld(g0 + 256, a0, b0);
+              eval(a1, b1, g0 + 64 < ns_col);
+              ld(g0 + 320, a1, b1);
+              eval(a2, b2, g0 + 128 < ns_col);
+              ld(g0 + 384, a2, b2);
+              eval(a3, b3, g0 + 192 < ns_col);
+              ld(g0 + 448, a3, b3);
+            }
+          }
+          n = ntot;
+        }
+      }
+    } else if (FUSED == 2 && A.mode == 2) {
       n = -1;                                  // known after the kernel's own walk over the sorting mesh
       if (A.beta) beta = A.beta[pt];
     } else {
@@ -874,12 +961,12 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
         }
       };
 
-      if (FUSED && A.mode == 2) {
+      if (FUSED == 2 && A.mode == 2) {
         // ---- obs_local fused in (no-limit mode, scale/letkf/letkf_tools.f90:1438-1476): walk the rectangle of
         // sorting-mesh cells of every observation type exactly like letkf_search_kernel, evaluate obs_local_cal per
         // lane for 64 candidate rows at a time, and append the accepted ones (ballot + prefix popcount: the
         // reference's list order) straight to the staging buffer -- the local list never exists in memory.
-        if constexpr (NW == 1 && FUSED) {
+        if constexpr (NW == 1 && FUSED == 2) {
           using namespace search_dev;
           const letkf_search_tables& t = A.stab;
           const double ri = A.pri[pt], rj = A.prj[pt], rlev = A.prlev[pt], rz = A.prz[pt];
@@ -1596,7 +1683,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
 }
 
 // ------------------------------------------------------------------ host launcher
-template <int KR, int NV, bool KKOUT, int NW, bool FUSED = false>
+template <int KR, int NV, bool KKOUT, int NW, int FUSED = 0>
 static hipError_t launch_wave(const PointArgs& a, int num_cu, hipStream_t st) {
   const size_t lds = (size_t)(NW == 1 ? 4 : 1) * wave_slice_doubles(KR, NV, NW) * sizeof(double);
   if (a.k < wave_kmin(KR, NW) || a.k > KR) return hipErrorInvalidValue;   // the Gram assumes its full member blocks
@@ -1654,7 +1741,7 @@ bool wave_kernel_supports(int k, int nv, int mode) {
   // one wave per point up to k = 62 (k + 2 augmented Gram columns in 64 lanes); two waves for 63..100 (at k >= 65 the
   // half-columns no longer fit the 256 VALU-addressable VGPRs three times over and part of them lives in AGPRs)
   if (k > 100) return false;
-  if (mode == 2) return nv == 11 && k <= 62;   // the fused search is written for one wave per point
+  if (mode == 2 || mode == 3) return nv == 11 && k <= 62;   // the fused search / the column-survivor mode are written for one wave per point
   if (mode == 0) return nv == 11;
   return nv == 0;
 }
@@ -1709,7 +1796,8 @@ hipError_t launch_wave_kernel_two(const PointArgs& a, int num_cu, hipStream_t st
 #define LETKF_WAVE_CASE(KR, NW)                                                                                 \
   if (k <= (NW == 1 ? (KR < 62 ? KR : 62) : KR)) {                                                              \
     if constexpr (NW == 1) {                                                                                    \
-      if (a.mode == 2) return launch_wave<KR, 11, false, NW, true>(a, num_cu, st);                              \
+      if (a.mode == 2) return launch_wave<KR, 11, false, NW, 2>(a, num_cu, st);                                 \
+      if (a.mode == 3) return launch_wave<KR, 11, false, NW, 3>(a, num_cu, st);                                 \
     }                                                                                                           \
     if (a.mode != 1)                                                                                            \
       return kkout ? launch_wave<KR, 11, true, NW>(a, num_cu, st) : launch_wave<KR, 11, false, NW>(a, num_cu, st); \

@@ -35,21 +35,92 @@ def test_column_pipeline_equals_search_plus_loop_body(name, list_mb):
     off, idx, rd, rl = cx.obs_search_columns(t_s, nij1, nlev, rig, rjg, pts[2], pts[3])
     cx.das_points(k, nv, off, idx, rd, rl, ens, w["kld"], dep, i0, w["gues"], a0, 1, npts, npts * nens, status=s0,
                   rtps_infl_out=r0, **sw)
-    # one call, lists by slabs inside the library
-    a1, i1, s1, r1 = fresh()
-    nobs = torch.full((npts,), -7, dtype=torch.int32, device=dev)
-    cx.das_columns(k, nv, t_s, nij1, nlev, rig, rjg, pts[2], pts[3], ens, w["kld"], dep, i1, w["gues"], a1, 1, npts, npts * nens,
-                   list_bytes=int(list_mb * 2 ** 20), nobs_out=nobs, status=s1, rtps_infl_out=r1, **sw)
-    torch.cuda.synchronize()
-    assert int(s0.abs().max()) == 0 and int(s1.abs().max()) == 0
-    assert torch.equal(nobs.long(), off[1:] - off[:-1])
-    g0 = a0.view(nv, nens, npts)
-    g1 = a1.view(nv, nens, npts)
+    # one call: the list-free route (survivors per column, batches of columns) where the one-wave kernel serves the call, and
+    # the lists by slabs of levels inside the library (LETKF_OPT_COLUMN_SURVIVORS = 0; k = 100 takes them anyway)
+    for survivors in (1, 0):
+        a1, i1, s1, r1 = fresh()
+        nobs = torch.full((npts,), -7, dtype=torch.int32, device=dev)
+        cx.set_option(cx.OPT_COLUMN_SURVIVORS, survivors)
+        try:
+            cx.das_columns(k, nv, t_s, nij1, nlev, rig, rjg, pts[2], pts[3], ens, w["kld"], dep, i1, w["gues"], a1, 1, npts,
+                           npts * nens, list_bytes=int(list_mb * 2 ** 20), nobs_out=nobs, status=s1, rtps_infl_out=r1, **sw)
+            torch.cuda.synchronize()
+        finally:
+            cx.set_option(cx.OPT_COLUMN_SURVIVORS, 2)
+        assert ("FUSED" in cx.last_path()) == (survivors == 1 and k <= 62), cx.last_path()
+        assert int(s0.abs().max()) == 0 and int(s1.abs().max()) == 0
+        assert torch.equal(nobs.long(), off[1:] - off[:-1])
+        g0 = a0.view(nv, nens, npts)
+        g1 = a1.view(nv, nens, npts)
+        x = w["gues"].view(nv, nens, npts)
+        members = list(range(k)) + [k + 1]
+        for v in range(nv):
+            scale = float(max(x[v, k].abs().max(), x[v, :k].abs().max()))
+            assert float((g0[v, members] - g1[v, members]).abs().max()) <= 1e-11 * scale, v
+        assert float((i0 - i1).abs().max()) <= 1e-12
+        assert float((r0 - r1).abs().max()) <= 1e-11
+        assert bool(torch.isnan(g1[:, k]).all())              # the mean slot is not the loop body's to write
+
+
+@pytest.mark.parametrize("name", ["C2-mini", "C2-mini-disc", "C2-mini-k20"])
+def test_list_free_route_equals_the_lists_bit_for_bit(name):
+    """Same runs (up whole columns), same weights (search_dev::column_vertical_cal is the column search's arithmetic), same order
+    of the local observations: the analysis of the list-free route IS the list route's, to the last bit."""
+    import bench_workload as bw
+    from _gpu import ctx, pkg
+    dev = torch.device("cuda:0")
+    w = bw.build(name, dev)
+    k, nv, npts, nens = w["k"], w["nv"], w["npts"], w["nens"]
+    nij1, nlev = w["cfg"]["nx"] * w["cfg"]["ny"], w["cfg"]["nz"]
+    cx = ctx()
+    cx.ens_mean(k, nv, npts, w["gues"], 1, npts, npts * nens)
+    cx.to_perturbations(k, nv, npts, w["gues"], 1, npts, npts * nens)
+    t_s, keep, order, pts = bw.search_tables(w, pkg, dev)
+    ens, dep = w["ensval"][order].contiguous(), w["dep"][order].contiguous()
+    rig, rjg = pts[0][:nij1].contiguous(), pts[1][:nij1].contiguous()
+    off, idx, rd, rl = cx.obs_search_columns(t_s, nij1, nlev, rig, rjg, pts[2], pts[3])
+    a0 = torch.full_like(w["gues"], float("nan"))
+    i0 = torch.ones(npts * nv, dtype=torch.float64, device=dev)
+    cx.das_points(k, nv, off, idx, rd, rl, ens, w["kld"], dep, i0, w["gues"], a0, 1, npts, npts * nens, relax_alpha_spread=0.95,
+                  warm_stride=nij1)
+    a1 = torch.full_like(w["gues"], float("nan"))
+    i1 = torch.ones(npts * nv, dtype=torch.float64, device=dev)
+    cx.set_option(cx.OPT_COLUMN_SURVIVORS, 1)
+    try:
+        cx.das_columns(k, nv, t_s, nij1, nlev, rig, rjg, pts[2], pts[3], ens, w["kld"], dep, i1, w["gues"], a1, 1, npts,
+                       npts * nens, list_bytes=1 << 34, relax_alpha_spread=0.95)
+        torch.cuda.synchronize()
+    finally:
+        cx.set_option(cx.OPT_COLUMN_SURVIVORS, 2)
+    assert "FUSED" in cx.last_path()
+    g0, g1 = a0.view(nv, nens, npts)[:, :k], a1.view(nv, nens, npts)[:, :k]
+    assert torch.equal(g0, g1)
+
+
+def test_the_route_is_chosen_by_the_size_of_the_lists():
+    """LETKF_OPT_COLUMN_SURVIVORS = 2 (default): lists where they fit list_bytes at once, the list-free route where they do not."""
+    import bench_workload as bw
+    from _gpu import ctx, pkg
+    dev = torch.device("cuda:0")
+    w = bw.build("C2-mini", dev)
+    k, nv, npts, nens = w["k"], w["nv"], w["npts"], w["nens"]
+    nij1, nlev = w["cfg"]["nx"] * w["cfg"]["ny"], w["cfg"]["nz"]
+    cx = ctx()
+    cx.ens_mean(k, nv, npts, w["gues"], 1, npts, npts * nens)
+    cx.to_perturbations(k, nv, npts, w["gues"], 1, npts, npts * nens)
+    t_s, keep, order, pts = bw.search_tables(w, pkg, dev)
+    ens, dep = w["ensval"][order].contiguous(), w["dep"][order].contiguous()
+    rig, rjg = pts[0][:nij1].contiguous(), pts[1][:nij1].contiguous()
+    res = []
+    for lb, fused in ((1 << 34, False), (1 << 20, True)):
+        a1 = torch.full_like(w["gues"], float("nan"))
+        i1 = torch.ones(npts * nv, dtype=torch.float64, device=dev)
+        cx.das_columns(k, nv, t_s, nij1, nlev, rig, rjg, pts[2], pts[3], ens, w["kld"], dep, i1, w["gues"], a1, 1, npts, npts * nens,
+                       list_bytes=lb, relax_alpha_spread=0.95)
+        torch.cuda.synchronize()
+        assert ("FUSED" in cx.last_path()) == fused, (lb, cx.last_path())
+        res.append(a1.view(nv, nens, npts)[:, :k].clone())
     x = w["gues"].view(nv, nens, npts)
-    members = list(range(k)) + [k + 1]
     for v in range(nv):
         scale = float(max(x[v, k].abs().max(), x[v, :k].abs().max()))
-        assert float((g0[v, members] - g1[v, members]).abs().max()) <= 1e-11 * scale, v
-    assert float((i0 - i1).abs().max()) <= 1e-12
-    assert float((r0 - r1).abs().max()) <= 1e-11
-    assert bool(torch.isnan(g1[:, k]).all())              # the mean slot is not the loop body's to write
+        assert float((res[0][v] - res[1][v]).abs().max()) <= 1e-11 * scale
