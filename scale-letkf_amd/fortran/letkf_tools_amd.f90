@@ -52,7 +52,7 @@ MODULE letkf_tools_amd
     INTEGER :: nlong = 0, nlatg = 0           ! global interior size
     REAL(r_size) :: i_org = 0.0d0, j_org = 0.0d0   ! ri - i_org = ril - IHALO - 0.5 of ij_obsgrd_ext (letkf_obs.f90:1221)
     INTEGER :: iv3d_p = 5, iv3d_q = 6, iv3d_qlast = 11   ! 1-based (common_scale.f90:36-51)
-    INTEGER(c_int64_t) :: list_bytes = 0                 ! device workspace for the local-observation lists of a slab of levels (0: 8 GiB)
+    INTEGER(c_int64_t) :: list_bytes = 0                 ! device workspace for the local-observation lists of a slab of levels, or -- list-free route, include/letkf_amd.h (3c) -- the horizontal survivors of a batch of columns (0: 8 GiB)
     REAL(r_size), ALLOCATABLE :: var_local(:, :)          ! (nv3d, 9)
     INTEGER, ALLOCATABLE :: ctype_merge(:, :)             ! (nid_obs, nobtype), > 0 = merge class (:167-178)
   END TYPE letkf_das_nml
