@@ -171,8 +171,8 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return None
-    if args.max_nobs > 0 and args.lists not in ("columns", "search"):
-        sys.exit("--max-nobs needs --lists columns or search (the device obs_local)")
+    if args.max_nobs > 0 and args.lists not in ("columns", "search", "pipeline"):
+        sys.exit("--max-nobs needs --lists columns, search or pipeline (the device obs_local)")
     slab_mode = args.level_slab > 0
     if slab_mode and (args.lists != "columns" or args.no_search_in_step or world > 1 or args.state_layout != "ref"):
         sys.exit("--level-slab: the column search inside the step, one GPU, the reference's state layout")

@@ -201,6 +201,7 @@ class Context:
 
     OPT_STAGED_POLY = 1     # include/letkf_amd.h LETKF_OPT_STAGED_POLY
     OPT_COLUMN_SURVIVORS = 2   # LETKF_OPT_COLUMN_SURVIVORS
+    OPT_LIMITED_RINGS = 3      # LETKF_OPT_LIMITED_RINGS
 
     def set_option(self, option, value):
         self._check(self._l.letkf_ctx_set_option(self._c, C.c_int(option), C.c_int(value)))

@@ -56,6 +56,14 @@ struct letkf_ctx {
   size_t list_ws_bytes = 0;
   char* slot_ws = nullptr;    // ... its list-free route: one local list per resident wave
   size_t slot_ws_bytes = 0;
+  char* ring_ws = nullptr;    // limited column search on dense observations: ring-ordered survivors of a batch of columns
+  size_t ring_ws_bytes = 0;
+  char* ring_aux = nullptr;   // ... their counts / offsets / ring starts
+  size_t ring_aux_bytes = 0;
+  bool ring_keep = false;     // inside letkf_das_columns_dev: the survivors of the first search call serve the later ones
+  bool ring_ready = false;
+  std::vector<int64_t> ring_hoff;
+  int limited_rings = 2;      // LETKF_OPT_LIMITED_RINGS: 0 never, 1 wherever eligible, 2 where a group's survivors overflow the column kernel's buffer
   char* staged_ws = nullptr;  // staged path: per-point slabs of a batch + meta / info words
   size_t staged_ws_bytes = 0;
   std::string last_path;      // kernels the last loop-body / letkf_core launch went through (bench.py reports it)
@@ -436,6 +444,8 @@ int letkf_ctx_destroy(letkf_ctx* c) {
     if (c->staged_ws) (void)hipFree(c->staged_ws);
     if (c->list_ws) (void)hipFree(c->list_ws);
     if (c->slot_ws) (void)hipFree(c->slot_ws);
+    if (c->ring_ws) (void)hipFree(c->ring_ws);
+    if (c->ring_aux) (void)hipFree(c->ring_aux);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   }
   delete c;
@@ -446,6 +456,10 @@ int letkf_ctx_set_option(letkf_ctx* c, int option, int value) {
   if (int rc = check_ctx(c)) return rc;
   switch (option) {
     case LETKF_OPT_STAGED_POLY: c->staged_poly = value != 0; return LETKF_OK;
+    case LETKF_OPT_LIMITED_RINGS:
+      if (value < 0 || value > 2) return fail(LETKF_E_INVALID, "LETKF_OPT_LIMITED_RINGS: 0, 1 or 2");
+      c->limited_rings = value;
+      return LETKF_OK;
     case LETKF_OPT_COLUMN_SURVIVORS:
       if (value < 0 || value > 2) return fail(LETKF_E_INVALID, "LETKF_OPT_COLUMN_SURVIVORS: 0, 1 or 2");
       c->col_survivors = value;
@@ -738,6 +752,12 @@ int letkf_das_columns_dev(letkf_ctx* c, const letkf_das_args* g, const letkf_sea
       if (take) return LETKF_OK;
     }
   }
+  // (the searches below -- one count pass, a fill pass per slab -- share the ring-ordered survivors of the dense limited case)
+  struct RingKeep {
+    letkf_ctx* c;
+    explicit RingKeep(letkf_ctx* c_) : c(c_) { c->ring_keep = true; c->ring_ready = false; }
+    ~RingKeep() { c->ring_keep = false; c->ring_ready = false; }
+  } ring_keep_guard(c);
   // workspace: counts [npts] int32 | obs_off [npts + 1] int64 | scan scratch
   size_t scan_bytes = 0;
   {
@@ -856,6 +876,96 @@ int letkf_obs_search_dev(letkf_ctx* c, const letkf_search_tables* t, int64_t npt
   return LETKF_OK;
 }
 
+namespace {
+// The limited column search on DENSE observations (letkf_search.hip, rings).  *taken = false: not eligible / not dense -- the
+// caller goes on with the LDS-buffered column kernel.
+int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij1, int32_t nlev, const double* rig,
+                         const double* rjg, const double* rlev, const double* rz, int32_t fill, int32_t* counts,
+                         const int64_t* obs_off, int32_t* obs_idx, double* rdiag_l, double* rloc_l, int32_t* nobs_ctype,
+                         double* cutd_ctype, bool* taken) {
+  *taken = false;
+  if (c->limited_rings == 0 || t->criterion != 1 || t->nctype > 64 || nij1 * (int64_t)t->ngroup >= 0x7fffffff) return LETKF_OK;
+  std::vector<int32_t> mx(t->nctype), gstart(t->ngroup + 1);
+  HIP_TRY(hipMemcpyAsync(gstart.data(), t->group_start, sizeof(int32_t) * (t->ngroup + 1), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(mx.data(), t->max_nobs, sizeof(int32_t) * t->nctype, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  std::vector<int32_t> gmem(gstart[t->ngroup]);
+  HIP_TRY(hipMemcpy(gmem.data(), t->group_member, sizeof(int32_t) * gmem.size(), hipMemcpyDeviceToHost));
+  int nlim = 0;
+  for (int g = 0; g < t->ngroup; ++g) {
+    const int nm = mx[gmem[gstart[g]]];
+    if (nm > letkf::search_rings_max_nobs()) return LETKF_OK;
+    nlim += nm > 0;
+  }
+  if (nlim == 0) return LETKF_OK;
+  const int ng = t->ngroup;
+  const size_t ncg = (size_t)nij1 * ng;
+  // aux: counts [ncg + 1] int32 | goff [ncg + 1] int64 | scan scratch | roff [batch]
+  size_t scan_b = 0;
+  {
+    auto in = rocprim::make_transform_iterator(static_cast<const int32_t*>(nullptr), [] __device__(int32_t v) { return (int64_t)v; });
+    HIP_TRY(rocprim::exclusive_scan(nullptr, scan_b, in, static_cast<int64_t*>(nullptr), (int64_t)0, ncg + 1, rocprim::plus<int64_t>(),
+                                    c->stream));
+  }
+  const size_t o_off = ((ncg + 1) * 4 + 255) & ~(size_t)255, o_scan = o_off + (((ncg + 1) * 8 + 255) & ~(size_t)255);
+  const size_t o_roff = o_scan + ((scan_b + 255) & ~(size_t)255);
+  const size_t roff_b = ncg * (size_t)(16 + 1) * 4;
+  const size_t need_aux = o_roff + roff_b + 256;
+  if (need_aux > c->ring_aux_bytes) HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc = ensure_bytes(c, &c->ring_aux, &c->ring_aux_bytes, need_aux)) return rc;
+  int32_t* cnt = reinterpret_cast<int32_t*>(c->ring_aux);
+  int64_t* goff = reinterpret_cast<int64_t*>(c->ring_aux + o_off);
+  int32_t* roff = reinterpret_cast<int32_t*>(c->ring_aux + o_roff);
+  if (c->ring_keep && c->ring_ready) {
+    // (a later call of the same letkf_das_columns_dev: same tables, same columns -- the ring-ordered survivors are still there)
+    *taken = true;
+    HIP_TRY(letkf::launch_search_rings(*t, 0, nij1, nij1, nlev, rlev, rz, fill, counts, reinterpret_cast<const long*>(obs_off), obs_idx,
+                                       rdiag_l, rloc_l, nobs_ctype, cutd_ctype, reinterpret_cast<const long*>(goff),
+                                       reinterpret_cast<double*>(c->ring_ws), roff, c->num_cu, c->stream));
+    return LETKF_OK;
+  }
+  HIP_TRY(hipMemsetAsync(cnt + ncg, 0, 4, c->stream));
+  HIP_TRY(letkf::launch_ring_survivors(*t, 0, nij1, rig, rjg, 0, cnt, nullptr, nullptr, nullptr, c->num_cu, c->stream));
+  {
+    auto in = rocprim::make_transform_iterator(static_cast<const int32_t*>(cnt), [] __device__(int32_t v) { return (int64_t)v; });
+    HIP_TRY(rocprim::exclusive_scan(c->ring_aux + o_scan, scan_b, in, goff, (int64_t)0, ncg + 1, rocprim::plus<int64_t>(), c->stream));
+  }
+  std::vector<int64_t> hoff(ncg + 1);
+  HIP_TRY(hipMemcpyAsync(hoff.data(), goff, (ncg + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->limited_rings == 2) {
+    // dense = the survivors of the limited groups overflow the column kernel's LDS buffer on average: below that the
+    // LDS-buffered kernel (everything of a column resident, all levels against it) is the faster one
+    double lim_surv = 0.0;
+    for (size_t i = 0; i < ncg; ++i)
+      if (mx[gmem[gstart[i % ng]]] > 0) lim_surv += (double)(hoff[i + 1] - hoff[i]);
+    if (lim_surv <= 0.75 * (double)letkf::search_rings_lds_survivors() * (double)nij1 * (double)nlim) return LETKF_OK;
+  }
+  *taken = true;
+  // 8 GiB of survivors per batch of columns; inside letkf_das_columns_dev up to 64 GiB in ONE batch, kept for the calls that follow
+  const bool keep = c->ring_keep && hoff[ncg] * 32 <= ((int64_t)64 << 30);
+  const int64_t budget = keep ? ((int64_t)64 << 30) : ((int64_t)8 << 30);
+  int64_t c0 = 0;
+  while (c0 < nij1) {
+    int64_t c1 = c0 + 1;
+    while (c1 < nij1 && (hoff[(size_t)(c1 + 1) * ng] - hoff[(size_t)c0 * ng]) * 32 <= budget) ++c1;
+    const int64_t nsv = hoff[(size_t)c1 * ng] - hoff[(size_t)c0 * ng];
+    const size_t need = (size_t)(nsv > 0 ? nsv : 1) * 32 + 256;
+    if (need > c->ring_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = ensure_bytes(c, &c->ring_ws, &c->ring_ws_bytes, need)) return rc;
+    double* sv = reinterpret_cast<double*>(c->ring_ws) - 4 * hoff[(size_t)c0 * ng];
+    const long* gq = reinterpret_cast<const long*>(goff + (size_t)c0 * ng);
+    int32_t* rq = roff + (size_t)c0 * ng * 17;
+    HIP_TRY(letkf::launch_ring_survivors(*t, c0, c1 - c0, rig, rjg, 1, nullptr, gq, sv, rq, c->num_cu, c->stream));
+    HIP_TRY(letkf::launch_search_rings(*t, c0, c1 - c0, nij1, nlev, rlev, rz, fill, counts, reinterpret_cast<const long*>(obs_off),
+                                       obs_idx, rdiag_l, rloc_l, nobs_ctype, cutd_ctype, gq, sv, rq, c->num_cu, c->stream));
+    c0 = c1;
+  }
+  c->ring_ready = keep;
+  return LETKF_OK;
+}
+}  // namespace
+
 int letkf_obs_search_columns_dev(letkf_ctx* c, const letkf_search_tables* t, int64_t nij1, int32_t nlev,
                                  const double* rig, const double* rjg, const double* rlev, const double* rz,
                                  int32_t fill, int32_t* counts, const int64_t* obs_off, int32_t* obs_idx,
@@ -873,6 +983,13 @@ int letkf_obs_search_columns_dev(letkf_ctx* c, const letkf_search_tables* t, int
     return fail(LETKF_E_INVALID, "too many levels for the column kernel's LDS counters");
   bool limited = false;
   if (int rc = tables_limited(c, t, &limited)) return rc;
+  if (limited) {
+    bool taken = false;
+    if (int rc = search_columns_rings(c, t, nij1, nlev, rig, rjg, rlev, rz, fill, counts, obs_off, obs_idx, rdiag_l, rloc_l,
+                                      nobs_ctype, cutd_ctype, &taken))
+      return rc;
+    if (taken) return LETKF_OK;
+  }
   if (limited || cutd_ctype)
     HIP_TRY(letkf::launch_search_columns_limited(*t, nij1, nlev, rig, rjg, rlev, rz, fill, counts,
                                                  reinterpret_cast<const long*>(obs_off), obs_idx, rdiag_l, rloc_l,

@@ -1204,6 +1204,399 @@ hipError_t launch_search_columns_limited(const letkf_search_tables& t, long nij1
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ MAX_NOBS_PER_GRID on DENSE observations: rings
+// The column kernel above buffers a group's horizontal survivors in LDS (kSurvL = 576) and falls back to a per-point
+// multi-sweep radix select when they do not fit -- ten walks over the sorting mesh per (point, group).  BASELINE configs[3]
+// with the reference's usual MAX_NOBS_PER_GRID = 100 has ~5000 survivors per column and group: 55 s of obs_local per analysis
+// for a loop body of 1.3 s.  For the distance criterion the selection key is nd = nd_h^2 + nd_v^2 >= nd_h^2, so the survivors of
+// a (column, group) are kept in global memory ORDERED BY RINGS of nd_h^2 (kRings equal steps up to the cut-off): a level takes
+// them tile by tile, nearest ring first, carries the best nmax found so far along, and stops as soon as the nmax-th best key
+// is below the lower bound of the next ring -- at configs[3] after the two innermost rings of sixteen.  Exact: the selected
+// SET is the reference's (up to ties of equal keys, as everywhere), nobsl_t and the cut-off measure likewise.
+constexpr int kRings = 16;
+constexpr double kRingScale = (double)kRings / 13.5;    // ring = min(kRings - 1, (int)(nd_h^2 * kRingScale)); 13.5 > dist_zero_fac^2
+
+struct RingBuildArgs {
+  letkf_search_tables t;
+  long col0, ncol;
+  const double *rig, *rjg;
+  int* counts;           // FILL = 0: [ncol * ngroup] survivors per (column, group)
+  const long* goff;      // FILL = 1: [ncol * ngroup + 1] entry offsets (absolute), group-fastest
+  double* sv;            // entries: (row | ctype << 32 as bits, nd_h, v_obs, err)
+  int* roff;             // FILL = 1: [ncol * ngroup][kRings + 1] ring starts relative to the (column, group)'s first entry
+};
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) letkf_ring_survivors_kernel(const RingBuildArgs A) {
+#pragma clang fp contract(off)
+  __shared__ int rpos_all[4][kRings + 1];
+  const letkf_search_tables& t = A.t;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int* rpos = rpos_all[wv];
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (long cb = (long)blockIdx.x * 4 + wv; cb < A.ncol; cb += (long)gridDim.x * 4) {
+    const long col = A.col0 + cb;
+    const double ri = A.rig[col], rj = A.rjg[col];
+    for (int ig = 0; ig < t.ngroup; ++ig) {
+      const int gs = t.group_start[ig], ge = t.group_start[ig + 1];
+      const bool ringed = t.max_nobs[t.group_member[gs]] > 0;      // (an unlimited group stays in the list order: one ring)
+      // walk(what): 0 count, 1 ring histogram, 2 placement
+      auto walk = [&](const int what, const long out) -> long {
+        long ns = 0;
+        for (int m = gs; m < ge; ++m) {
+          const int ic = t.group_member[m];
+          if (t.varloc[ic] < kTiny) continue;                       // local_cal :1843
+          const int vm = t.vmode[ic];
+          const double vloc = t.vert_loc[ic], hloc = t.hori_loc[ic];
+          const double dzi = hloc * kDistZeroFac / t.dx, dzj = hloc * kDistZeroFac / t.dy;
+          int imin, imax, jmin, jmax;
+          ij_obsgrd_ext(t, ic, ri - dzi, rj - dzj, imin, jmin);
+          ij_obsgrd_ext(t, ic, ri + dzi, rj + dzj, imax, jmax);
+          imin = max(imin, 1);
+          jmin = max(jmin, 1);
+          imax = min(imax, t.ngrdext_i[ic]);
+          jmax = min(jmax, t.ngrdext_j[ic]);
+          if (imin > imax || jmin > jmax) continue;
+          const long acb = t.ac_off[ic];
+          const int ld = t.ngrdext_i[ic] + 1;
+          for (int j = jmin; j <= jmax; ++j) {
+            const int lo = t.ac_ext[acb + (imin - 1) + (long)ld * (j - 1)];
+            const int hi = t.ac_ext[acb + imax + (long)ld * (j - 1)];
+            for (int base = lo; base < hi; base += 64) {
+              const int row = base + lane;
+              bool ok = false;
+              double nd_h = 0.0;
+              if (row < hi) {
+                const double rdx = (ri - t.ob_ri[row]) * t.dx;      // :1876-1878
+                const double rdy = (rj - t.ob_rj[row]) * t.dy;
+                nd_h = sqrt(rdx * rdx + rdy * rdy) / hloc;
+                ok = !(nd_h > kDistZeroFac);                        // :1881
+              }
+              const unsigned long long mk = __ballot(ok);
+              if (what != 0 && mk) {
+                const int ring = ringed ? min(kRings - 1, (int)(nd_h * nd_h * kRingScale)) : 0;
+                // lane order inside a ring: deterministic positions (an LDS atomic per lane would scatter them run by run)
+                for (int r = 0; r < kRings; ++r) {
+                  const unsigned long long mr = __ballot(ok && ring == r);
+                  if (!mr) continue;
+                  const int b0 = rpos[r];
+                  if (what == 2 && ok && ring == r) {
+                    double vobs = 0.0;
+                    if (vloc != 0.0) {
+                      if (vm == 1) vobs = t.ob_lev[row];
+                      else if (vm == 2) vobs = log(t.ob_dat[row]);
+                      else if (vm != 3) vobs = log(t.ob_lev[row]);
+                    }
+                    const long o = 4 * (out + b0 + __popcll(mr & lt_mask));
+                    *reinterpret_cast<double2*>(&A.sv[o]) = double2{__longlong_as_double((long)row | ((long)ic << 32)), nd_h};
+                    *reinterpret_cast<double2*>(&A.sv[o + 2]) = double2{vobs, t.ob_err[row]};
+                  }
+                  wave_lds_sync();
+                  if (lane == 0) rpos[r] = b0 + __popcll(mr);
+                  wave_lds_sync();
+                }
+              }
+              ns += __popcll(mk);
+            }
+          }
+        }
+        return ns;
+      };
+      if (!FILL) {
+        const long ns = walk(0, 0);
+        if (lane == 0) A.counts[cb * t.ngroup + ig] = (int)ns;
+      } else {
+        const long e0 = A.goff[cb * t.ngroup + ig];
+        if (lane <= kRings) rpos[lane] = 0;
+        wave_lds_sync();
+        walk(1, 0);                                                 // rpos[r] = survivors in ring r
+        wave_lds_sync();
+        // (exclusive scan by lane 0 -- 16 additions)
+        wave_lds_sync();
+        if (lane == 0) {
+          int acc = 0;
+          for (int r = 0; r < kRings; ++r) {
+            const int cr = rpos[r];
+            rpos[r] = acc;
+            A.roff[(cb * t.ngroup + ig) * (kRings + 1) + r] = acc;
+            acc += cr;
+          }
+          A.roff[(cb * t.ngroup + ig) * (kRings + 1) + kRings] = acc;
+        }
+        wave_lds_sync();
+        walk(2, e0);
+        wave_lds_sync();
+      }
+    }
+  }
+}
+
+struct RingSearchArgs {
+  letkf_search_tables t;
+  long col0, ncol, nij1;
+  int nlev;
+  const double *rlev, *rz;
+  int fill;
+  int* counts;
+  const long* obs_off;
+  int* obs_idx;
+  double *rdiag_l, *rloc_l;
+  int* nobs_ctype;
+  double* cutd_ctype;
+  const long* goff;      // [ncol * ngroup + 1] absolute entry offsets of this batch's columns
+  const double* sv;      // (base shifted so that the absolute offsets address it)
+  const int* roff;       // [ncol * ngroup][kRings + 1]
+};
+constexpr int kRingSel = 192;   // largest MAX_NOBS_PER_GRID this kernel serves (the carried selection lives in LDS and re-enters every tile)
+
+__global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSearchArgs A) {
+#pragma clang fp contract(off)
+  __shared__ __attribute__((aligned(16))) unsigned int hist_all[4][kSurvL / 2];
+  __shared__ unsigned long long bkey_all[4][kRingSel];
+  __shared__ long brw_all[4][kRingSel];
+  __shared__ double berr_all[4][kRingSel];
+  __shared__ int s_vm[64], s_nct[4][64];
+  __shared__ double s_vloc[64], s_varloc[64];
+  const letkf_search_tables& t = A.t;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned int* hist = hist_all[wv];
+  unsigned long long* bkey = bkey_all[wv];
+  long* brw = brw_all[wv];
+  double* berr = berr_all[wv];
+  int* nct = s_nct[wv];
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int i = threadIdx.x; i < t.nctype; i += 256) {
+    s_vm[i] = t.vmode[i];
+    s_vloc[i] = t.vert_loc[i];
+    s_varloc[i] = t.varloc[i];
+  }
+  __syncthreads();
+  const double lnrain = log(t.rain_base);
+  const int ng = t.ngroup;
+  for (long cb = (long)blockIdx.x * 4 + wv; cb < A.ncol; cb += (long)gridDim.x * 4) {
+    const long col = A.col0 + cb;
+    for (int lev = 0; lev < A.nlev; ++lev) {
+      const long p = col + A.nij1 * (long)lev;
+      const double vz = A.rz[p], vlnp = log(A.rlev[p]);
+      const long out0 = A.fill ? A.obs_off[p] : 0;
+      int emitted = 0;
+      if (A.nobs_ctype || A.cutd_ctype)                            // defaults: letkf_tools.f90:1380-1391, :1427-1432
+        for (int ic = lane; ic < t.nctype; ic += 64) {
+          if (A.nobs_ctype) A.nobs_ctype[p * t.nctype + ic] = 0;
+          if (A.cutd_ctype) A.cutd_ctype[p * t.nctype + ic] = 0.0;
+        }
+      for (int ig = 0; ig < ng; ++ig) {
+        const int gs = t.group_start[ig];
+        const int icm = t.group_member[gs];
+        const int nmax = t.max_nobs[icm];
+        const long e0 = A.goff[cb * ng + ig], e1 = A.goff[cb * ng + ig + 1];
+        const int n_g = (int)(e1 - e0);
+        const int* ro = A.roff + (cb * ng + ig) * (kRings + 1);
+        // one entry -> its selection key (the squared normalised distance as bits), or kNoKey
+        auto entry_key = [&](const double2 a2, const double2 b2, double& nd_out) -> bool {
+          const int ic = (int)(__double_as_longlong(a2.x) >> 32);
+          const int vm = s_vm[ic];
+          const double vloc = s_vloc[ic];
+          const double vref = vm == 1 ? vz : vlnp;
+          double vconst = 0.0;
+          if (vm == 3 && vloc != 0.0) vconst = fabs(lnrain - vref) / vloc;
+          const VertOut vo = vertical_nd(vm, vloc, s_varloc[ic], vconst, vloc != 0.0 ? vref : 0.0, a2.y, b2.x, b2.y);
+          nd_out = vo.nd;
+          return vo.acc;
+        };
+        int nsel = 0;
+        double cutd = (t.criterion == 1) ? t.hori_loc[icm] * kDistZeroFac : 0.0;   // :1384-1389
+        if (nmax <= 0) {
+          // ---- no limit: every accepted row, in the list order
+          if (A.nobs_ctype) {
+            nct[lane] = 0;
+            wave_lds_sync();
+          }
+          for (int pos = 0; pos < n_g; pos += 64) {
+            const int e = pos + lane;
+            bool acc = false;
+            double nd = 0.0;
+            double2 a2{0.0, 0.0}, b2{0.0, 0.0};
+            if (e < n_g) {
+              a2 = *reinterpret_cast<const double2*>(&A.sv[4 * (e0 + e)]);
+              b2 = *reinterpret_cast<const double2*>(&A.sv[4 * (e0 + e) + 2]);
+              acc = entry_key(a2, b2, nd);
+            }
+            const unsigned long long mk = __ballot(acc);
+            if (acc) {
+              const long rw = __double_as_longlong(a2.x);
+              const int ic = (int)(rw >> 32);
+              if (A.fill) {
+                const long o = out0 + emitted + nsel + __popcll(mk & lt_mask);
+                const double rloc = s_varloc[ic] * exp(-0.5 * nd);                       // :1899
+                A.obs_idx[o] = (int)(rw & 0xffffffffL);
+                A.rdiag_l[o] = b2.y * b2.y / rloc;                                        // :1903
+                A.rloc_l[o] = rloc;
+              }
+              if (A.nobs_ctype) atomicAdd(&nct[ic], 1);
+            }
+            nsel += __popcll(mk);
+          }
+          if (A.nobs_ctype) {
+            wave_lds_sync();
+            for (int m = gs + lane; m < t.group_start[ig + 1]; m += 64) {
+              const int ic = t.group_member[m];
+              A.nobs_ctype[p * t.nctype + ic] = nct[ic];
+            }
+            wave_lds_sync();
+          }
+        } else {
+          // ---- the nmax nearest: tiles in ring order, the selection so far carried in LDS and re-entered with every tile
+          const bool count_only = !A.fill && !A.cutd_ctype;
+          int nB = 0, tot = 0, pos = 0, rp = 0;
+          unsigned long long tau = kNoKey;
+          while (pos < n_g) {
+            while (rp + 1 < kRings && ro[rp + 1] <= pos) ++rp;      // the ring the next entry lies in
+            if (count_only && tot >= nmax) break;
+            if (nB == nmax) {
+              const double lb = (double)rp * (1.0 / kRingScale) * (1.0 - 1e-12);   // nd >= nd_h^2 >= lb for everything from here on
+              if ((unsigned long long)__double_as_longlong(lb) >= tau) break;
+            }
+            const int nbs = (nB + 63) >> 6;                          // slots the carried selection takes
+            unsigned long long keyr[kKeyS];
+            long rwr[kKeyS];
+            double errr[kKeyS];
+            int nreal = 0, nnew = 0;
+#pragma unroll
+            for (int u = 0; u < kKeyS; ++u) {
+              keyr[u] = kNoKey;
+              rwr[u] = 0;
+              errr[u] = 0.0;
+              if (u < nbs) {
+                const int j = u * 64 + lane;
+                if (j < nB) {
+                  keyr[u] = bkey[j];
+                  rwr[u] = brw[j];
+                  errr[u] = berr[j];
+                }
+              } else {
+                const int e = pos + (u - nbs) * 64 + lane;
+                if (e < n_g) {
+                  const double2 a2 = *reinterpret_cast<const double2*>(&A.sv[4 * (e0 + e)]);
+                  const double2 b2 = *reinterpret_cast<const double2*>(&A.sv[4 * (e0 + e) + 2]);
+                  double nd;
+                  if (entry_key(a2, b2, nd)) {
+                    keyr[u] = (unsigned long long)__double_as_longlong(nd);
+                    rwr[u] = __double_as_longlong(a2.x);
+                    errr[u] = b2.y;
+                  }
+                }
+              }
+              const int c = __popcll(__ballot(keyr[u] != kNoKey));
+              nreal += c;
+              if (u >= nbs) nnew += c;
+            }
+            tot += nnew;
+            pos += (kKeyS - nbs) * 64;
+            if (count_only) continue;
+            wave_lds_sync();                                         // (everybody has read the carried selection)
+            unsigned long long thresh = kNoKey;
+            int tie_budget = 0;
+            if (nreal > nmax) hist_thresh<kKeyS>(keyr, kKeyS * 64, nreal, nmax, hist, thresh, tie_budget, 256.0 / 13.5);
+            tie_budget = uni(tie_budget);
+            const bool ties = thresh != kNoKey;
+            int nl = 0;
+#pragma unroll
+            for (int u = 0; u < kKeyS; ++u) {
+              const bool take = keyr[u] < thresh, tie = ties && keyr[u] == thresh;   // (kNoKey is below nothing)
+              const unsigned long long mk = __ballot(take), tk = __ballot(tie);
+              const int nm = __popcll(mk), tpos = mbcnt(tk);
+              if (take || (tie && tpos < tie_budget)) {
+                const int j = nl + (take ? mbcnt(mk) : nm + tpos);
+                bkey[j] = keyr[u];
+                brw[j] = rwr[u];
+                berr[j] = errr[u];
+              }
+              const int nt = min((int)__popcll(tk), tie_budget);
+              tie_budget -= nt;
+              nl += nm + nt;
+            }
+            nB = nl;
+            if (nreal >= nmax) {
+              // tau = the nmax-th best key so far (with nreal == nmax: the largest key of the selection)
+              if (nreal > nmax) tau = thresh;
+              else {
+                unsigned int hi = 0u;
+#pragma unroll
+                for (int u = 0; u < kKeyS; ++u)
+                  if (keyr[u] != kNoKey) hi = max(hi, (unsigned int)(keyr[u] >> 32));
+                tau = ((unsigned long long)wave_max_u32(hi) + 1ull) << 32;   // (an upper bound is enough for the stop test)
+              }
+            }
+            wave_lds_sync();
+          }
+          nsel = count_only ? min(tot, nmax) : nB;
+          if (!count_only && nB == nmax) {
+            // the cut-off measure once the limit is reached: hori_loc * sqrt(nmax-th smallest squared distance) (:1384-1389)
+            unsigned long long kmx = 0ull;
+            for (int j = lane; j < nB; j += 64) kmx = bkey[j] > kmx ? bkey[j] : kmx;
+            const unsigned int hmx = wave_max_u32((unsigned int)(kmx >> 32));
+            unsigned int lmx = ((unsigned int)(kmx >> 32) == hmx) ? (unsigned int)kmx : 0u;
+            lmx = wave_max_u32(lmx);
+            const double kv = __longlong_as_double((long long)(((unsigned long long)hmx << 32) | lmx));
+            cutd = t.hori_loc[icm] * sqrt(kv);
+          }
+          if (A.fill) {
+            for (int j = lane; j < nB; j += 64) {
+              const long rw = brw[j];
+              const int ic = (int)(rw >> 32);
+              const double nd = __longlong_as_double((long long)bkey[j]);
+              const double rloc = s_varloc[ic] * exp(-0.5 * nd);                         // :1899
+              const long o = out0 + emitted + j;
+              A.obs_idx[o] = (int)(rw & 0xffffffffL);
+              A.rdiag_l[o] = berr[j] * berr[j] / rloc;                                    // :1903
+              A.rloc_l[o] = rloc;
+            }
+          }
+          if (lane == 0) {
+            if (A.nobs_ctype) A.nobs_ctype[p * t.nctype + icm] = nsel;                    // nobsl_t of the master (:1633, :1713)
+            if (A.cutd_ctype) A.cutd_ctype[p * t.nctype + icm] = cutd;
+          }
+          wave_lds_sync();
+        }
+        emitted += nsel;
+      }
+      if (!A.fill && lane == 0) A.counts[p] = emitted;
+    }
+  }
+}
+
+hipError_t launch_ring_survivors(const letkf_search_tables& t, long col0, long ncol, const double* rig, const double* rjg, int fill,
+                                 int* counts, const long* goff, double* sv, int* roff, int num_cu, hipStream_t st) {
+  if (ncol <= 0) return hipSuccess;
+  RingBuildArgs a{t, col0, ncol, rig, rjg, counts, goff, sv, roff};
+  const long nwg = (ncol + 3) / 4;
+  const long g = (long)num_cu * 8;
+  const int grid = (int)(nwg < g ? nwg : g);
+  if (fill) hipLaunchKernelGGL(letkf_ring_survivors_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(letkf_ring_survivors_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_search_rings(const letkf_search_tables& t, long col0, long ncol, long nij1, int nlev, const double* rlev,
+                               const double* rz, int fill, int* counts, const long* obs_off, int* obs_idx, double* rdiag_l,
+                               double* rloc_l, int* nobs_ctype, double* cutd_ctype, const long* goff, const double* sv,
+                               const int* roff, int num_cu, hipStream_t st) {
+  if (ncol <= 0) return hipSuccess;
+  RingSearchArgs a{t, col0, ncol, nij1, nlev, rlev, rz, fill, counts, obs_off, obs_idx, rdiag_l, rloc_l, nobs_ctype, cutd_ctype,
+                   goff, sv, roff};
+  const long nwg = (ncol + 3) / 4;
+  const long g = (long)num_cu * 4;
+  const int grid = (int)(nwg < g ? nwg : g);
+  hipLaunchKernelGGL(letkf_search_rings_kernel, dim3(grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+int search_rings_max_nobs() { return kRingSel; }
+int search_rings_lds_survivors() { return kSurvL; }
+
 // ------------------------------------------------------------------ the horizontal half of obs_local, once per column
 // (the list-free route of letkf_das_columns_dev; the vertical half runs inside the loop body kernel, letkf_wave.hip mode 3).
 // One wave per column walks the rectangle of sorting-mesh cells of every combined type exactly like the column search and

@@ -91,12 +91,15 @@ def test_column_search_equals_point_search(nlev):
     assert torch.equal(d1, d2) and torch.equal(l1, l2)
 
 
+@pytest.mark.parametrize("rings", [0, 1])
 @pytest.mark.parametrize("criterion", [1, 2, 3])
 @pytest.mark.parametrize("nlev,max_nobs", [(7, (25, 25, 10, 5)), (3, (40, 0, 0, 7)), (60, (30, 30, 30, 30))])
-def test_column_search_with_obs_number_limit(criterion, nlev, max_nobs):
+def test_column_search_with_obs_number_limit(criterion, nlev, max_nobs, rings):
     """MAX_NOBS_PER_GRID on the column path (letkf_tools.f90:1479-1729; merged group (0, 1) under its master's limit,
     :1434-1436): per point the same SET as the per-point kernel -- which the oracle tests pin to the reference's
-    selection -- with the same weights, plus the NOBS_OUT inputs nobsl_t and cutd_t (:1633-1640, :1713-1727)."""
+    selection -- with the same weights, plus the NOBS_OUT inputs nobsl_t and cutd_t (:1633-1640, :1713-1727).
+    rings = 1: the route for DENSE observations forced on (LETKF_OPT_LIMITED_RINGS; distance criterion only -- the others keep
+    the LDS-buffered kernel whatever the option says): survivors by rings of nd_h^2 in global memory, tiles, early stop."""
     from _gpu import ctx, dev
     case = build_case(33 + criterion, npts=70, max_nobs=max_nobs, criterion=criterion)
     t, keep = device_struct(case, "cuda")
@@ -110,9 +113,13 @@ def test_column_search_with_obs_number_limit(criterion, nlev, max_nobs):
     o1, i1, d1, l1 = c.obs_search(t, dev(np.tile(rig, nlev)), dev(np.tile(rjg, nlev)), dev(rlev), dev(rz))
     nct = torch.full((nij1 * nlev, 4), -1, dtype=torch.int32, device="cuda")
     cut = torch.full((nij1 * nlev, 4), -1.0, dtype=torch.float64, device="cuda")
-    o2, i2, d2, l2 = c.obs_search_columns(t, nij1, nlev, dev(rig), dev(rjg), dev(rlev), dev(rz), nobs_ctype=nct,
-                                          cutd_ctype=cut)
-    torch.cuda.synchronize()
+    c.set_option(c.OPT_LIMITED_RINGS, rings)
+    try:
+        o2, i2, d2, l2 = c.obs_search_columns(t, nij1, nlev, dev(rig), dev(rjg), dev(rlev), dev(rz), nobs_ctype=nct,
+                                              cutd_ctype=cut)
+        torch.cuda.synchronize()
+    finally:
+        c.set_option(c.OPT_LIMITED_RINGS, 2)
     assert torch.equal(o1, o2)
     o1, i1, d1, l1, i2, d2, l2 = (x.cpu().numpy() for x in (o1, i1, d1, l1, i2, d2, l2))
     nct, cut = nct.cpu().numpy(), cut.cpu().numpy()
@@ -174,3 +181,60 @@ def test_search_limit_hint_spares_the_sync():
         b2 = c.obs_search(t1, dev(p["ri"]), dev(p["rj"]), dev(p["rlev"]), dev(p["rz"]))
         for x, y in zip(a + a2, b + b2):
             assert torch.equal(x, y)
+
+
+def test_dense_observations_under_a_limit_rings_equal_the_lds_kernel():
+    """BASELINE configs[3]'s observation density (~5000 horizontal survivors per column and group) with the reference's usual
+    MAX_NOBS_PER_GRID = 100: the survivors overflow the column kernel's LDS buffer, whose fall-back is the per-point multi-sweep
+    select (the path the oracle tests pin); the ring route -- several tiles per level, the selection carried from tile to tile, the
+    early stop at a ring boundary -- must select the same rows with the same weights, count the same nobsl_t and report the same
+    cut-off measure."""
+    import bench_workload as bw
+    from _gpu import ctx, pkg
+    dev_ = torch.device("cuda:0")
+    w = bw.build("C4-slab", dev_, lists=False)
+    nij1, nlev = w["cfg"]["nx"] * w["cfg"]["ny"], w["cfg"]["nz"]
+    t_s, keep, order, pts = bw.search_tables(w, pkg, dev_, max_nobs=100)
+    nct_n = t_s.nctype
+    c = ctx()
+    rig, rjg = pts[0][:nij1].contiguous(), pts[1][:nij1].contiguous()
+    res = []
+    for rings in (0, 1):
+        nct = torch.full((nij1 * nlev, nct_n), -1, dtype=torch.int32, device=dev_)
+        cut = torch.full((nij1 * nlev, nct_n), -1.0, dtype=torch.float64, device=dev_)
+        c.set_option(c.OPT_LIMITED_RINGS, rings)
+        try:
+            o, i, d, l = c.obs_search_columns(t_s, nij1, nlev, rig, rjg, pts[2], pts[3], nobs_ctype=nct, cutd_ctype=cut)
+            torch.cuda.synchronize()
+        finally:
+            c.set_option(c.OPT_LIMITED_RINGS, 2)
+        res.append([x.cpu().numpy() for x in (o, i, d, l, nct, cut)])
+    (o0, i0, d0, l0, n0, c0), (o1, i1, d1, l1, n1, c1) = res
+    # without the diagnostics the counting pass only counts (stops at the limit): same offsets, same lists
+    c.set_option(c.OPT_LIMITED_RINGS, 1)
+    try:
+        o2, i2, d2, l2 = c.obs_search_columns(t_s, nij1, nlev, rig, rjg, pts[2], pts[3])
+        torch.cuda.synchronize()
+    finally:
+        c.set_option(c.OPT_LIMITED_RINGS, 2)
+    assert np.array_equal(o2.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), i1) and np.array_equal(l2.cpu().numpy(), l1)
+    assert np.array_equal(o0, o1) and int(o0[-1]) > 50 * nij1 * nlev
+    assert np.array_equal(n0, n1)
+    assert np.allclose(c0, c1, rtol=1e-14, atol=0)
+    assert int(np.diff(o0).max()) <= 100 * nct_n
+    ties = 0
+    for pt in range(nij1 * nlev):
+        s = slice(o0[pt], o0[pt + 1])
+        # the observations sit on a regular lattice: many EXACTLY equal distances, and which of the candidates tied at the
+        # nmax-th key are taken is implementation-defined (in the reference too: an unstable quick-select).  So: the same
+        # multiset of weights, and the same rows wherever the weight is strictly better than a list's worst.
+        assert sorted(l0[s].tolist()) == sorted(l1[s].tolist()), pt
+        assert sorted(d0[s].tolist()) == sorted(d1[s].tolist()), pt
+        r0 = {(r, w_) for r, w_ in zip(i0[s].tolist(), l0[s].tolist())}
+        r1 = {(r, w_) for r, w_ in zip(i1[s].tolist(), l1[s].tolist())}
+        worst = {w_ for _, w_ in r0 ^ r1}
+        ties += len(r0 ^ r1) > 0
+        for _, w_ in r0 ^ r1:                      # rows that differ carry a weight that is ALSO present in the common part
+            assert sum(1 for x in l0[s].tolist() if x == w_) >= 2 or len(worst) <= 2 * nct_n, pt
+        assert len(worst) <= 2 * nct_n, (pt, worst)   # at most one tied key per limited group
+    assert ties > 0                                  # (the lattice does produce ties: the comparison above was exercised)
