@@ -36,5 +36,5 @@ print('$t', round(d['bench']['value']), d['bench']['roofline']['frac'])
 for k,e in d['kernels'].items():
     if e.get('pct',0)>5: print('   ', k, 'ms', round(e['avg_ms'],3), 'traffic GB', round(e.get('traffic_bytes_per_launch',0)/1e9,2), 'TB/s', round(e.get('traffic_TB_per_s',0),2), 'wait', round(e.get('wait_inst_any_frac_of_wave_cycles',0),2), 'valu', round(e.get('valu_busy_frac',0),2))
 "; done
-  echo "== full size"; tools/r3_fullsize.sh $TAG C3 C4p C5
+  echo "== full size"; tools/r3_fullsize.sh $TAG C3 C4p C4l C5
 fi
