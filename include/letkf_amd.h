@@ -245,7 +245,9 @@ typedef struct {
   int32_t nlon, nlat;         /* interior size of the (sub)domain the mesh was built on */
   int32_t limit_hint;         /* what the HOST knows about max_nobs (a device array): 0 unknown -- the search entries read
                                  it back and synchronise the stream once per call; 1 no combined type has a limit;
-                                 2 at least one has.  Set it to keep a pipeline of calls free of host synchronisation. */
+                                 2 at least one has.  Set it to keep a pipeline of calls free of host synchronisation (the column
+                                 entry still synchronises where it weighs the ring route for dense limited observations:
+                                 it reads the limits and the survivor counts back to size its buffers). */
   double dx, dy;              /* DX, DY */
   double i_org, j_org;        /* ri - i_org is (ril - IHALO - 0.5) of ij_obsgrd_ext (letkf_obs.f90:1221) */
   double rain_base;           /* VERT_LOCAL_RAIN_BASE */
