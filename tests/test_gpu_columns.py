@@ -124,3 +124,63 @@ def test_the_route_is_chosen_by_the_size_of_the_lists():
     for v in range(nv):
         scale = float(max(x[v, k].abs().max(), x[v, :k].abs().max()))
         assert float((res[0][v] - res[1][v]).abs().max()) <= 1e-11 * scale
+
+
+@pytest.mark.parametrize("nlev,list_kb", [(5, 1 << 20), (9, 64)])
+def test_list_free_route_with_four_combined_types_and_three_vertical_modes(nlev, list_kb):
+    """The survivors of a column carry their combined type: a merged radar group (height), upper-air T (ln p) and surface pressure
+    (the observed value as vertical coordinate), different horizontal and vertical scales and variable-localisation factors
+    (tests/_search.py) -- the type's numbers are read per 64-entry chunk, every type's entries padded to whole chunks.  Against
+    letkf_obs_search_columns_dev + ONE letkf_das_points_dev with the same runs up the columns: bit for bit; small workspaces force
+    several batches of columns."""
+    from _gpu import ctx, dev
+    from _search import build_case, device_struct
+    nij1 = 60
+    case = build_case(91, npts=nij1)
+    t, keep = device_struct(case, "cuda")
+    p = case["pts"]
+    rng = np.random.default_rng(7 + nlev)
+    k, nv, nens = 24, 11, 25
+    npts = nij1 * nlev
+    nobs = len(case["arr"]["ob_ri"]) if "ob_ri" in case["arr"] else int(case["ctype_rows"][-1])
+    rlev = rng.uniform(2.5e4, 1.0e5, npts)
+    rz = rng.uniform(0.0, 12000.0, npts)
+    kld = k + 1
+    ens = rng.standard_normal((nobs, kld)) * 2.0
+    ens[:, :k] -= ens[:, :k].mean(axis=1, keepdims=True)
+    dep = rng.standard_normal(nobs) * 3.0
+    gues = rng.standard_normal(nv * nens * npts)
+    gv = gues.reshape(nv, nens, npts)
+    gv[:, :k] -= gv[:, :k].mean(axis=1, keepdims=True)          # perturbations in slots 0..k-1, the mean in slot k
+    gv[:, k] = 10.0 + rng.standard_normal((nv, npts))
+    c = ctx()
+    d = lambda a: dev(np.ascontiguousarray(a))
+    g_ens, g_dep, g_gues = d(ens.reshape(-1)), d(dep), d(gues)
+    rig, rjg, g_rlev, g_rz = d(p["ri"][:nij1]), d(p["rj"][:nij1]), d(rlev), d(rz)
+    off, idx, rd, rl = c.obs_search_columns(t, nij1, nlev, rig, rjg, g_rlev, g_rz)
+    assert int(off[-1]) > 20 * npts
+    a0 = torch.full((gues.size,), float("nan"), dtype=torch.float64, device="cuda")
+    i0 = torch.ones(npts * nv, dtype=torch.float64, device="cuda")
+    s0 = torch.full((npts,), -1, dtype=torch.int32, device="cuda")
+    c.das_points(k, nv, off, idx, rd, rl, g_ens, kld, g_dep, i0, g_gues, a0, 1, npts, npts * nens, relax_alpha_spread=0.9,
+                 status=s0, warm_stride=nij1)
+    a1 = torch.full((gues.size,), float("nan"), dtype=torch.float64, device="cuda")
+    i1 = torch.ones(npts * nv, dtype=torch.float64, device="cuda")
+    s1 = torch.full((npts,), -1, dtype=torch.int32, device="cuda")
+    nobs_out = torch.full((npts,), -5, dtype=torch.int32, device="cuda")
+    c.set_option(c.OPT_COLUMN_SURVIVORS, 1)
+    try:
+        c.das_columns(k, nv, t, nij1, nlev, rig, rjg, g_rlev, g_rz, g_ens, kld, g_dep, i1, g_gues, a1, 1, npts, npts * nens,
+                      list_bytes=list_kb * 1024, nobs_out=nobs_out, relax_alpha_spread=0.9, status=s1)
+        torch.cuda.synchronize()
+    finally:
+        c.set_option(c.OPT_COLUMN_SURVIVORS, 2)
+    assert "FUSED" in c.last_path()
+    assert int(s0.abs().max()) == 0 and int(s1.abs().max()) == 0
+    assert torch.equal(nobs_out.long(), off[1:] - off[:-1])
+    g0, g1 = a0.view(nv, nens, npts)[:, :k], a1.view(nv, nens, npts)[:, :k]
+    if list_kb >= 1 << 20:
+        assert torch.equal(g0, g1)                   # one batch: the same runs, the same bits
+    else:
+        # (batches of a few columns: the launch splits its runs differently -- other warm starts, same analysis to rounding)
+        assert float((g0 - g1).abs().max()) <= 1e-11 * float(g0.abs().max())
