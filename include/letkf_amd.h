@@ -78,7 +78,7 @@ int letkf_ctx_synchronize(letkf_ctx *ctx);
 /* LETKF_OPT_LIMITED_RINGS: the column search under MAX_NOBS_PER_GRID (distance criterion) on DENSE observations -- a group's
  * horizontal survivors kept in global memory by rings of nd_h^2, a level takes the nearest rings only (letkf_search.hip).
  * 2 (default): where the survivors overflow the column kernel's buffer on average; 1: wherever eligible (criterion 1, every
- * limit <= 192, <= 64 combined types); 0: never. */
+ * limit <= 128, <= 64 combined types); 0: never. */
 #define LETKF_OPT_LIMITED_RINGS 3
 int letkf_ctx_set_option(letkf_ctx *ctx, int option, int value);
 

@@ -942,9 +942,15 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
     if (lim_surv <= 0.75 * (double)letkf::search_rings_lds_survivors() * (double)nij1 * (double)nlim) return LETKF_OK;
   }
   *taken = true;
-  // 8 GiB of survivors per batch of columns; inside letkf_das_columns_dev up to 64 GiB in ONE batch, kept for the calls that follow
-  const bool keep = c->ring_keep && hoff[ncg] * 32 <= ((int64_t)64 << 30);
-  const int64_t budget = keep ? ((int64_t)64 << 30) : ((int64_t)8 << 30);
+  // 8 GiB of survivors per batch of columns; inside letkf_das_columns_dev ONE batch, kept for the calls that follow, where
+  // that takes no more than half of the device memory still free (configs[3] with two limited types: 128 GiB)
+  bool keep = false;
+  if (c->ring_keep) {
+    size_t fr = 0, tot = 0;
+    HIP_TRY(hipMemGetInfo(&fr, &tot));
+    keep = (size_t)hoff[ncg] * 32 + 256 <= c->ring_ws_bytes + fr / 2;
+  }
+  const int64_t budget = keep ? hoff[ncg] * 32 + 256 : ((int64_t)8 << 30);
   int64_t c0 = 0;
   while (c0 < nij1) {
     int64_t c1 = c0 + 1;

@@ -1348,7 +1348,8 @@ struct RingSearchArgs {
   const double* sv;      // (base shifted so that the absolute offsets address it)
   const int* roff;       // [ncol * ngroup][kRings + 1]
 };
-constexpr int kRingSel = 192;   // largest MAX_NOBS_PER_GRID this kernel serves (the carried selection lives in LDS and re-enters every tile)
+constexpr int kRingSlots = 6;    // slots of 64 keys per lane a tile takes (carried selection + new entries): with the 9 of the LDS kernel the tile spilled 1.2 KB per lane
+constexpr int kRingSel = 128;    // largest MAX_NOBS_PER_GRID this kernel serves (the carried selection lives in LDS and re-enters every tile)
 
 __global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSearchArgs A) {
 #pragma clang fp contract(off)
@@ -1460,12 +1461,23 @@ __global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSe
               if ((unsigned long long)__double_as_longlong(lb) >= tau) break;
             }
             const int nbs = (nB + 63) >> 6;                          // slots the carried selection takes
-            unsigned long long keyr[kKeyS];
-            long rwr[kKeyS];
-            double errr[kKeyS];
+            unsigned long long keyr[kRingSlots];
+            long rwr[kRingSlots];
+            double errr[kRingSlots];
             int nreal = 0, nnew = 0;
+            // the tile's entries: every load issued before the first is used, unconditionally from a clamped address (written
+            // as `if (e < n_g) load` per slot, hipcc waits vmcnt(0) behind each branch: a memory round trip per slot, 12 us per
+            // tile -- found in the kernel stats: 65 us per (column, level, group) instead of ~3)
+            double2 ta[kRingSlots], tb[kRingSlots];
 #pragma unroll
-            for (int u = 0; u < kKeyS; ++u) {
+            for (int u = 0; u < kRingSlots; ++u) {
+              const int e = min(pos + (u - nbs) * 64 + lane, n_g - 1);
+              const long ea = e0 + (u >= nbs ? e : 0);
+              ta[u] = *reinterpret_cast<const double2*>(&A.sv[4 * ea]);
+              tb[u] = *reinterpret_cast<const double2*>(&A.sv[4 * ea + 2]);
+            }
+#pragma unroll
+            for (int u = 0; u < kRingSlots; ++u) {
               keyr[u] = kNoKey;
               rwr[u] = 0;
               errr[u] = 0.0;
@@ -1478,15 +1490,11 @@ __global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSe
                 }
               } else {
                 const int e = pos + (u - nbs) * 64 + lane;
-                if (e < n_g) {
-                  const double2 a2 = *reinterpret_cast<const double2*>(&A.sv[4 * (e0 + e)]);
-                  const double2 b2 = *reinterpret_cast<const double2*>(&A.sv[4 * (e0 + e) + 2]);
-                  double nd;
-                  if (entry_key(a2, b2, nd)) {
-                    keyr[u] = (unsigned long long)__double_as_longlong(nd);
-                    rwr[u] = __double_as_longlong(a2.x);
-                    errr[u] = b2.y;
-                  }
+                double nd;
+                if (e < n_g && entry_key(ta[u], tb[u], nd)) {
+                  keyr[u] = (unsigned long long)__double_as_longlong(nd);
+                  rwr[u] = __double_as_longlong(ta[u].x);
+                  errr[u] = tb[u].y;
                 }
               }
               const int c = __popcll(__ballot(keyr[u] != kNoKey));
@@ -1494,17 +1502,17 @@ __global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSe
               if (u >= nbs) nnew += c;
             }
             tot += nnew;
-            pos += (kKeyS - nbs) * 64;
+            pos += (kRingSlots - nbs) * 64;
             if (count_only) continue;
             wave_lds_sync();                                         // (everybody has read the carried selection)
             unsigned long long thresh = kNoKey;
             int tie_budget = 0;
-            if (nreal > nmax) hist_thresh<kKeyS>(keyr, kKeyS * 64, nreal, nmax, hist, thresh, tie_budget, 256.0 / 13.5);
+            if (nreal > nmax) hist_thresh<kRingSlots>(keyr, kRingSlots * 64, nreal, nmax, hist, thresh, tie_budget, 256.0 / 13.5);
             tie_budget = uni(tie_budget);
             const bool ties = thresh != kNoKey;
             int nl = 0;
 #pragma unroll
-            for (int u = 0; u < kKeyS; ++u) {
+            for (int u = 0; u < kRingSlots; ++u) {
               const bool take = keyr[u] < thresh, tie = ties && keyr[u] == thresh;   // (kNoKey is below nothing)
               const unsigned long long mk = __ballot(take), tk = __ballot(tie);
               const int nm = __popcll(mk), tpos = mbcnt(tk);
@@ -1525,7 +1533,7 @@ __global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSe
               else {
                 unsigned int hi = 0u;
 #pragma unroll
-                for (int u = 0; u < kKeyS; ++u)
+                for (int u = 0; u < kRingSlots; ++u)
                   if (keyr[u] != kNoKey) hi = max(hi, (unsigned int)(keyr[u] >> 32));
                 tau = ((unsigned long long)wave_max_u32(hi) + 1ull) << 32;   // (an upper bound is enough for the stop test)
               }
