@@ -60,6 +60,10 @@ struct letkf_ctx {
   size_t ring_ws_bytes = 0;
   char* ring_aux = nullptr;   // ... their counts / offsets / ring starts
   size_t ring_aux_bytes = 0;
+  // (the last "not dense" verdict, by the identity of the tables and columns it was given for: the weighing costs a survivor count
+  // and two read-backs -- 17 ms on C2's grid, per search call.  A stale verdict costs speed only: both routes are exact.)
+  const void* ring_no[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int64_t ring_no_n = -1;
   bool ring_keep = false;     // inside letkf_das_columns_dev: the survivors of the first search call serve the later ones
   bool ring_ready = false;
   std::vector<int64_t> ring_hoff;
@@ -885,6 +889,8 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
                          double* cutd_ctype, bool* taken) {
   *taken = false;
   if (c->limited_rings == 0 || t->criterion != 1 || t->nctype > 64 || nij1 * (int64_t)t->ngroup >= 0x7fffffff) return LETKF_OK;
+  const void* key[5] = {t->ob_ri, t->ac_ext, t->max_nobs, rig, rjg};
+  if (c->limited_rings == 2 && c->ring_no_n == nij1 && std::equal(key, key + 5, c->ring_no)) return LETKF_OK;
   std::vector<int32_t> mx(t->nctype), gstart(t->ngroup + 1);
   HIP_TRY(hipMemcpyAsync(gstart.data(), t->group_start, sizeof(int32_t) * (t->ngroup + 1), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(mx.data(), t->max_nobs, sizeof(int32_t) * t->nctype, hipMemcpyDeviceToHost, c->stream));
@@ -934,12 +940,20 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
   HIP_TRY(hipMemcpyAsync(hoff.data(), goff, (ncg + 1) * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->limited_rings == 2) {
-    // dense = the survivors of the limited groups overflow the column kernel's LDS buffer on average: below that the
-    // LDS-buffered kernel (everything of a column resident, all levels against it) is the faster one
-    double lim_surv = 0.0;
+    // dense = more than one in twenty (column, limited group) pairs overflow the column kernel's LDS buffer and would take its
+    // multi-sweep fall-back (20 x the cost of a pair that fits); while they fit, that kernel -- everything of a column resident,
+    // all levels against it -- is the faster one (C2's grid under a limit of 100: ~450 survivors per pair, 34 against 68 ms)
+    size_t n_over = 0, n_lim = 0;
     for (size_t i = 0; i < ncg; ++i)
-      if (mx[gmem[gstart[i % ng]]] > 0) lim_surv += (double)(hoff[i + 1] - hoff[i]);
-    if (lim_surv <= 0.75 * (double)letkf::search_rings_lds_survivors() * (double)nij1 * (double)nlim) return LETKF_OK;
+      if (mx[gmem[gstart[i % ng]]] > 0) {
+        ++n_lim;
+        n_over += (hoff[i + 1] - hoff[i]) > (int64_t)letkf::search_rings_lds_survivors();
+      }
+    if (n_over * 20 <= n_lim) {
+      std::copy(key, key + 5, c->ring_no);
+      c->ring_no_n = nij1;
+      return LETKF_OK;
+    }
   }
   *taken = true;
   // 8 GiB of survivors per batch of columns; inside letkf_das_columns_dev ONE batch, kept for the calls that follow, where
