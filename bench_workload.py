@@ -64,6 +64,10 @@ CONFIGS = {
                ztop=18000.0, seed=20240630),
     "C4-gpu": dict(nx=250, ny=500, nz=80, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=1100.0, err=3.0,
                    ztop=18000.0, seed=20240631, halo=True),
+    # configs[3]'s observation density at the ensemble size of 20 of the reference's 38 run configurations (MEMBER = 100), half of
+    # the C4-gpu tile (the state of the whole tile at 101 slots would be 2 x 90 GB): meant for --max-nobs 100
+    "C4h-k100": dict(nx=250, ny=250, nz=80, k=100, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=1100.0, err=3.0,
+                     ztop=18000.0, seed=20240634, halo=True),
     "C5-gpu": dict(nx=120, ny=240, nz=60, k=1000, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
                    ztop=18000.0, seed=20240632, halo=True),
     # C2's grid at k = 20 (the memory-bound regime of configs[0]: arithmetic intensity ~5 flop/B)

@@ -14,6 +14,7 @@ for what in "$@"; do
     C4f)    timeout -k 10 900 python bench.py --workload C4-gpu --lists fused --no-torch-lists --steps 2 --warmup 1 2>$O/err_C4f.log | tee $O/bench_C4-gpu_fused.json | j C4-gpu-fused || tail -8 $O/err_C4f.log ;;
     C4p)    timeout -k 10 900 python bench.py --workload C4-gpu --lists pipeline --list-gb 24 --no-torch-lists --steps 2 --warmup 1 2>$O/err_C4p.log | tee $O/bench_C4-gpu_pipeline.json | j C4-gpu-pipeline || tail -8 $O/err_C4p.log ;;
     C4l)    timeout -k 10 900 python bench.py --workload C4-gpu --lists pipeline --list-gb 24 --no-torch-lists --max-nobs 100 --steps 2 --warmup 1 2>$O/err_C4l.log | tee $O/bench_C4-gpu_maxnobs100.json | j C4-gpu-maxnobs100 || tail -8 $O/err_C4l.log ;;
+    C4k)    timeout -k 10 900 python bench.py --workload C4h-k100 --lists pipeline --list-gb 24 --no-torch-lists --max-nobs 100 --steps 2 --warmup 1 2>$O/err_C4k.log | tee $O/bench_C4h-k100_maxnobs100.json | j C4h-k100-maxnobs100 || tail -8 $O/err_C4k.log ;;
     C5)     timeout -k 10 900 python bench.py --workload C5-gpu --level-slab 4 --state-slab --steps 2 --warmup 1 --cpu-seconds 8 2>$O/err_C5.log | tee $O/bench_C5-gpu.json | j C5-gpu || tail -8 $O/err_C5.log ;;
   esac
 done
