@@ -76,7 +76,7 @@ def point_conds(c, k):
 
 
 @pytest.mark.parametrize("name", ["rtps_adaptive_det", "rtpp", "rtps_qtop", "norelax"])
-@pytest.mark.parametrize("k,npts,nobs_tot,n_mean", [(64, 16, 300, 40), (80, 16, 400, 100), (100, 24, 500, 70), (100, 16, 600, 150), (144, 24, 500, 70), (144, 20, 600, 140), (320, 16, 700, 150), (320, 8, 900, 330), (1000, 4, 600, 200)])
+@pytest.mark.parametrize("k,npts,nobs_tot,n_mean", [(63, 12, 300, 40), (63, 12, 400, 90), (64, 16, 300, 40), (65, 12, 300, 80), (80, 16, 400, 100), (128, 12, 500, 60), (128, 12, 600, 170), (100, 24, 500, 70), (100, 16, 600, 150), (144, 24, 500, 70), (144, 20, 600, 140), (320, 16, 700, 150), (320, 8, 900, 330), (1000, 4, 600, 200)])
 def test_eigenfree_points_equal_jacobi_points_and_oracle(name, k, npts, nobs_tot, n_mean):
     from test_gpu_das import CONFIGS, compare_anal
     cfg = CONFIGS[name]
