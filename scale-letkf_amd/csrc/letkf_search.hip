@@ -1274,7 +1274,11 @@ __global__ void __launch_bounds__(256) letkf_ring_survivors_kernel(const RingBui
                 ok = !(nd_h > kDistZeroFac);                        // :1881
               }
               const unsigned long long mk = __ballot(ok);
-              if (what != 0 && mk) {
+              if (what == 1 && mk) {
+                // the histogram: one LDS atomic per survivor (the ORDER of the additions is irrelevant here)
+                const int ring = ringed ? min(kRings - 1, (int)(nd_h * nd_h * kRingScale)) : 0;
+                if (ok) atomicAdd(&rpos[ring], 1);
+              } else if (what == 2 && mk) {
                 const int ring = ringed ? min(kRings - 1, (int)(nd_h * nd_h * kRingScale)) : 0;
                 // lane order inside a ring: deterministic positions (an LDS atomic per lane would scatter them run by run)
                 for (int r = 0; r < kRings; ++r) {
