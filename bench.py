@@ -79,6 +79,9 @@ def main():
                     help="N > 1: the obs all-gather through torch.distributed (default) or through the library's own "
                          "letkf_obs_allgatherv_dev on an RCCL communicator this script creates (ncclCommInitRank); "
                          "halo (--scaling strong only): pairwise sends of just the rows each extended subdomain holds")
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="N=V",
+                    help="letkf_ctx_set_option(N, V) on the bench's context (include/letkf_amd.h LETKF_OPT_*), e.g. 2=1: the list-free "
+                         "route of --lists pipeline wherever it is eligible")
     ap.add_argument("--eigen-stage-only", action="store_true",
                     help="measurement of the fallback: LETKF_OPT_STAGED_POLY = 0, every staged point through the eigen stage "
                          "(workgroup Jacobi at orders <= 208, block Jacobi above) instead of the eigen-free route")
@@ -137,6 +140,9 @@ def main():
     ctx = pkg.Context(local_rank, stream.cuda_stream)
     if args.eigen_stage_only:
         ctx.set_option(ctx.OPT_STAGED_POLY, 0)
+    for ov in args.ctx_option:
+        o_, v_ = ov.split("=")
+        ctx.set_option(int(o_), int(v_))
 
     if args.scaling == "strong":
         import bench_tiles
