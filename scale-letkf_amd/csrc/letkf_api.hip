@@ -728,7 +728,7 @@ int letkf_das_columns_dev(letkf_ctx* c, const letkf_das_args* g, const letkf_sea
       // (2 = automatic: the list-free route where the lists of all levels would not fit the workspace at once -- about half
       // of a column's horizontal survivors pass a level's vertical cut-off, 20 B each.  Where they fit, one fill pass for
       // the whole domain is cheaper than the vertical half inside the register-bound loop body kernel: C2, 203 local
-      // observations per point, 384 against 390 ms per analysis; BASELINE configs[3], 4900 per point, 40 slabs: 7.45 against 6.26 s.)
+      // observations per point, 384 against 394 ms per analysis; BASELINE configs[3], 4900 per point, 40 slabs: 7.45 against 6.26 s.)
       const bool take = c->col_survivors == 1 || (double)hoff[nij1] * (double)nlev * 10.0 > (double)list_bytes;
       // batches of columns whose survivors fit the workspace (32 B each), at least one column
       int64_t c0 = take ? 0 : nij1;

@@ -577,75 +577,6 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
 #define PROF_UNIT
 #endif
 
-// The vertical half of obs_local on a column's horizontal survivors (wave kernel mode 3, see there): appends the accepted rows to the
-// wave's list slot and returns their number.  Deliberately a call, not inline code.
-__device__ __attribute__((noinline)) int survivors_prepass(const double* __restrict__ surv, const long s_lo, const long s_hi,
-                                                           const int* __restrict__ t_vmode, const double* __restrict__ t_vloc,
-                                                           const double* __restrict__ t_varloc, const double v_z, const double v_p,
-                                                           const double l_rain, int* __restrict__ sl_idx, double* __restrict__ sl_rd,
-                                                           double* __restrict__ sl_rl, const long o0, const int wlane) {
-  using namespace search_dev;
-  const unsigned long long lt_mask = (wlane == 0) ? 0ull : (~0ull >> (64 - wlane));
-  int ntot = 0;
-  if (s_hi > s_lo) {
-    // Four chunks of 64 entries in flight, in four buffers with STATIC names: the survivors stream from HBM (no wave reads a
-    // column's list while it is still in a cache: 320 KB per column at configs[3], 2048 columns in flight).  Found in the ISA of
-    // the first versions: one chunk ahead = a full memory round trip per chunk; four ahead through a rotation of register copies
-    // (a0 = a1; ...) copies the destination of the load issued last -- s_waitcnt vmcnt(0) in every iteration; and the 64-bit
-    // `entry + lane` offsets were hoisted out of the point loop, spilled, and their scratch_load -- which counts in vmcnt with
-    // the prefetches -- waited for everything in flight.  Hence: four evaluations written out, each refilling its own buffer right
-    // behind itself, 32-bit offsets, every load unconditional from a clamped address.
-    const int ns_col = (int)(s_hi - s_lo);                         // (a multiple of 64: the survivor kernel pads)
-    const double* sbase = surv + 4 * s_lo;
-    auto ld = [&](const int e0, double2& x, double2& y) {
-      int e = e0 + wlane;
-      e = e < ns_col ? e : ns_col - 1;
-      x = *reinterpret_cast<const double2*>(&sbase[4 * e]);
-      y = *reinterpret_cast<const double2*>(&sbase[4 * e + 2]);
-    };
-    double2 a0, b0, a1, b1, a2, b2, a3, b3;
-    ld(0, a0, b0);
-    ld(64, a1, b1);
-    ld(128, a2, b2);
-    ld(192, a3, b3);
-    // the ctype's three numbers through the scalar cache (a chunk is of ONE type: the survivor kernel pads every type's entries
-    // to whole chunks with rows outside every cut-off)
-    int ic_s = -1, vm_s = 0;
-    double vloc_s = 0.0, varloc_s = 0.0;
-    auto eval = [&](const double2& ca, const double2& cb, const bool live) {
-      const long rw = __double_as_longlong(ca.x);
-      const int ic0 = __builtin_amdgcn_readfirstlane((int)(rw >> 32));
-      if (ic0 != ic_s) {
-        ic_s = ic0;
-        vm_s = t_vmode[ic0];
-        vloc_s = t_vloc[ic0];
-        varloc_s = t_varloc[ic0];
-      }
-      const ColVert vo = column_vertical_cal(vm_s, vloc_s, varloc_s, ca.y, cb.x, cb.y, v_z, v_p, l_rain);
-      const bool acc_ = live && vo.rloc != 0.0;                      // :1460
-      const unsigned long long mk = __ballot(acc_);
-      if (acc_) {
-        const long j = o0 + ntot + __popcll(mk & lt_mask);
-        sl_idx[j] = (int)(rw & 0xffffffffL);
-        sl_rd[j] = vo.rdiag;
-        sl_rl[j] = vo.rloc;
-      }
-      ntot += __popcll(mk);
-    };
-    for (int g0 = 0; g0 < ns_col; g0 += 256) {
-      eval(a0, b0, true);
-      ld(g0 + 256, a0, b0);
-      eval(a1, b1, g0 + 64 < ns_col);
-      ld(g0 + 320, a1, b1);
-      eval(a2, b2, g0 + 128 < ns_col);
-      ld(g0 + 384, a2, b2);
-      eval(a3, b3, g0 + 192 < ns_col);
-      ld(g0 + 448, a3, b3);
-    }
-  }
-  return ntot;
-}
-
 template <int KR, int NV, bool KKOUT, int NW, int FUSED>
 __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER_SIMD(KR, NW)) ? 2 : 1) letkf_wave_kernel(const PointArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -782,11 +713,72 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
         // straight into the Gram's staging buffer, flush and matrix-core steps inside this loop -- the four buffers and the
         // evaluated chunks stayed live across them, 800 B/lane of scratch, slower than the lists.)
         if (beta != 0.0) {
+          using namespace search_dev;
+          const letkf_search_tables& t = A.stab;
           o0 = ((long)blockIdx.x * PPW + wv) * A.sl_cap;
-          // (a function of its own, NOT inlined: inlined, its buffers and hoisted addresses changed the register allocation of
-          // the whole kernel -- 548 against 392 B/lane of scratch, the later phases 5 % slower on C2)
-          const int ntot = survivors_prepass(A.surv, A.sv_off[rb], A.sv_off[rb + 1], A.stab.vmode, A.stab.vert_loc, A.stab.varloc,
-                                             A.prz[pt], log(A.prlev[pt]), log(A.stab.rain_base), A.sl_idx, A.sl_rd, A.sl_rl, o0, wlane);
+          const double v_z = A.prz[pt], v_p = log(A.prlev[pt]), l_rain = log(t.rain_base);
+          const unsigned long long lt_mask = (wlane == 0) ? 0ull : (~0ull >> (64 - wlane));
+          const long s_lo = A.sv_off[rb], s_hi = A.sv_off[rb + 1];
+          int ntot = 0;
+          if (s_hi > s_lo) {
+            // Four chunks of 64 entries in flight, in four buffers with STATIC names: the survivors stream from HBM (no wave
+            // reads a column's list while it is still in a cache: 320 KB per column at configs[3], 2048 columns in flight).
+            // Found in the ISA of the first versions: one chunk ahead = a full memory round trip per chunk; four ahead
+            // through a rotation of register copies (a0 = a1; ...) copies the destination of the load issued last --
+            // s_waitcnt vmcnt(0) in every iteration; and the 64-bit `entry + lane` offsets were hoisted out of the point
+            // loop, spilled, and their scratch_load -- which counts in vmcnt with the prefetches -- waited for everything in
+            // flight.  Hence: four evaluations written out, each refilling its own buffer right behind itself, 32-bit
+            // offsets from a laundered lane number, every load unconditional from a clamped address.
+            const int ns_col = (int)(s_hi - s_lo);                         // (a multiple of 64: the survivor kernel pads)
+            const double* sbase = A.surv + 4 * s_lo;
+            int wl = wlane;
+            asm volatile("" : "+v"(wl));
+            auto ld = [&](const int e0, double2& x, double2& y) {
+              int e = e0 + wl;
+              e = e < ns_col ? e : ns_col - 1;
+              x = *reinterpret_cast<const double2*>(&sbase[4 * e]);
+              y = *reinterpret_cast<const double2*>(&sbase[4 * e + 2]);
+            };
+            double2 a0, b0, a1, b1, a2, b2, a3, b3;
+            ld(0, a0, b0);
+            ld(64, a1, b1);
+            ld(128, a2, b2);
+            ld(192, a3, b3);
+            // the ctype's three numbers through the scalar cache (a chunk is of ONE type: the survivor kernel pads every type's
+            // entries to whole chunks with rows outside every cut-off)
+            int ic_s = -1, vm_s = 0;
+            double vloc_s = 0.0, varloc_s = 0.0;
+            auto eval = [&](const double2& ca, const double2& cb, const bool live) {
+              const long rw = __double_as_longlong(ca.x);
+              const int ic0 = __builtin_amdgcn_readfirstlane((int)(rw >> 32));
+              if (ic0 != ic_s) {
+                ic_s = ic0;
+                vm_s = t.vmode[ic0];
+                vloc_s = t.vert_loc[ic0];
+                varloc_s = t.varloc[ic0];
+              }
+              const ColVert vo = column_vertical_cal(vm_s, vloc_s, varloc_s, ca.y, cb.x, cb.y, v_z, v_p, l_rain);
+              const bool acc_ = live && vo.rloc != 0.0;                      // :1460
+              const unsigned long long mk = __ballot(acc_);
+              if (acc_) {
+                const long j = o0 + ntot + __popcll(mk & lt_mask);
+                A.sl_idx[j] = (int)(rw & 0xffffffffL);
+                A.sl_rd[j] = vo.rdiag;
+                A.sl_rl[j] = vo.rloc;
+              }
+              ntot += __popcll(mk);
+            };
+            for (int g0 = 0; g0 < ns_col; g0 += 256) {
+              eval(a0, b0, true);
+              ld(g0 + 256, a0, b0);
+              eval(a1, b1, g0 + 64 < ns_col);
+              ld(g0 + 320, a1, b1);
+              eval(a2, b2, g0 + 128 < ns_col);
+              ld(g0 + 384, a2, b2);
+              eval(a3, b3, g0 + 192 < ns_col);
+              ld(g0 + 448, a3, b3);
+            }
+          }
           n = ntot;
         }
       }
