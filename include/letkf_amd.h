@@ -79,8 +79,8 @@ int letkf_ctx_synchronize(letkf_ctx *ctx);
  * horizontal survivors kept in global memory by rings of nd_h^2, a level takes the nearest rings only (letkf_search.hip).
  * 2 (default): where the survivors overflow the column kernel's buffer on average (weighed with a survivor count and two
  * read-backs; a "not dense" verdict is remembered for the same tables and columns -- by their addresses -- and not weighed again:
- * set 1 if the same buffers turn dense later); 1: wherever eligible (criterion 1, every
- * limit <= 128, <= 64 combined types); 0: never. */
+ * set 1 if the same buffers turn dense later); 1: wherever eligible (criterion 1, or 2 with one
+ * variable-localisation factor per merged group; every limit <= 128; <= 64 combined types); 0: never. */
 #define LETKF_OPT_LIMITED_RINGS 3
 int letkf_ctx_set_option(letkf_ctx *ctx, int option, int value);
 

@@ -888,7 +888,7 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
                          const int64_t* obs_off, int32_t* obs_idx, double* rdiag_l, double* rloc_l, int32_t* nobs_ctype,
                          double* cutd_ctype, bool* taken) {
   *taken = false;
-  if (c->limited_rings == 0 || t->criterion != 1 || t->nctype > 64 || nij1 * (int64_t)t->ngroup >= 0x7fffffff) return LETKF_OK;
+  if (c->limited_rings == 0 || t->criterion > 2 || t->nctype > 64 || nij1 * (int64_t)t->ngroup >= 0x7fffffff) return LETKF_OK;
   const void* key[5] = {t->ob_ri, t->ac_ext, t->max_nobs, rig, rjg};
   if (c->limited_rings == 2 && c->ring_no_n == nij1 && std::equal(key, key + 5, c->ring_no)) return LETKF_OK;
   std::vector<int32_t> mx(t->nctype), gstart(t->ngroup + 1);
@@ -898,10 +898,18 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
   std::vector<int32_t> gmem(gstart[t->ngroup]);
   HIP_TRY(hipMemcpy(gmem.data(), t->group_member, sizeof(int32_t) * gmem.size(), hipMemcpyDeviceToHost));
   int nlim = 0;
+  std::vector<double> vl;
+  if (t->criterion == 2) {   // the weight criterion orders like the distance where a group has ONE variable-localisation factor
+    vl.resize(t->nctype);
+    HIP_TRY(hipMemcpy(vl.data(), t->varloc, sizeof(double) * t->nctype, hipMemcpyDeviceToHost));
+  }
   for (int g = 0; g < t->ngroup; ++g) {
     const int nm = mx[gmem[gstart[g]]];
     if (nm > letkf::search_rings_max_nobs()) return LETKF_OK;
     nlim += nm > 0;
+    if (nm > 0 && t->criterion == 2)
+      for (int m = gstart[g] + 1; m < gstart[g + 1]; ++m)
+        if (vl[gmem[m]] != vl[gmem[gstart[g]]]) return LETKF_OK;
   }
   if (nlim == 0) return LETKF_OK;
   const int ng = t->ngroup;

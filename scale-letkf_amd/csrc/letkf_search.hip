@@ -1211,7 +1211,8 @@ hipError_t launch_search_columns_limited(const letkf_search_tables& t, long nij1
 // for a loop body of 1.3 s.  For the distance criterion the selection key is nd = nd_h^2 + nd_v^2 >= nd_h^2, so the survivors of
 // a (column, group) are kept in global memory ORDERED BY RINGS of nd_h^2 (kRings equal steps up to the cut-off): a level takes
 // them tile by tile, nearest ring first, carries the best nmax found so far along, and stops as soon as the nmax-th best key
-// is below the lower bound of the next ring -- at configs[3] after the two innermost rings of sixteen.  Exact: the selected
+// is below the lower bound of the next ring -- at configs[3] after the two innermost rings of sixteen.  (The weight criterion, 2,
+// orders like the distance where a group's types share one variable-localisation factor: served too.)  Exact: the selected
 // SET is the reference's (up to ties of equal keys, as everywhere), nobsl_t and the cut-off measure likewise.
 constexpr int kRings = 16;
 constexpr double kRingScale = (double)kRings / 13.5;    // ring = min(kRings - 1, (int)(nd_h^2 * kRingScale)); 13.5 > dist_zero_fac^2
@@ -1553,7 +1554,8 @@ __global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSe
             unsigned int lmx = ((unsigned int)(kmx >> 32) == hmx) ? (unsigned int)kmx : 0u;
             lmx = wave_max_u32(lmx);
             const double kv = __longlong_as_double((long long)(((unsigned long long)hmx << 32) | lmx));
-            cutd = t.hori_loc[icm] * sqrt(kv);
+            // (criterion 2: the smallest selected weight -- one variable-localisation factor per group, the host checked)
+            cutd = (t.criterion == 1) ? t.hori_loc[icm] * sqrt(kv) : s_varloc[icm] * exp(-0.5 * kv);
           }
           if (A.fill) {
             for (int j = lane; j < nB; j += 64) {

@@ -98,8 +98,8 @@ def test_column_search_with_obs_number_limit(criterion, nlev, max_nobs, rings):
     """MAX_NOBS_PER_GRID on the column path (letkf_tools.f90:1479-1729; merged group (0, 1) under its master's limit,
     :1434-1436): per point the same SET as the per-point kernel -- which the oracle tests pin to the reference's
     selection -- with the same weights, plus the NOBS_OUT inputs nobsl_t and cutd_t (:1633-1640, :1713-1727).
-    rings = 1: the route for DENSE observations forced on (LETKF_OPT_LIMITED_RINGS; distance criterion only -- the others keep
-    the LDS-buffered kernel whatever the option says): survivors by rings of nd_h^2 in global memory, tiles, early stop."""
+    rings = 1: the route for DENSE observations forced on (LETKF_OPT_LIMITED_RINGS; the distance criterion, and the weight criterion
+    where a merged group has one variable-localisation factor as here -- criterion 3 keeps the LDS-buffered kernel whatever the option says): survivors by rings of nd_h^2 in global memory, tiles, early stop."""
     from _gpu import ctx, dev
     case = build_case(33 + criterion, npts=70, max_nobs=max_nobs, criterion=criterion)
     t, keep = device_struct(case, "cuda")
