@@ -82,6 +82,8 @@ int letkf_ctx_synchronize(letkf_ctx *ctx);
  * set 1 if the same buffers turn dense later); 1: wherever eligible (criterion 1, or 2 with one
  * variable-localisation factor per merged group; every limit <= 128; <= 64 combined types); 0: never. */
 #define LETKF_OPT_LIMITED_RINGS 3
+/* LETKF_OPT_RING_BATCH_MB (default 8192): device workspace of the ring route per batch of columns, in MiB. */
+#define LETKF_OPT_RING_BATCH_MB 4
 int letkf_ctx_set_option(letkf_ctx *ctx, int option, int value);
 
 /*---------------------------------------------------------------------------

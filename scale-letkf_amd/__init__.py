@@ -202,6 +202,7 @@ class Context:
     OPT_STAGED_POLY = 1     # include/letkf_amd.h LETKF_OPT_STAGED_POLY
     OPT_COLUMN_SURVIVORS = 2   # LETKF_OPT_COLUMN_SURVIVORS
     OPT_LIMITED_RINGS = 3      # LETKF_OPT_LIMITED_RINGS
+    OPT_RING_BATCH_MB = 4      # LETKF_OPT_RING_BATCH_MB
 
     def set_option(self, option, value):
         self._check(self._l.letkf_ctx_set_option(self._c, C.c_int(option), C.c_int(value)))

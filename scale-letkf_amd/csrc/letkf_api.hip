@@ -67,6 +67,7 @@ struct letkf_ctx {
   bool ring_keep = false;     // inside letkf_das_columns_dev: the survivors of the first search call serve the later ones
   bool ring_ready = false;
   std::vector<int64_t> ring_hoff;
+  int ring_batch_mb = 8192;   // LETKF_OPT_RING_BATCH_MB
   int limited_rings = 2;      // LETKF_OPT_LIMITED_RINGS: 0 never, 1 wherever eligible, 2 where a group's survivors overflow the column kernel's buffer
   char* staged_ws = nullptr;  // staged path: per-point slabs of a batch + meta / info words
   size_t staged_ws_bytes = 0;
@@ -460,6 +461,10 @@ int letkf_ctx_set_option(letkf_ctx* c, int option, int value) {
   if (int rc = check_ctx(c)) return rc;
   switch (option) {
     case LETKF_OPT_STAGED_POLY: c->staged_poly = value != 0; return LETKF_OK;
+    case LETKF_OPT_RING_BATCH_MB:
+      if (value < 1) return fail(LETKF_E_INVALID, "LETKF_OPT_RING_BATCH_MB: >= 1");
+      c->ring_batch_mb = value;
+      return LETKF_OK;
     case LETKF_OPT_LIMITED_RINGS:
       if (value < 0 || value > 2) return fail(LETKF_E_INVALID, "LETKF_OPT_LIMITED_RINGS: 0, 1 or 2");
       c->limited_rings = value;
@@ -964,7 +969,7 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
     }
   }
   *taken = true;
-  // 8 GiB of survivors per batch of columns; inside letkf_das_columns_dev ONE batch, kept for the calls that follow, where
+  // LETKF_OPT_RING_BATCH_MB (8 GiB) of survivors per batch of columns; inside letkf_das_columns_dev ONE batch, kept for the calls that follow, where
   // that takes no more than half of the device memory still free (configs[3] with two limited types: 128 GiB)
   bool keep = false;
   if (c->ring_keep) {
@@ -972,7 +977,7 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
     HIP_TRY(hipMemGetInfo(&fr, &tot));
     keep = (size_t)hoff[ncg] * 32 + 256 <= c->ring_ws_bytes + fr / 2;
   }
-  const int64_t budget = keep ? hoff[ncg] * 32 + 256 : ((int64_t)8 << 30);
+  const int64_t budget = keep ? hoff[ncg] * 32 + 256 : ((int64_t)c->ring_batch_mb << 20);
   int64_t c0 = 0;
   while (c0 < nij1) {
     int64_t c1 = c0 + 1;

@@ -218,6 +218,17 @@ def test_dense_observations_under_a_limit_rings_equal_the_lds_kernel():
     finally:
         c.set_option(c.OPT_LIMITED_RINGS, 2)
     assert np.array_equal(o2.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), i1) and np.array_equal(l2.cpu().numpy(), l1)
+    # ... and a workspace of 2 MiB per batch of columns (the survivors are ~190 MB here: ~100 batches): the same lists to the last row
+    c.set_option(c.OPT_LIMITED_RINGS, 1)
+    c.set_option(c.OPT_RING_BATCH_MB, 2)
+    try:
+        o3, i3, d3, l3 = c.obs_search_columns(t_s, nij1, nlev, rig, rjg, pts[2], pts[3])
+        torch.cuda.synchronize()
+    finally:
+        c.set_option(c.OPT_LIMITED_RINGS, 2)
+        c.set_option(c.OPT_RING_BATCH_MB, 8192)
+    assert np.array_equal(o3.cpu().numpy(), o1) and np.array_equal(i3.cpu().numpy(), i1) and np.array_equal(l3.cpu().numpy(), l1)
+    assert np.array_equal(d3.cpu().numpy(), d1)
     assert np.array_equal(o0, o1) and int(o0[-1]) > 50 * nij1 * nlev
     assert np.array_equal(n0, n1)
     assert np.allclose(c0, c1, rtol=1e-14, atol=0)
