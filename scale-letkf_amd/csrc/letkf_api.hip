@@ -928,7 +928,8 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
   }
   const size_t o_off = ((ncg + 1) * 4 + 255) & ~(size_t)255, o_scan = o_off + (((ncg + 1) * 8 + 255) & ~(size_t)255);
   const size_t o_roff = o_scan + ((scan_b + 255) & ~(size_t)255);
-  const size_t roff_b = ncg * (size_t)(16 + 1) * 4;
+  const size_t nring1 = (size_t)letkf::search_rings_count() + 1;   // ring starts per (column, group)
+  const size_t roff_b = ncg * nring1 * 4;
   const size_t need_aux = o_roff + roff_b + 256;
   if (need_aux > c->ring_aux_bytes) HIP_TRY(hipStreamSynchronize(c->stream));
   if (int rc = ensure_bytes(c, &c->ring_aux, &c->ring_aux_bytes, need_aux)) return rc;
@@ -988,7 +989,7 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
     if (int rc = ensure_bytes(c, &c->ring_ws, &c->ring_ws_bytes, need)) return rc;
     double* sv = reinterpret_cast<double*>(c->ring_ws) - 4 * hoff[(size_t)c0 * ng];
     const long* gq = reinterpret_cast<const long*>(goff + (size_t)c0 * ng);
-    int32_t* rq = roff + (size_t)c0 * ng * 17;
+    int32_t* rq = roff + (size_t)c0 * ng * nring1;
     HIP_TRY(letkf::launch_ring_survivors(*t, c0, c1 - c0, rig, rjg, 1, nullptr, gq, sv, rq, c->num_cu, c->stream));
     HIP_TRY(letkf::launch_search_rings(*t, c0, c1 - c0, nij1, nlev, rlev, rz, fill, counts, reinterpret_cast<const long*>(obs_off),
                                        obs_idx, rdiag_l, rloc_l, nobs_ctype, cutd_ctype, gq, sv, rq, c->num_cu, c->stream));

@@ -168,6 +168,7 @@ hipError_t launch_search_rings(const letkf_search_tables& t, long col0, long nco
                                double* rloc_l, int* nobs_ctype, double* cutd_ctype, const long* goff, const double* sv,
                                const int* roff, int num_cu, hipStream_t st);
 int search_rings_max_nobs();
+int search_rings_count();
 int search_rings_lds_survivors();
 hipError_t launch_survivors(const letkf_search_tables& t, long col0, long ncol, const double* rig, const double* rjg, int fill,
                             int* counts, const long* sv_off, double* sv, int num_cu, hipStream_t st);

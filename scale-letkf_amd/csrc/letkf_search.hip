@@ -1609,6 +1609,7 @@ hipError_t launch_search_rings(const letkf_search_tables& t, long col0, long nco
 }
 
 int search_rings_max_nobs() { return kRingSel; }
+int search_rings_count() { return kRings; }
 int search_rings_lds_survivors() { return kSurvL; }
 
 // ------------------------------------------------------------------ the horizontal half of obs_local, once per column
