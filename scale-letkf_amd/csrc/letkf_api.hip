@@ -240,7 +240,7 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, int warm_run = 0, long warm_stride
     if (int rc = ensure_bytes(c, &c->warm_ws, &c->warm_ws_bytes, wbytes)) return rc;
     a.warm_ws = reinterpret_cast<double*>(c->warm_ws);
     if (a.mode == 3) {   // one local-list slot per wave of the grid (4 waves per workgroup): idx | rdiag | rloc
-      const size_t nslot = (size_t)a.wave_grid * 4, cap = (size_t)(a.sl_cap > 0 ? a.sl_cap : 4);
+      const size_t nslot = (size_t)a.wave_grid * 4, cap = 2 * (size_t)(a.sl_cap > 0 ? a.sl_cap : 4);   // (two lists per wave: this level's and the next one's)
       const size_t o_rd = (nslot * cap * 4 + 255) & ~(size_t)255, o_rl = o_rd + nslot * cap * 8;
       const size_t need = o_rl + nslot * cap * 8 + 256;
       if (need > c->slot_ws_bytes) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -733,7 +733,7 @@ int letkf_das_columns_dev(letkf_ctx* c, const letkf_das_args* g, const letkf_sea
       // (2 = automatic: the list-free route where the lists of all levels would not fit the workspace at once -- about half
       // of a column's horizontal survivors pass a level's vertical cut-off, 20 B each.  Where they fit, one fill pass for
       // the whole domain is cheaper than the vertical half inside the register-bound loop body kernel: C2, 203 local
-      // observations per point, 384 against 394 ms per analysis; BASELINE configs[3], 4900 per point, 40 slabs: 7.45 against 6.26 s.)
+      // observations per point, 384 against 394 ms per analysis; BASELINE configs[3], 4900 per point, 40 slabs: 7.45 against 6.11 s.)
       const bool take = c->col_survivors == 1 || (double)hoff[nij1] * (double)nlev * 10.0 > (double)list_bytes;
       // batches of columns whose survivors fit the workspace (32 B each), at least one column
       int64_t c0 = take ? 0 : nij1;

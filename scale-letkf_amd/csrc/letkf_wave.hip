@@ -678,6 +678,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
    const long rchunk = rid / S, rb = rid - rchunk * S;
    const long ra0 = rchunk * run_len;
    bool have_u = false;
+   [[maybe_unused]] int pre_n = -1;             // mode 3: the NEXT point's list was assembled with this one's (its length; second half of the slot)
    for (int ir = ir0; ir < ir1; ++ir) {
     if (ra0 + ir >= nA) break;
     long pt = (ra0 + ir) * S + rb;
@@ -712,14 +713,25 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
         // BASELINE configs[3] -- never exist, nor does the count pass over the levels.  (First version: the accepted rows went
         // straight into the Gram's staging buffer, flush and matrix-core steps inside this loop -- the four buffers and the
         // evaluated chunks stayed live across them, 800 B/lane of scratch, slower than the lists.)
-        if (beta != 0.0) {
+        // Two levels per pass: the survivors are read once for this point AND the next one of the run (one level up the same
+        // column): the stream is what bounds the pre-pass (configs[3]: 1.1 MB per point and level), the arithmetic doubles per
+        // entry and halves per point.  The next point finds its list in the other half of the wave's slot (2 sl_cap entries).
+        if (pre_n >= 0) {
+          o0 = ((long)blockIdx.x * PPW + wv) * (2 * A.sl_cap) + A.sl_cap;
+          n = pre_n;
+          pre_n = -1;
+        } else if (beta != 0.0) {
           using namespace search_dev;
           const letkf_search_tables& t = A.stab;
-          o0 = ((long)blockIdx.x * PPW + wv) * A.sl_cap;
+          o0 = ((long)blockIdx.x * PPW + wv) * (2 * A.sl_cap);
+          const long o1 = o0 + A.sl_cap;
+          const bool two = ir + 1 < ir1 && ra0 + ir + 1 < nA;            // (wave-uniform) a next point in this run
+          const long ptn = two ? pt + (A.pt_stride ? A.pt_stride : S) : pt;
           const double v_z = A.prz[pt], v_p = log(A.prlev[pt]), l_rain = log(t.rain_base);
+          const double v_z1 = A.prz[ptn], v_p1 = log(A.prlev[ptn]);
           const unsigned long long lt_mask = (wlane == 0) ? 0ull : (~0ull >> (64 - wlane));
           const long s_lo = A.sv_off[rb], s_hi = A.sv_off[rb + 1];
-          int ntot = 0;
+          int ntot = 0, ntot1 = 0;
           if (s_hi > s_lo) {
             // Four chunks of 64 entries in flight, in four buffers with STATIC names: the survivors stream from HBM (no wave
             // reads a column's list while it is still in a cache: 320 KB per column at configs[3], 2048 columns in flight).
@@ -757,16 +769,30 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
                 vloc_s = t.vert_loc[ic0];
                 varloc_s = t.varloc[ic0];
               }
-              const ColVert vo = column_vertical_cal(vm_s, vloc_s, varloc_s, ca.y, cb.x, cb.y, v_z, v_p, l_rain);
-              const bool acc_ = live && vo.rloc != 0.0;                      // :1460
-              const unsigned long long mk = __ballot(acc_);
-              if (acc_) {
-                const long j = o0 + ntot + __popcll(mk & lt_mask);
-                A.sl_idx[j] = (int)(rw & 0xffffffffL);
-                A.sl_rd[j] = vo.rdiag;
-                A.sl_rl[j] = vo.rloc;
+              {
+                const ColVert vo = column_vertical_cal(vm_s, vloc_s, varloc_s, ca.y, cb.x, cb.y, v_z, v_p, l_rain);
+                const bool acc_ = live && vo.rloc != 0.0;                    // :1460
+                const unsigned long long mk = __ballot(acc_);
+                if (acc_) {
+                  const long j = o0 + ntot + __popcll(mk & lt_mask);
+                  A.sl_idx[j] = (int)(rw & 0xffffffffL);
+                  A.sl_rd[j] = vo.rdiag;
+                  A.sl_rl[j] = vo.rloc;
+                }
+                ntot += __popcll(mk);
               }
-              ntot += __popcll(mk);
+              if (two) {                                                     // (wave-uniform)
+                const ColVert vo = column_vertical_cal(vm_s, vloc_s, varloc_s, ca.y, cb.x, cb.y, v_z1, v_p1, l_rain);
+                const bool acc_ = live && vo.rloc != 0.0;
+                const unsigned long long mk = __ballot(acc_);
+                if (acc_) {
+                  const long j = o1 + ntot1 + __popcll(mk & lt_mask);
+                  A.sl_idx[j] = (int)(rw & 0xffffffffL);
+                  A.sl_rd[j] = vo.rdiag;
+                  A.sl_rl[j] = vo.rloc;
+                }
+                ntot1 += __popcll(mk);
+              }
             };
             for (int g0 = 0; g0 < ns_col; g0 += 256) {
               eval(a0, b0, true);
@@ -779,6 +805,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
               ld(g0 + 448, a3, b3);
             }
           }
+          if (two) pre_n = ntot1;
           n = ntot;
         }
       }
