@@ -198,12 +198,23 @@ def main():
         w["dep"] *= ((1.0 + args.obs_spread ** 2) / (1.0 + spread_built ** 2)) ** 0.5   # departures ~ N(0, err^2 + spread^2)
     obs_spread = args.obs_spread if args.obs_spread > 0.0 else spread_built
     search_ms = None
+    host_lists_ok = True
     in_step = args.lists in ("search", "columns") and not args.no_search_in_step
     if args.lists != "torch":
         # the table as set_letkf_obs leaves it behind: rows in mesh order, prefix sums per cell
         t_s, keep_s, order_s, pts_s = bw.search_tables(w, pkg, dev, max_nobs=args.max_nobs)
+        n_rows_unsorted = int(w["ensval"].shape[0])
         w["ensval"] = w["ensval"][order_s].contiguous()
         w["dep"] = w["dep"][order_s].contiguous()
+        if args.lists in ("fused", "pipeline") and w.get("obs_idx") is not None:
+            # the torch-built lists (kept for the CPU checker: these two modes have no lists of their own on the host side) index
+            # the table in its ORIGINAL order: through the inverse of the sort (the table may have lost rows on the way: a list
+            # that names one cannot be checked)
+            inv_s = torch.full((n_rows_unsorted,), -1, dtype=torch.int64, device=order_s.device)
+            inv_s[order_s.long()] = torch.arange(order_s.numel(), device=order_s.device, dtype=torch.int64)
+            mapped = inv_s[w["obs_idx"].long()]
+            host_lists_ok = bool((mapped >= 0).all().item())
+            w["obs_idx"] = mapped.clamp(min=0).to(w["obs_idx"].dtype)
     if args.lists in ("search", "columns") and slab_mode:
         nij_s = w["cfg"]["nx"] * w["cfg"]["ny"]
         rig_s, rjg_s = pts_s[0][:nij_s].contiguous(), pts_s[1][:nij_s].contiguous()
@@ -420,7 +431,8 @@ def main():
                             "(HIP events), ms_per_step also holds obs_local when search_in_step"}
         cpu = cpu_ref = None
         parity = None
-        if n_gpus == 1 and not args.no_cpu_baseline and not args.no_torch_lists:
+        # (--lists pipeline under a limit: the host has only the torch builder's UNLIMITED lists -- nothing to check against)
+        if n_gpus == 1 and not args.no_cpu_baseline and not args.no_torch_lists and not (args.lists == "pipeline" and args.max_nobs > 0) and host_lists_ok:
             cpu, parity = cpu_baseline(w_chk, relax, args.cpu_seconds, args.cpu_threads, anal_chk)
             cpu_ref = cpu_baseline_reference(w_chk, args.cpu_threads, min(args.cpu_seconds, 10.0))
             if parity is not None and not (parity <= 1e-10):
