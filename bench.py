@@ -210,11 +210,7 @@ def main():
             # the torch-built lists (kept for the CPU checker: these two modes have no lists of their own on the host side) index
             # the table in its ORIGINAL order: through the inverse of the sort (the table may have lost rows on the way: a list
             # that names one cannot be checked)
-            inv_s = torch.full((n_rows_unsorted,), -1, dtype=torch.int64, device=order_s.device)
-            inv_s[order_s.long()] = torch.arange(order_s.numel(), device=order_s.device, dtype=torch.int64)
-            mapped = inv_s[w["obs_idx"].long()]
-            host_lists_ok = bool((mapped >= 0).all().item())
-            w["obs_idx"] = mapped.clamp(min=0).to(w["obs_idx"].dtype)
+            w["obs_idx"], host_lists_ok = bw.remap_lists_to_sorted(w["obs_idx"], order_s, n_rows_unsorted)
     if args.lists in ("search", "columns") and slab_mode:
         nij_s = w["cfg"]["nx"] * w["cfg"]["ny"]
         rig_s, rjg_s = pts_s[0][:nij_s].contiguous(), pts_s[1][:nij_s].contiguous()

@@ -362,6 +362,18 @@ def search_tables(w, pkg, device, max_nobs=0):
     return t, keep, order, (pri, prj, prl, prz)
 
 
+def remap_lists_to_sorted(obs_idx, order, n_rows_unsorted):
+    """The torch builder's list entries index the observation table in its original order; `order` (search_tables) is the
+    row order of the sorted table (sorted row i = original row order[i], possibly a subset, possibly with repeats shifted by
+    the table length for a second combined type).  Returns (the entries as rows of the SORTED table, whether every entry
+    has one): an entry that names a row the sorted table lost maps to row 0 and makes the second value False."""
+    inv = torch.full((n_rows_unsorted,), -1, dtype=torch.int64, device=order.device)
+    inv[order.long()] = torch.arange(order.numel(), device=order.device, dtype=torch.int64)
+    mapped = inv[obs_idx.long()]
+    ok = bool((mapped >= 0).all().item())
+    return mapped.clamp(min=0).to(obs_idx.dtype), ok
+
+
 def sample_points(w, pts):
     """Host copies of everything the loop body reads for the grid points `pts` (sorted numpy int64): CSR lists
     re-based to the sample, the sample's slice of the state.  For the CPU checker / baseline (bench.py, tests)."""

@@ -45,3 +45,20 @@ def test_local_lists_match_obs_local_cal():
         assert got.tolist() == [e[0] for e in exp], pt
         assert np.allclose(rloc[off[pt]:off[pt + 1]], [e[1] for e in exp], rtol=1e-12, atol=0)
         assert np.allclose(rdiag[off[pt]:off[pt + 1]], [e[2] for e in exp], rtol=1e-12, atol=0)
+
+
+def test_remap_lists_to_sorted_table():
+    """bench.py --lists pipeline / fused: the CPU checker's lists follow the table through its mesh sort (a subset of the rows on
+    the disc workloads); an entry whose row the sorted table lost is reported, never used as an index."""
+    import torch
+    import bench_workload as bw
+    order = torch.tensor([5, 2, 7, 0], dtype=torch.int64)          # sorted row i = original row order[i]; rows 1, 3, 4, 6 lost
+    idx = torch.tensor([0, 7, 2, 5, 5], dtype=torch.int32)
+    mapped, ok = bw.remap_lists_to_sorted(idx, order, 8)
+    assert ok and mapped.tolist() == [3, 2, 1, 0, 0] and mapped.dtype == torch.int32
+    mapped, ok = bw.remap_lists_to_sorted(torch.tensor([0, 3], dtype=torch.int32), order, 8)
+    assert not ok and mapped.tolist() == [3, 0]
+    # a second combined type: the table twice, the second copy's rows shifted by the table length
+    order2 = torch.cat([order, order + 8])
+    mapped, ok = bw.remap_lists_to_sorted(torch.tensor([5, 13], dtype=torch.int32), order2, 16)
+    assert ok and mapped.tolist() == [0, 4]
