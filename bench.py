@@ -399,6 +399,7 @@ def main():
         kern_s = kern_ms * 1e-3
         achieved = b_alg * npts / kern_s / 1e9 if kern_s > 0 else None
         traffic = None
+        traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_member.json" if args.state_layout == "member" else "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -406,6 +407,9 @@ def main():
                 if (tj.get("workload") == args.workload and args.ensval == "iid" and args.max_nobs == 0
                         and tj.get("state_layout", "ref") == args.state_layout):
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = (f"{os.path.relpath(tpath, ROOT)}: rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, "
+                                      f"MI355X_MICROARCH.md) of build {tj.get('build', '?')} on this workload -- a recorded constant, "
+                                      f"NOT measured by this run")
             except Exception:
                 traffic = None
         # Which roof bounds the kernel: arithmetic intensity of the algorithmic work against the ridge of the chip
@@ -416,7 +420,7 @@ def main():
         compute_bound = f_alg / b_alg > 78.6e12 / 8.0e12
         main_ = fp64 if compute_bound else hbm
         roofline = {"bound": "mfma" if compute_bound else "hbm", "achieved": main_["achieved"], "peak": main_["peak"],
-                    "unit": main_["unit"], "frac": main_["frac"], "traffic": traffic,
+                    "unit": main_["unit"], "frac": main_["frac"], "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": ctx.last_path(), "kernel_ms": kern_ms, "kernel_ms_per_launch": kern_launch_ms,
                     "launches": nlaunch, "alg_bytes_per_solve": b_alg, "alg_flops_per_solve": f_alg,
                     "alg_flops_kxk_nominal": f_kxk,
@@ -427,12 +431,26 @@ def main():
                             "(HIP events), ms_per_step also holds obs_local when search_in_step"}
         cpu = cpu_ref = None
         parity = None
-        # (--lists pipeline under a limit: the host has only the torch builder's UNLIMITED lists -- nothing to check against)
-        if n_gpus == 1 and not args.no_cpu_baseline and not args.no_torch_lists and not (args.lists == "pipeline" and args.max_nobs > 0) and host_lists_ok:
-            cpu, parity = cpu_baseline(w_chk, relax, args.cpu_seconds, args.cpu_threads, anal_chk)
-            cpu_ref = cpu_baseline_reference(w_chk, args.cpu_threads, min(args.cpu_seconds, 10.0))
-            if parity is not None and not (parity <= 1e-10):
-                rc = 3
+        parity_note = None
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            # The checker's local-observation lists come from the ORACLE's obs_local (oracle/letkf_oracle.c orc_obs_local, limit
+            # and criterion included) on a host copy of the same tables -- not from the device search, whichever route the step
+            # took: the list-free and pipeline routes and the runs under MAX_NOBS_PER_GRID are checked like every other.
+            # (--lists torch has no tables: the torch builder's lists serve.)
+            chk = None
+            if args.lists != "torch":
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import _search
+                h_, alive_ = _search.host_struct_from_torch(t_s, keep_s)
+                lo_ = slab_stat["last"][0] if slab_mode else 0
+                hi_ = slab_stat["last"][1] if slab_mode else npts
+                chk = dict(tables=h_, alive=alive_, coords=[c_[lo_:hi_].cpu().numpy() for c_ in pts_s], limited=args.max_nobs > 0)
+            if chk is not None or (w_chk.get("obs_off") is not None and host_lists_ok):
+                cpu, parity, parity_note = cpu_baseline(w_chk, relax, args.cpu_seconds, args.cpu_threads, anal_chk, chk)
+                if w_chk.get("obs_off") is not None and host_lists_ok:
+                    cpu_ref = cpu_baseline_reference(w_chk, args.cpu_threads, min(args.cpu_seconds, 10.0))
+                if parity is not None and not (parity <= 1e-10):
+                    rc = 3
         out = {"metric": "grid-point LETKF solves/sec", "value": value, "unit": "solves/s", "n_gpus": n_gpus,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
@@ -455,7 +473,7 @@ def main():
                "obs_spread": obs_spread,
                "lists": args.lists, "search_ms": search_ms,
                "search_in_step": bool(in_step),
-               "parity_sample_max_rel": parity, "parity_tolerance": 1e-10,
+               "parity_sample_max_rel": parity, "parity_tolerance": 1e-10, "parity_lists": parity_note,
                "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_reference": cpu_ref}
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -479,10 +497,15 @@ def host_threads(requested):
     return min(n, 16)   # a one-GPU box's CPU share is 16 cores
 
 
-def cpu_baseline(w, relax, seconds, threads, anal):
+def cpu_baseline(w, relax, seconds, threads, anal, chk=None):
     """The oracle's OpenMP restatement of the same loop body on a bounded sample of the same points (kind "port"),
     timed on this box's host cores -- and the GPU analysis of those very points checked against it
-    (max over variables of |d xa| / max(|x-bar|, |x'|)).  A reported baseline, not the target."""
+    (max over variables of |d xa| / max(|x-bar|, |x'|)).  A reported baseline, not the target.
+    chk = dict(tables, coords, limited): the sample's local-observation lists are built by the oracle's own obs_local
+    (orc_obs_local: scale/letkf/letkf_tools.f90:1325-1759) on the host copy `tables` of the search tables, for the points at
+    `coords` -- the check is then independent of the device search.  Under MAX_NOBS_PER_GRID a point whose selection falls
+    between EQUAL keys at the threshold is left out (the reference's quick-select is unstable there, common_sort.f90:341-369:
+    either choice is its result, and a lattice has such points).  The list building is not part of the timed baseline."""
     import numpy as np
     import torch
     import bench_workload as bw
@@ -493,10 +516,31 @@ def cpu_baseline(w, relax, seconds, threads, anal):
     ens = w["ensval"].cpu().numpy()
     dep = w["dep"].cpu().numpy()
     rng = np.random.default_rng(1)
+    note = {"lists": "device search / torch builder", "points": 0, "left_out_for_ties": 0}
+
+    def sample(pts):
+        if chk is None:
+            return bw.sample_points(w, pts)
+        import _search
+        co = chk["coords"]
+        off, idx, rd, rl, tied = _search.oracle_csr(chk["tables"], co[0][pts], co[1][pts], co[2][pts], co[3][pts], nthreads=ncores)
+        if chk["limited"] and tied.any():
+            keep = tied == 0
+            ent = np.repeat(keep, np.diff(off))
+            cnt = np.diff(off)[keep]
+            off = np.zeros(len(cnt) + 1, dtype=np.int64)
+            off[1:] = np.cumsum(cnt)
+            idx, rd, rl, pts = idx[ent], rd[ent], rl[ent], pts[keep]
+            note["left_out_for_ties"] += int((~keep).sum())
+        note["lists"] = "oracle obs_local (orc_obs_local) on a host copy of the tables"
+        tp = torch.from_numpy(pts).to(w["gues"].device)
+        gv = bw.state_view(w, w["gues"])[:, :, tp].contiguous().cpu().numpy().reshape(-1)
+        return dict(off=off, idx=idx, rdiag=rd, rloc=rl, gues=gv, ns=len(pts), pts=pts)
 
     def run(ns):
-        pts = np.sort(rng.choice(npts, size=ns, replace=False))
-        s = bw.sample_points(w, pts)
+        s = sample(np.sort(rng.choice(npts, size=ns, replace=False)))
+        pts, ns = s["pts"], s["ns"]
+        note["points"] += ns
         prm = _oracle.DasParams(k=k, nv=nv, det_run=0, infl_adaptive=0, relax_to_inflated_prior=0,
                                 relax_alpha=relax.get("relax_alpha", 0.0),
                                 relax_alpha_spread=relax.get("relax_alpha_spread", 0.0), q_update_top=0.0,
@@ -523,7 +567,7 @@ def cpu_baseline(w, relax, seconds, threads, anal):
     rate, p1 = run(ns)
     return ({"value": rate, "unit": "solves/s", "cores": ncores, "kind": "port",
              "sample": f"{ns} randomly chosen grid points of the same workload (all {nv} variables, same relaxation), "
-                       f"oracle/letkf_oracle.c orc_das_letkf_points, OpenMP dynamic over points"}, max(p0, p1))
+                       f"oracle/letkf_oracle.c orc_das_letkf_points, OpenMP dynamic over points"}, max(p0, p1), note)
 
 
 def cpu_baseline_reference(w, threads, seconds):

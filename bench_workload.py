@@ -73,8 +73,16 @@ CONFIGS = {
     # C2's grid at k = 20 (the memory-bound regime of configs[0]: arithmetic intensity ~5 flop/B)
     "C2-k20": dict(nx=240, ny=240, nz=60, k=20, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2900.0, err=3.0,
                    ztop=18000.0, seed=20240633),
-    "C1": dict(nx=40, ny=40, nz=30, k=20, dx=15000.0, hloc=120000.0, vloc=4000.0, spacing=30000.0, err=3.0,
-               ztop=18000.0, seed=20240608),
+    # BASELINE configs[0] as SURVEY.md section 8(d) specifies it: 40 x 40 x 30 at DX = 15 km, k = 20, 500 observations at
+    # uniformly random positions, conventional upper-air type (ADPUPA): vertical localisation in ln p (letkf_tools.f90:1864,
+    # scale 0.4), HORI_LOCAL 500 km -- the horizontal cut-off covers the whole domain, so n is whatever the ln-p test leaves of
+    # the 500 (round 3's C1 was a 400-observation radar lattice with z localisation)
+    "C1": dict(nx=40, ny=40, nz=30, k=20, dx=15000.0, hloc=500000.0, vloc=0.4, err=1.0, ztop=18000.0, seed=20240608,
+               obs="random", nobs=500, vmode=0),
+    # configs[3]'s observation density inside a radar disc, nothing outside: columns with ~16 k, a few hundred and no horizontal
+    # survivors in one call (the list-free route's batches, passes and empty columns)
+    "C4-slab-disc": dict(nx=48, ny=44, nz=7, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=1100.0, err=3.0,
+                         ztop=18000.0, seed=20240635, halo=True, disc=16000.0),
 }
 
 
@@ -108,6 +116,8 @@ def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval_kind="
     """lists = False: no torch-built local-observation lists (the full-size configurations: the lists come from the
     device search, one level slab at a time)."""
     cfg = CONFIGS[cfg_name]
+    if cfg.get("obs") == "random":
+        return build_random(cfg_name, device, nv=nv, det_run=det_run, rank=rank, lists=lists)
     nx, ny, nz, k = cfg["nx"], cfg["ny"], cfg["nz"], cfg["k"]
     dx, hloc, vloc, sp_o, err = cfg["dx"], cfg["hloc"], cfg["vloc"], cfg["spacing"], cfg["err"]
     g = torch.Generator(device=device)
@@ -199,6 +209,94 @@ def build(cfg_name, device, nv=11, det_run=False, rank=0, world=1, ensval_kind="
                 sig=sig, gen=g)
 
 
+def p_mean(z):
+    """p = 1000 hPa * exp(-z / 7.5 km)"""
+    return 1.0e5 * torch.exp(-z / 7500.0)
+
+
+def build_random(cfg_name, device, nv=11, det_run=False, rank=0, lists=True):
+    """Workloads whose observations sit at uniformly random positions (cfg["obs"] == "random"; C1): conventional type,
+    vertical localisation in ln p (vmode 0: |ln p_obs - ln p_point| / vloc, letkf_tools.f90:1864).  The lists are the
+    brute-force evaluation of obs_local_cal (:1793-1906) for every (point, observation) pair in table order."""
+    cfg = CONFIGS[cfg_name]
+    nx, ny, nz, k, dx = cfg["nx"], cfg["ny"], cfg["nz"], cfg["k"], cfg["dx"]
+    hloc, vloc, err, nobs = cfg["hloc"], cfg["vloc"], cfg["err"], cfg["nobs"]
+    f64 = torch.float64
+    g = torch.Generator(device=device)
+    g.manual_seed(cfg["seed"] + 7919 * rank)
+    u = torch.rand(3, nobs, generator=g, device=device, dtype=f64)
+    ob_x, ob_y, ob_z = u[0] * nx * dx, u[1] * ny * dx, u[2] * cfg["ztop"]
+    ob_p = p_mean(ob_z)
+    kld = k + 1
+    ensval = torch.randn(nobs, kld, generator=g, device=device, dtype=f64) * 2.0
+    ensval[:, :k] -= ensval[:, :k].mean(dim=1, keepdim=True)
+    dep = torch.randn(nobs, generator=g, device=device, dtype=f64) * math.sqrt(err * err + 4.0)
+    zlev = torch.from_numpy(level_heights(nz, cfg["ztop"])).to(device)
+    plev = p_mean(zlev)
+    nij = nx * ny
+    npts = nij * nz
+    # the table order of search_tables(): rows sorted by mesh cell (j, i), stable -- the brute-force lists below follow the
+    # candidate order of obs_local (mesh row j, then table row), which for a rectangle that covers whole mesh rows IS table order
+    counts = torch.zeros(1, dtype=torch.int64, device=device)
+    obs_off = obs_idx = rloc = rdiag = None
+    if lists:
+        _, order = random_mesh(cfg, ob_x, ob_y)
+        sx, sy, sp_ = ob_x[order] / dx, ob_y[order] / dx, ob_p[order]
+        gx = (torch.arange(nx, device=device, dtype=f64) + 0.5)
+        gy = (torch.arange(ny, device=device, dtype=f64) + 0.5)
+        pri, prj = gx.repeat(ny), gy.repeat_interleave(nx)
+        rdx = (pri[:, None] - sx[None, :]) * dx
+        rdy = (prj[:, None] - sy[None, :]) * dx
+        ndh = torch.sqrt(rdx * rdx + rdy * rdy) / hloc                         # [nij, nobs]
+        cnt_l, idx_l, rl_l = [], [], []
+        for lev in range(nz):
+            ndv = (torch.log(sp_) - torch.log(plev[lev])).abs() / vloc           # [nobs]
+            nd2 = ndh * ndh + (ndv * ndv)[None, :]
+            ok = (ndv <= DIST_ZERO_FAC)[None, :] & (ndh <= DIST_ZERO_FAC) & (nd2 <= DIST_ZERO_FAC_SQUARE)
+            cnt_l.append(ok.sum(dim=1))
+            sel = ok.reshape(-1).nonzero(as_tuple=False).squeeze(1)
+            idx_l.append(order[sel % nobs].to(torch.int32))                      # (entries name ORIGINAL rows, as build())
+            rl_l.append(torch.exp(-0.5 * nd2.reshape(-1)[sel]))
+        counts = torch.cat(cnt_l)
+        obs_off = torch.zeros(npts + 1, dtype=torch.int64, device=device)
+        obs_off[1:] = torch.cumsum(counts, 0)
+        obs_idx, rloc = torch.cat(idx_l), torch.cat(rl_l)
+        rdiag = (err * err) / rloc
+    nens = k + 1 + (1 if det_run else 0)
+    gues = torch.empty(nv * nens * npts, dtype=f64, device=device)
+    gv = gues.view(nv, nens, npts)
+    sig = [2.0, 2.0, 2.0, 1.0, 50.0] + [1e-3] * (nv - 5)
+    mean0 = [10.0, 5.0, 0.1, 280.0, 8.0e4] + [5e-3] * (nv - 5)
+    for v in range(nv):
+        gv[v].normal_(mean0[v], sig[v], generator=g)
+    return dict(cfg=cfg, name=cfg_name, k=k, nv=nv, npts=npts, nens=nens, kld=kld, nobs=nobs, ensval=ensval, dep=dep,
+                obs_off=obs_off, obs_idx=obs_idx, rdiag=rdiag, rloc=rloc, gues=gues, sp=1, sm=npts, sv=npts * nens,
+                n_mean=float(counts.double().mean()), n_max=int(counts.max()), det_run=det_run, ensval_kind="iid",
+                sig=sig, gen=g, ob_x=ob_x, ob_y=ob_y, ob_lev=ob_p)
+
+
+def mesh_shape(cfg):
+    """The sorting mesh of set_letkf_obs for one combined type (letkf_obs.f90:655-695): (ngrd_i, ngrd_j, nsch_i, nsch_j)."""
+    nx, ny, dx, hloc = cfg["nx"], cfg["ny"], cfg["dx"], cfg["hloc"]
+    spc = hloc * DIST_ZERO_FAC / 6.0
+    ngrd_i = min(math.ceil(dx * nx / spc), nx)
+    ngrd_j = min(math.ceil(dx * ny / spc), ny)
+    nsch_i = math.ceil(hloc * DIST_ZERO_FAC / (dx * nx / ngrd_i))
+    nsch_j = math.ceil(hloc * DIST_ZERO_FAC / (dx * ny / ngrd_j))
+    return ngrd_i, ngrd_j, nsch_i, nsch_j
+
+
+def random_mesh(cfg, ob_x, ob_y):
+    """(cell index per observation, stable sort order by cell) on that mesh, for observations at (ob_x, ob_y) metres."""
+    nx, ny, dx = cfg["nx"], cfg["ny"], cfg["dx"]
+    ngrd_i, ngrd_j, nsch_i, nsch_j = mesh_shape(cfg)
+    next_i, next_j = ngrd_i + 2 * nsch_i, ngrd_j + 2 * nsch_j
+    ogi = (torch.ceil(ob_x / dx * ngrd_i / nx).long() + nsch_i).clamp(1, next_i)
+    ogj = (torch.ceil(ob_y / dx * ngrd_j / ny).long() + nsch_j).clamp(1, next_j)
+    cell = (ogj - 1) * next_i + (ogi - 1)
+    return cell, torch.argsort(cell, stable=True)
+
+
 def state_view(w, t):
     """[v, m, p] view of a state buffer in the workload's layout (element (p, m, v) at p*sp + m*sm + v*sv)."""
     return torch.as_strided(t, (w["nv"], w["nens"], w["npts"]), (w["sv"], w["sm"], w["sp"]))
@@ -284,22 +382,25 @@ def search_tables(w, pkg, device, max_nobs=0):
     torch.  Returns (tables struct, keepalive, row order, point coordinate tensors)."""
     cfg = w["cfg"]
     nx, ny, nz = cfg["nx"], cfg["ny"], cfg["nz"]
-    dx, hloc, vloc, sp_o = cfg["dx"], cfg["hloc"], cfg["vloc"], cfg["spacing"]
+    dx, hloc, vloc = cfg["dx"], cfg["hloc"], cfg["vloc"]
     f64 = torch.float64
-    ox, oy, oz, _, _ = lattice(cfg, device)
-    nox, noy, noz = len(ox), len(oy), len(oz)
-    # lattice row index = (iz*noy + iy)*nox + ix  (as in build())
-    ri = (ox / dx).repeat(noy * noz)
-    rj = (oy / dx).repeat_interleave(nox).repeat(noz)
-    lev = oz.repeat_interleave(nox * noy)
-    nlat = ri.numel()                                  # rows of the full lattice (= rows of w["ensval"])
-    kept = disc_mask(cfg, ox, oy).reshape(-1).repeat(noz).nonzero(as_tuple=False).squeeze(1)   # lattice rows with an observation
-    ri, rj, lev = ri[kept], rj[kept], lev[kept]
-    spc = hloc * DIST_ZERO_FAC / 6.0
-    ngrd_i = min(math.ceil(dx * nx / spc), nx)
-    ngrd_j = min(math.ceil(dx * ny / spc), ny)
-    nsch_i = math.ceil(hloc * DIST_ZERO_FAC / (dx * nx / ngrd_i))
-    nsch_j = math.ceil(hloc * DIST_ZERO_FAC / (dx * ny / ngrd_j))
+    random_obs = cfg.get("obs") == "random"
+    if random_obs:
+        ri, rj, lev = w["ob_x"] / dx, w["ob_y"] / dx, w["ob_lev"]
+        nlat = ri.numel()
+        kept = torch.arange(nlat, device=device)
+    else:
+        sp_o = cfg["spacing"]
+        ox, oy, oz, _, _ = lattice(cfg, device)
+        nox, noy, noz = len(ox), len(oy), len(oz)
+        # lattice row index = (iz*noy + iy)*nox + ix  (as in build())
+        ri = (ox / dx).repeat(noy * noz)
+        rj = (oy / dx).repeat_interleave(nox).repeat(noz)
+        lev = oz.repeat_interleave(nox * noy)
+        nlat = ri.numel()                                  # rows of the full lattice (= rows of w["ensval"])
+        kept = disc_mask(cfg, ox, oy).reshape(-1).repeat(noz).nonzero(as_tuple=False).squeeze(1)   # lattice rows with an observation
+        ri, rj, lev = ri[kept], rj[kept], lev[kept]
+    ngrd_i, ngrd_j, nsch_i, nsch_j = mesh_shape(cfg)
     next_i, next_j = ngrd_i + 2 * nsch_i, ngrd_j + 2 * nsch_j
     # (lattice rows beyond the extended mesh -- a halo lattice can reach a fraction of a spacing past the cut-off -- are
     # clamped into its edge cells: they are outside every point's cut-off anyway)
@@ -319,7 +420,7 @@ def search_tables(w, pkg, device, max_nobs=0):
     t.dx, t.dy, t.i_org, t.j_org, t.rain_base = dx, dx, 0.0, 0.0, 8.5e4
     i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
     d64 = lambda v: torch.tensor(v, dtype=f64, device=device)
-    keep = dict(group_start=i32([0, 1]), group_member=i32([0]), vmode=i32([1]), hori_loc=d64([hloc]),
+    keep = dict(group_start=i32([0, 1]), group_member=i32([0]), vmode=i32([cfg.get("vmode", 1)]), hori_loc=d64([hloc]),
                 vert_loc=d64([vloc]), varloc=d64([1.0]), max_nobs=i32([0]), ngrd_i=i32([ngrd_i]), ngrd_j=i32([ngrd_j]),
                 ngrdsch_i=i32([nsch_i]), ngrdsch_j=i32([nsch_j]), ngrdext_i=i32([next_i]), ngrdext_j=i32([next_j]),
                 ac_off=torch.zeros(1, dtype=torch.int64, device=device), ac_ext=ac.reshape(-1).to(torch.int32),
@@ -358,7 +459,7 @@ def search_tables(w, pkg, device, max_nobs=0):
     pri = gx.repeat(ny).repeat(nz)
     prj = gy.repeat_interleave(nx).repeat(nz)
     prz = zlev.repeat_interleave(nx * ny)
-    prl = torch.full_like(pri, 1.0e5)
+    prl = p_mean(prz)                                  # (only read by the ln-p vertical modes)
     return t, keep, order, (pri, prj, prl, prz)
 
 

@@ -191,7 +191,7 @@ typedef struct {
   double *transm_out;        /* dev [npts][k] or NULL */
   double *pa_out;            /* dev [npts][k*k] or NULL */
   int32_t *status;           /* dev [npts] or NULL */
-  int32_t *nsweep;           /* dev [npts] or NULL: Jacobi sweeps; < 0: -(Chebyshev degree) of a point analysed without an eigen stage (LETKF_OPT_STAGED_POLY) */
+  int32_t *nsweep;           /* dev [npts] or NULL: Jacobi sweeps; < 0: -(CG iterations) of a point analysed without an eigen stage (LETKF_OPT_STAGED_POLY) */
   double *rtps_infl_out;     /* dev [npts*nv] or NULL: the RTPS factor applied to T per variable, work3da of
                                 RELAX_SPREAD_OUT (scale/letkf/letkf_tools.f90:271-276, 460-462, 735-759); 1 where
                                 no RTPS factor applies (RTPP / none / beta = 0 / Q_UPDATE_TOP skip) */
@@ -335,7 +335,8 @@ int letkf_das_points_fused_dev(letkf_ctx *ctx, const letkf_das_args *args, const
  * No count pass over the levels, nothing per (point, observation) in memory; same observations in the same order with the
  * same weights, hence the same analysis to the last bit (tests/test_gpu_columns.py).  (3b) walks the sorting mesh per POINT
  * instead and is superseded by this route wherever both apply.
- * nobs_out: dev [npts] or NULL, receives nobsl of every point. */
+ * nobs_out: dev [npts] or NULL, receives nobsl of every point -- 0 where beta = 0 on either route (the reference does not run
+ * obs_local there, scale/letkf/letkf_tools.f90:333-359). */
 int letkf_das_columns_dev(letkf_ctx *ctx, const letkf_das_args *args, const letkf_search_tables *tables, int64_t nij1,
                           int32_t nlev, const double *rig, const double *rjg, const double *rlev, const double *rz,
                           int64_t list_bytes, int32_t *nobs_out);

@@ -918,9 +918,10 @@ static inline int32_t orc_ac(const orc_search_tables *t, int ic, int i, int j) {
   return t->ac_ext[t->ac_off[ic] + i + (int64_t)(t->ngrdext_i[ic] + 1) * (j - 1)];
 }
 
-int orc_obs_local(const orc_search_tables *t, double ri, double rj, double rlev, double rz, int cap,
-                  int32_t *idx_out, double *rdiag_out, double *rloc_out, double *dist_out) {
+static int obs_local_impl(const orc_search_tables *t, double ri, double rj, double rlev, double rz, int cap,
+                          int32_t *idx_out, double *rdiag_out, double *rloc_out, double *dist_out, int *tied) {
   int nobsl = 0;
+  if (tied) *tied = 0;
   for (int ig = 0; ig < t->ngroup; ++ig) {                       /* do ic = 1, nctype (masters only) :1426-1432 */
     const int gs = t->group_start[ig], ge = t->group_start[ig + 1];
     const int icm = t->group_member[gs];                         /* master ctype :1434-1436 */
@@ -965,6 +966,9 @@ int orc_obs_local(const orc_search_tables *t, double ri, double rj, double rlev,
       for (int i = 0; i < ncand; ++i)
         key[i] = (t->criterion == 1) ? cr[3 * i + 2] : (t->criterion == 2) ? cr[3 * i] : cr[3 * i + 1];
       orc_select_arg(key, order, ncand, nmax, t->criterion == 2);
+      /* the last key selected equals the first one rejected: WHICH of them the reference keeps is up to its unstable
+       * quick-select (common/common_sort.f90:341-369) -- the caller may want to know that this point's list is one of several */
+      if (tied && key[order[nmax - 1]] == key[order[nmax]]) *tied = 1;
       free(key);
       nsel = nmax;
     }
@@ -985,6 +989,16 @@ int orc_obs_local(const orc_search_tables *t, double ri, double rj, double rlev,
     free(order);
   }
   return nobsl;
+}
+
+int orc_obs_local(const orc_search_tables *t, double ri, double rj, double rlev, double rz, int cap,
+                  int32_t *idx_out, double *rdiag_out, double *rloc_out, double *dist_out) {
+  return obs_local_impl(t, ri, rj, rlev, rz, cap, idx_out, rdiag_out, rloc_out, dist_out, NULL);
+}
+
+int orc_obs_local_tied(const orc_search_tables *t, double ri, double rj, double rlev, double rz, int cap,
+                       int32_t *idx_out, double *rdiag_out, double *rloc_out, double *dist_out, int *tied_out) {
+  return obs_local_impl(t, ri, rj, rlev, rz, cap, idx_out, rdiag_out, rloc_out, dist_out, tied_out);
 }
 
 /* scale/common/common_scale.f90:1181-1224 and :1229-1280 */

@@ -61,9 +61,13 @@ struct letkf_ctx {
   char* ring_aux = nullptr;   // ... their counts / offsets / ring starts
   size_t ring_aux_bytes = 0;
   // (the last "not dense" verdict, by the identity of the tables and columns it was given for: the weighing costs a survivor count
-  // and two read-backs -- 17 ms on C2's grid, per search call.  A stale verdict costs speed only: both routes are exact.)
+  // and two read-backs -- 17 ms on C2's grid.  Pointer identity says nothing about the CONTENT -- a host that frees and reallocates
+  // its tables every analysis gets the same addresses with other observations -- so the verdict only serves (a) the fill call that
+  // directly follows the count call it was made in and (b) the calls of one letkf_das_columns_dev; it is dropped after that use, at
+  // the end of that entry and by letkf_ctx_set_option.)
   const void* ring_no[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int64_t ring_no_n = -1;
+  int ring_no_crit = 0;
   bool ring_keep = false;     // inside letkf_das_columns_dev: the survivors of the first search call serve the later ones
   bool ring_ready = false;
   std::vector<int64_t> ring_hoff;
@@ -260,6 +264,14 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, int warm_run = 0, long warm_stride
     a.warm_dbg = 0;
     if (const char* e = LETKF_KNOB("LETKF_AMD_WARM_DBG")) a.warm_dbg = std::atoi(e);
     a.prof = nullptr;
+#ifdef LETKF_CHECKED
+    {   // the violation record of the checked build (letkf_wave.hip LETKF_CHECK): code | workgroup | value | bound
+      static unsigned long long* rec = nullptr;
+      if (!rec) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&rec), 4 * sizeof(unsigned long long)));
+      HIP_TRY(hipMemsetAsync(rec, 0, 4 * sizeof(unsigned long long), c->stream));
+      a.prof = rec;
+    }
+#endif
   }
   // every argument check is behind us: only now create the timing events (destroyed again if the launch fails)
   EventPair ev;
@@ -307,6 +319,16 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, int warm_run = 0, long warm_stride
     c->events.emplace_back(ev.e0, ev.e1);
     ev.e0 = ev.e1 = nullptr;   // owned by the context from here
   }
+#ifdef LETKF_CHECKED
+  if (wave && a.prof) {
+    unsigned long long h[4];
+    HIP_TRY(hipMemcpyAsync(h, a.prof, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h[0])
+      return fail(LETKF_E_HIP, "checked build: bound " + std::to_string(h[0]) + " violated in workgroup " + std::to_string(h[1]) + ": value " +
+                                   std::to_string((long long)h[2]) + " against " + std::to_string((long long)h[3]));
+  }
+#endif
   return LETKF_OK;
 }
 
@@ -459,6 +481,7 @@ int letkf_ctx_destroy(letkf_ctx* c) {
 
 int letkf_ctx_set_option(letkf_ctx* c, int option, int value) {
   if (int rc = check_ctx(c)) return rc;
+  c->ring_no_n = -1;   // (no verdict of the limited column search outlives a change of options)
   switch (option) {
     case LETKF_OPT_STAGED_POLY: c->staged_poly = value != 0; return LETKF_OK;
     case LETKF_OPT_RING_BATCH_MB:
@@ -564,6 +587,11 @@ int letkf_core_batch_dev(letkf_ctx* c, const letkf_core_batch_args* g) {
 }
 
 namespace {
+
+__global__ void zero_where_beta_is_zero(int64_t n, const double* __restrict__ beta, int32_t* __restrict__ cnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && beta[i] == 0.0) cnt[i] = 0;
+}
 
 // does any combined type carry a MAX_NOBS_PER_GRID limit?  From the host's hint when given, else read back (one sync)
 int tables_limited(letkf_ctx* c, const letkf_search_tables* t, bool* limited) {
@@ -764,8 +792,19 @@ int letkf_das_columns_dev(letkf_ctx* c, const letkf_das_args* g, const letkf_sea
   // (the searches below -- one count pass, a fill pass per slab -- share the ring-ordered survivors of the dense limited case)
   struct RingKeep {
     letkf_ctx* c;
-    explicit RingKeep(letkf_ctx* c_) : c(c_) { c->ring_keep = true; c->ring_ready = false; }
-    ~RingKeep() { c->ring_keep = false; c->ring_ready = false; }
+    explicit RingKeep(letkf_ctx* c_) : c(c_) { c->ring_keep = true; c->ring_ready = false; c->ring_no_n = -1; }
+    ~RingKeep() {
+      c->ring_keep = false;
+      c->ring_ready = false;
+      c->ring_no_n = -1;
+      // the kept survivors can be a large part of the device (configs[3] with two limited types: 128 GiB): hand back whatever
+      // exceeds the batch budget, the host model shares this GPU (hipFree waits for the work that still reads the buffer)
+      if (c->ring_ws && c->ring_ws_bytes > ((size_t)c->ring_batch_mb << 20) + ((size_t)c->ring_batch_mb << 18) + 8192) {
+        (void)hipFree(c->ring_ws);
+        c->ring_ws = nullptr;
+        c->ring_ws_bytes = 0;
+      }
+    }
   } ring_keep_guard(c);
   // workspace: counts [npts] int32 | obs_off [npts + 1] int64 | scan scratch
   size_t scan_bytes = 0;
@@ -790,7 +829,14 @@ int letkf_das_columns_dev(letkf_ctx* c, const letkf_das_args* g, const letkf_sea
     HIP_TRY(rocprim::exclusive_scan(c->scratch + off_scan, scan_bytes, in, off, (int64_t)0, (size_t)npts + 1,
                                     rocprim::plus<int64_t>(), c->stream));
   }
-  if (nobs_out) HIP_TRY(hipMemcpyAsync(nobs_out, counts, (size_t)npts * 4, hipMemcpyDeviceToDevice, c->stream));
+  if (nobs_out) {
+    HIP_TRY(hipMemcpyAsync(nobs_out, counts, (size_t)npts * 4, hipMemcpyDeviceToDevice, c->stream));
+    // (as the list-free route reports them: the reference does not run obs_local where beta = 0, letkf_tools.f90:333-359)
+    if (g->beta) {
+      hipLaunchKernelGGL(zero_where_beta_is_zero, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, c->stream, npts, g->beta, nobs_out);
+      HIP_TRY(hipGetLastError());
+    }
+  }
   std::vector<int64_t> lev_off((size_t)nlev + 1);
   HIP_TRY(hipMemcpy2DAsync(lev_off.data(), 8, off, (size_t)nij1 * 8, 8, (size_t)nlev + 1, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -895,7 +941,11 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
   *taken = false;
   if (c->limited_rings == 0 || t->criterion > 2 || t->nctype > 64 || nij1 * (int64_t)t->ngroup >= 0x7fffffff) return LETKF_OK;
   const void* key[5] = {t->ob_ri, t->ac_ext, t->max_nobs, rig, rjg};
-  if (c->limited_rings == 2 && c->ring_no_n == nij1 && std::equal(key, key + 5, c->ring_no)) return LETKF_OK;
+  if (c->limited_rings == 2 && c->ring_no_n == nij1 && c->ring_no_crit == t->criterion && std::equal(key, key + 5, c->ring_no)) {
+    if (!c->ring_keep) c->ring_no_n = -1;   // (a count -> fill pair: used once)
+    return LETKF_OK;
+  }
+  c->ring_no_n = -1;
   std::vector<int32_t> mx(t->nctype), gstart(t->ngroup + 1);
   HIP_TRY(hipMemcpyAsync(gstart.data(), t->group_start, sizeof(int32_t) * (t->ngroup + 1), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(mx.data(), t->max_nobs, sizeof(int32_t) * t->nctype, hipMemcpyDeviceToHost, c->stream));
@@ -964,8 +1014,11 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
         n_over += (hoff[i + 1] - hoff[i]) > (int64_t)letkf::search_rings_lds_survivors();
       }
     if (n_over * 20 <= n_lim) {
-      std::copy(key, key + 5, c->ring_no);
-      c->ring_no_n = nij1;
+      if (c->ring_keep || !fill) {   // (remembered for the fill call of this pair / the later calls of this letkf_das_columns_dev)
+        std::copy(key, key + 5, c->ring_no);
+        c->ring_no_n = nij1;
+        c->ring_no_crit = t->criterion;
+      }
       return LETKF_OK;
     }
   }
@@ -976,7 +1029,22 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
   if (c->ring_keep) {
     size_t fr = 0, tot = 0;
     HIP_TRY(hipMemGetInfo(&fr, &tot));
-    keep = (size_t)hoff[ncg] * 32 + 256 <= c->ring_ws_bytes + fr / 2;
+    const size_t want = (size_t)hoff[ncg] * 32 + 256;
+    keep = want <= c->ring_ws_bytes + fr / 2;
+    if (keep && want > c->ring_ws_bytes) {
+      // the exact size (ensure_bytes would ask for a quarter more), and a failure is no error: the batches below need 8 GiB
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (c->ring_ws) HIP_TRY(hipFree(c->ring_ws));
+      c->ring_ws = nullptr;
+      c->ring_ws_bytes = 0;
+      if (hipMalloc(reinterpret_cast<void**>(&c->ring_ws), want) == hipSuccess) {
+        c->ring_ws_bytes = want;
+      } else {
+        (void)hipGetLastError();
+        c->ring_ws = nullptr;
+        keep = false;
+      }
+    }
   }
   const int64_t budget = keep ? hoff[ncg] * 32 + 256 : ((int64_t)c->ring_batch_mb << 20);
   int64_t c0 = 0;

@@ -577,6 +577,25 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
 #define PROF_UNIT
 #endif
 
+// Checked build (make CHECKED=1 -> lib/libletkf_amd_checked.so, run by tests/test_gpu_checked.py): every index the column-survivor
+// mode derives from device data -- the run's column, the column's survivor range, the wave's slot, each list entry -- is tested
+// against the bound the HOST sized the buffers by before it is used; a violation is recorded (code, workgroup, value, bound) in
+// PointArgs::prof and the access is left out, so that the entry returns an error instead of the process dying on a memory fault
+// with nothing to tell which access it was.  Absent from the normal build.
+#ifdef LETKF_CHECKED
+#define LETKF_CHECK(ok, code, val, lim) letkf_check_fail(A.prof, (ok), (code), (long)(val), (long)(lim))
+__device__ __forceinline__ bool letkf_check_fail(unsigned long long* rec, const bool ok, const int code, const long val, const long lim) {
+  if (!ok && rec && atomicCAS(&rec[0], 0ull, (unsigned long long)code) == 0ull) {
+    rec[1] = blockIdx.x;
+    rec[2] = (unsigned long long)val;
+    rec[3] = (unsigned long long)lim;
+  }
+  return ok;
+}
+#else
+#define LETKF_CHECK(ok, code, val, lim) true
+#endif
+
 template <int KR, int NV, bool KKOUT, int NW, int FUSED>
 __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER_SIMD(KR, NW)) ? 2 : 1) letkf_wave_kernel(const PointArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -718,7 +737,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
         // entry and halves per point.  The next point finds its list in the other half of the wave's slot (2 sl_cap entries).
         if (pre_n >= 0) {
           o0 = ((long)blockIdx.x * PPW + wv) * (2 * A.sl_cap) + A.sl_cap;
-          n = pre_n;
+          n = LETKF_CHECK(pre_n <= A.sl_cap, 7, pre_n, A.sl_cap) ? pre_n : 0;
           pre_n = -1;
         } else if (beta != 0.0) {
           using namespace search_dev;
@@ -730,7 +749,16 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
           const double v_z = A.prz[pt], v_p = log(A.prlev[pt]), l_rain = log(t.rain_base);
           const double v_z1 = A.prz[ptn], v_p1 = log(A.prlev[ptn]);
           const unsigned long long lt_mask = (wlane == 0) ? 0ull : (~0ull >> (64 - wlane));
-          const long s_lo = A.sv_off[rb], s_hi = A.sv_off[rb + 1];
+          long s_lo = A.sv_off[rb], s_hi = A.sv_off[rb + 1];
+#ifdef LETKF_CHECKED
+          {   // the run's column is one of the launch's, its survivors fit the slot the host sized, the slot is one of the grid's
+            bool ok = LETKF_CHECK(rb >= 0 && rb < S, 1, rb, S);
+            ok = ok && LETKF_CHECK(s_hi >= s_lo && ((s_hi - s_lo) & 63) == 0, 2, s_hi - s_lo, 64);
+            ok = ok && LETKF_CHECK(s_hi - s_lo <= A.sl_cap, 3, s_hi - s_lo, A.sl_cap);
+            ok = ok && LETKF_CHECK((long)blockIdx.x < (long)A.wave_grid, 4, blockIdx.x, A.wave_grid);
+            if (!ok) s_hi = s_lo;
+          }
+#endif
           int ntot = 0, ntot1 = 0;
           if (s_hi > s_lo) {
             // Four chunks of 64 entries in flight, in four buffers with STATIC names: the survivors stream from HBM (no wave
@@ -773,7 +801,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
                 const ColVert vo = column_vertical_cal(vm_s, vloc_s, varloc_s, ca.y, cb.x, cb.y, v_z, v_p, l_rain);
                 const bool acc_ = live && vo.rloc != 0.0;                    // :1460
                 const unsigned long long mk = __ballot(acc_);
-                if (acc_) {
+                if (acc_ && LETKF_CHECK(ntot + __popcll(mk) <= A.sl_cap, 5, ntot + __popcll(mk), A.sl_cap)) {
                   const long j = o0 + ntot + __popcll(mk & lt_mask);
                   A.sl_idx[j] = (int)(rw & 0xffffffffL);
                   A.sl_rd[j] = vo.rdiag;
@@ -785,7 +813,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
                 const ColVert vo = column_vertical_cal(vm_s, vloc_s, varloc_s, ca.y, cb.x, cb.y, v_z1, v_p1, l_rain);
                 const bool acc_ = live && vo.rloc != 0.0;
                 const unsigned long long mk = __ballot(acc_);
-                if (acc_) {
+                if (acc_ && LETKF_CHECK(ntot1 + __popcll(mk) <= A.sl_cap, 6, ntot1 + __popcll(mk), A.sl_cap)) {
                   const long j = o1 + ntot1 + __popcll(mk & lt_mask);
                   A.sl_idx[j] = (int)(rw & 0xffffffffL);
                   A.sl_rd[j] = vo.rdiag;

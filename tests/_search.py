@@ -147,3 +147,58 @@ def oracle_lists(case, cap=20000):
         assert n >= 0
         out.append((idx[:n].copy(), rd[:n].copy(), rl[:n].copy(), ds[:n].copy()))
     return out
+
+
+def host_struct_from_torch(t, keep):
+    """(struct, keepalive): a numpy-backed copy of a SearchTables whose arrays are torch tensors (the dict that
+    bench_workload.search_tables returns beside the struct) -- what the oracle's orc_obs_local reads."""
+    h = SearchTables()
+    for name, _ in SearchTables._fields_:
+        if name not in ARRAY_FIELDS:
+            setattr(h, name, getattr(t, name))
+    alive = []
+    for f in ARRAY_FIELDS:
+        a = np.ascontiguousarray(keep[f].detach().cpu().numpy())
+        alive.append(a)
+        setattr(h, f, a.ctypes.data)
+    return h, alive
+
+
+def oracle_csr(h, ri, rj, rlev, rz, cap=1 << 16, nthreads=8):
+    """obs_local of the ORACLE (oracle/letkf_oracle.c orc_obs_local = scale/letkf/letkf_tools.f90:1325-1759, every selection
+    mode) for the points (ri, rj, rlev, rz): CSR lists (off int64, idx int32, rdiag, rloc) whose entries are rows of the
+    table `h` describes, plus tied[i] = 1 where a limited group's selection fell between equal keys (either choice is the
+    reference's: its quick-select is unstable).  The points are dealt to a few host threads (ctypes drops the GIL)."""
+    import threading
+    import _oracle
+    lib = _oracle.oracle()
+    f = lib.orc_obs_local_tied
+    f.restype = C.c_int
+    n = len(ri)
+    res = [None] * n
+    tied = np.zeros(n, dtype=np.int32)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+
+    def work(r):
+        c = cap
+        idx, rd, rl = np.zeros(c, dtype=np.int32), np.zeros(c), np.zeros(c)
+        tf = C.c_int(0)
+        for i in range(r, n, nthreads):
+            while True:
+                m = f(C.byref(h), C.c_double(ri[i]), C.c_double(rj[i]), C.c_double(rlev[i]), C.c_double(rz[i]), C.c_int(c),
+                      idx.ctypes.data_as(ip), rd.ctypes.data_as(dp), rl.ctypes.data_as(dp), None, C.byref(tf))
+                if m >= 0:
+                    break
+                c *= 2
+                idx, rd, rl = np.zeros(c, dtype=np.int32), np.zeros(c), np.zeros(c)
+            res[i] = (idx[:m].copy(), rd[:m].copy(), rl[:m].copy())
+            tied[i] = tf.value
+    th = [threading.Thread(target=work, args=(r,)) for r in range(min(nthreads, max(n, 1)))]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    off = np.zeros(n + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(r[0]) for r in res])
+    cat = lambda j, dt: (np.concatenate([r[j] for r in res]) if n else np.zeros(0)).astype(dt)
+    return off, cat(0, np.int32), cat(1, np.float64), cat(2, np.float64), tied

@@ -184,3 +184,164 @@ def test_list_free_route_with_four_combined_types_and_three_vertical_modes(nlev,
     else:
         # (batches of a few columns: the launch splits its runs differently -- other warm starts, same analysis to rounding)
         assert float((g0 - g1).abs().max()) <= 1e-11 * float(g0.abs().max())
+
+
+def _oracle_sample_check(w, t_s, keep, pts4, ens, dep, sample, beta, infl0, anal, infl1, nobs, sw, tol=1e-10):
+    """The analysis of the grid points `sample` against the ORACLE end to end: obs_local by oracle/letkf_oracle.c orc_obs_local
+    on a host copy of the same tables (scale/letkf/letkf_tools.f90:1325-1759 -- nothing of the device search is involved), then
+    the loop body orc_das_letkf_points (:313-527) on those lists.  Returns the worst |d xa| / max(|x-bar|, |x'|)."""
+    import _oracle
+    import _search
+    import bench_workload as bw
+    k, nv, npts, nens = w["k"], w["nv"], w["npts"], w["nens"]
+    h, alive = _search.host_struct_from_torch(t_s, keep)
+    P = [p.cpu().numpy() for p in pts4]
+    off, idx, rd, rl, tied = _search.oracle_csr(h, P[0][sample], P[1][sample], P[2][sample], P[3][sample])
+    assert not tied.any()
+    ns = len(sample)
+    tp = torch.from_numpy(sample).cuda()
+    gs = bw.state_view(w, w["gues"])[:, :, tp].contiguous().cpu().numpy().reshape(-1)
+    b = beta[tp].cpu().numpy() if beta is not None else None
+    i0 = infl0.view(nv, npts)[:, tp].contiguous().cpu().numpy().reshape(-1)
+    prm = _oracle.DasParams(k=k, nv=nv, det_run=int(sw.get("det_run", False)), infl_adaptive=int(sw.get("infl_adaptive", False)),
+                            relax_to_inflated_prior=0, relax_alpha=sw.get("relax_alpha", 0.0),
+                            relax_alpha_spread=sw.get("relax_alpha_spread", 0.0), q_update_top=0.0, q_sprd_max=0.0, iv_p=4,
+                            iv_q_first=5, iv_q_last=10, nthreads=8)
+    ref = _oracle.das_points(prm, off, idx, rd, rl, ens.cpu().numpy(), dep.cpu().numpy(), b, i0, gs, 1, ns, ns * nens)
+    assert ref["rc"] == 0
+    got = bw.state_view(w, anal)[:, :, tp].cpu().numpy()
+    exp = ref["anal"].reshape(nv, nens, ns)
+    x = gs.reshape(nv, nens, ns)
+    members = list(range(k)) + ([k + 1] if sw.get("det_run") else [])
+    worst = 0.0
+    for v in range(nv):
+        scale = max(np.abs(x[v, k]).max(), np.abs(x[v, :k]).max())
+        assert np.isfinite(got[v, members]).all()
+        err = np.abs(got[v, members] - exp[v, members]).max()
+        assert err <= tol * scale, (v, err, scale)
+        worst = max(worst, err / scale)
+    gi = infl1.view(nv, npts)[:, tp].cpu().numpy().reshape(-1)
+    assert np.abs(gi - ref["infl"]).max() <= 1e-12
+    if nobs is not None:
+        cnt = np.diff(off)
+        live = np.ones(ns, bool) if b is None else b != 0.0
+        assert np.array_equal(nobs[tp].cpu().numpy()[live], cnt[live])
+    return worst, np.diff(off)
+
+
+@pytest.mark.parametrize("name,list_mb,nsample", [("C4-slab", 24.0, 20), ("C4-slab-disc", 40.0, 28)])
+def test_list_free_route_at_configs3_density_against_the_oracle(name, list_mb, nsample):
+    """BASELINE configs[3]'s density (n ~ 4900 local observations, ~16 k horizontal survivors per column: dozens of 256-entry
+    passes, both halves of a wave's list slot, slots of sl_cap entries) on the route `das_letkf_amd` takes there
+    (LETKF_OPT_COLUMN_SURVIVORS = 1, two levels per pass), with DET_RUN, adaptive inflation and a beta field that has zeros
+    and fractions, in batches of columns whose last one is ragged: sampled points against the oracle's obs_local + loop body."""
+    import bench_workload as bw
+    from _gpu import ctx, pkg
+    dev = torch.device("cuda:0")
+    w = bw.build(name, dev, det_run=True, lists=False)
+    k, nv, npts, nens = w["k"], w["nv"], w["npts"], w["nens"]
+    nij1, nlev = w["cfg"]["nx"] * w["cfg"]["ny"], w["cfg"]["nz"]
+    cx = ctx()
+    cx.ens_mean(k, nv, npts, w["gues"], 1, npts, npts * nens)
+    cx.to_perturbations(k, nv, npts, w["gues"], 1, npts, npts * nens)
+    t_s, keep, order, pts = bw.search_tables(w, pkg, dev)
+    ens, dep = w["ensval"][order].contiguous(), w["dep"][order].contiguous()
+    rig, rjg = pts[0][:nij1].contiguous(), pts[1][:nij1].contiguous()
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    beta = torch.rand(npts, generator=g, device=dev, dtype=torch.float64)
+    beta[torch.rand(npts, generator=g, device=dev) < 0.15] = 0.0       # relax_beta's zeros (letkf_tools.f90:333-359)
+    beta[torch.rand(npts, generator=g, device=dev) < 0.5] = 1.0
+    infl0 = 1.0 + 0.1 * torch.rand(npts * nv, generator=g, device=dev, dtype=torch.float64)
+    sw = dict(det_run=True, infl_adaptive=True, relax_alpha_spread=0.95)
+    anal = torch.full_like(w["gues"], float("nan"))
+    infl = infl0.clone()
+    status = torch.full((npts,), -1, dtype=torch.int32, device=dev)
+    nobs = torch.full((npts,), -7, dtype=torch.int32, device=dev)
+    cx.set_option(cx.OPT_COLUMN_SURVIVORS, 1)
+    try:
+        cx.das_columns(k, nv, t_s, nij1, nlev, rig, rjg, pts[2], pts[3], ens, w["kld"], dep, infl, w["gues"], anal, 1, npts,
+                       npts * nens, list_bytes=int(list_mb * 2 ** 20), nobs_out=nobs, beta=beta, status=status, **sw)
+        torch.cuda.synchronize()
+    finally:
+        cx.set_option(cx.OPT_COLUMN_SURVIVORS, 2)
+    assert "FUSED" in cx.last_path()
+    assert int(status.abs().max()) == 0
+    # the sample: points of the densest columns, of the disc's rim, of empty columns (disc), beta = 0 / fraction / 1
+    rng = np.random.default_rng(5)
+    nb = nobs.cpu().numpy()
+    dense = np.flatnonzero(nb >= 0.9 * nb.max())
+    bz = beta.cpu().numpy()
+    sample = [rng.choice(dense, size=min(len(dense), nsample // 2), replace=False), rng.choice(npts, size=nsample // 2, replace=False),
+              rng.choice(np.flatnonzero(bz == 0.0), size=2, replace=False), rng.choice(np.flatnonzero(bz == 1.0), size=2, replace=False)]
+    if "disc" in name:
+        rim = np.flatnonzero((nb > 0) & (nb < 600))
+        empty = np.flatnonzero((nb == 0) & (beta.cpu().numpy() != 0.0))
+        assert len(rim) and len(empty)
+        sample += [rng.choice(rim, size=4, replace=False), rng.choice(empty, size=2, replace=False)]
+    sample = np.unique(np.concatenate(sample)).astype(np.int64)
+    worst, cnt = _oracle_sample_check(w, t_s, keep, pts, ens, dep, sample, beta, infl0, anal, infl, nobs, sw)
+    assert cnt.max() > 4500 and (cnt % 256 != 0).any()
+    bs = beta.cpu().numpy()[sample]
+    assert (bs == 0.0).any() and (bs == 1.0).any() and ((bs > 0.0) & (bs < 1.0)).any()
+    # the geometry the test is about: several batches of columns with a ragged last one, columns of many passes
+    print(f"{name}: {len(sample)} points against the oracle, worst {worst:.2e}, n up to {cnt.max()}")
+
+
+@pytest.mark.parametrize("nlev_cut,run", [(11, 0), (7, 5), (12, 3)])
+def test_list_free_route_with_beta_zeros_and_odd_runs_equals_the_lists(nlev_cut, run):
+    """The pairs of levels of the two-levels-per-pass pre-pass under everything that breaks a pair: an odd number of levels,
+    runs of an odd length (warm_run) and quarter-split units, beta = 0 at the first / second point of a pair (the pass is
+    skipped, or its second list is dropped).  Against the list route with the same runs: same lists, same analysis."""
+    import bench_workload as bw
+    from _gpu import ctx, pkg
+    dev = torch.device("cuda:0")
+    w = bw.build("C2-mini", dev)
+    k, nv, nens = w["k"], w["nv"], w["nens"]
+    nij1, nlev_all = w["cfg"]["nx"] * w["cfg"]["ny"], w["cfg"]["nz"]
+    npts_all = w["npts"]
+    nlev = nlev_cut
+    npts = nij1 * nlev
+    cx = ctx()
+    cx.ens_mean(k, nv, npts_all, w["gues"], 1, npts_all, npts_all * nens)
+    cx.to_perturbations(k, nv, npts_all, w["gues"], 1, npts_all, npts_all * nens)
+    t_s, keep, order, pts = bw.search_tables(w, pkg, dev)
+    ens, dep = w["ensval"][order].contiguous(), w["dep"][order].contiguous()
+    rig, rjg = pts[0][:nij1].contiguous(), pts[1][:nij1].contiguous()
+    rlev, rz = pts[2][:npts].contiguous(), pts[3][:npts].contiguous()
+    g = torch.Generator(device=dev)
+    g.manual_seed(3 + nlev)
+    beta = torch.rand(npts, generator=g, device=dev, dtype=torch.float64)
+    beta[torch.rand(npts, generator=g, device=dev) < 0.3] = 0.0
+    beta[torch.rand(npts, generator=g, device=dev) < 0.3] = 1.0
+    beta.view(nlev, nij1)[:, :7] = 0.0                                  # whole columns switched off
+    beta.view(nlev, nij1)[0::2, 7:14] = 0.0                             # every first / every second point of a pair
+    beta.view(nlev, nij1)[1::2, 14:21] = 0.0
+    off, idx, rd, rl = cx.obs_search_columns(t_s, nij1, nlev, rig, rjg, rlev, rz)
+    # (the state keeps the strides of the full workload: element (p, m, v) at p + m npts_all + v npts_all nens)
+    a0 = torch.full_like(w["gues"], float("nan"))
+    i0 = torch.ones(npts_all * nv, dtype=torch.float64, device=dev)
+    s0 = torch.full((npts,), -1, dtype=torch.int32, device=dev)
+    cx.das_points(k, nv, off, idx, rd, rl, ens, w["kld"], dep, i0, w["gues"], a0, 1, npts_all, npts_all * nens, beta=beta,
+                  relax_alpha_spread=0.95, infl_adaptive=True, status=s0, warm_stride=nij1, warm_run=run, infl_sv=npts_all)
+    a1 = torch.full_like(w["gues"], float("nan"))
+    i1 = torch.ones(npts_all * nv, dtype=torch.float64, device=dev)
+    s1 = torch.full((npts,), -1, dtype=torch.int32, device=dev)
+    nobs = torch.full((npts,), -5, dtype=torch.int32, device=dev)
+    cx.set_option(cx.OPT_COLUMN_SURVIVORS, 1)
+    try:
+        cx.das_columns(k, nv, t_s, nij1, nlev, rig, rjg, rlev, rz, ens, w["kld"], dep, i1, w["gues"], a1, 1, npts_all,
+                       npts_all * nens, list_bytes=1 << 34, nobs_out=nobs, beta=beta, relax_alpha_spread=0.95, infl_adaptive=True,
+                       status=s1, warm_run=run, infl_sv=npts_all)
+        torch.cuda.synchronize()
+    finally:
+        cx.set_option(cx.OPT_COLUMN_SURVIVORS, 2)
+    assert "FUSED" in cx.last_path()
+    assert int(s0.abs().max()) == 0 and int(s1.abs().max()) == 0
+    live = beta != 0.0
+    cnt = (off[1:] - off[:-1]).to(torch.int32)
+    assert torch.equal(nobs[live], cnt[live]) and int(nobs[~live].abs().max()) == 0
+    g0 = a0.view(nv, nens, npts_all)[:, :k, :npts]
+    g1 = a1.view(nv, nens, npts_all)[:, :k, :npts]
+    assert torch.equal(g0, g1)
+    assert torch.equal(i0, i1)

@@ -113,3 +113,55 @@ def test_c5_ragged_points_k1000_det():
     c, ref, got, infl, status, _, _ = run_both(1000, 11, 3, 500, 200, seed=47, cfg=cfg)
     assert (status == 0).all(), status
     compare_anal(c, ref, got, 1000, 11, True)
+
+
+@pytest.mark.parametrize("route", ["columns", "search+points"])
+def test_c1_workload(route):
+    """BASELINE configs[0] as SURVEY.md section 8(d) specifies it (bench_workload "C1": 40 x 40 x 30 at 15 km, k = 20, 500
+    uniformly random conventional observations, vertical localisation in ln p, scale/letkf/letkf_tools.f90:1851-1865): the whole
+    domain, EVERY point, against the oracle end to end -- orc_obs_local on a host copy of the tables, then the loop body -- through
+    the one-call main loop (what das_letkf_amd calls) and through the column search + letkf_das_points_dev."""
+    import _search
+    from _gpu import ctx, pkg
+    dev = torch.device("cuda")
+    w = bw.build("C1", dev)
+    k, nv, npts, nens = w["k"], w["nv"], w["npts"], w["nens"]
+    assert (k, npts, w["nobs"]) == (20, 48000, 500) and 350 < w["n_mean"] < 450 and w["n_max"] == 500
+    nij1, nlev = w["cfg"]["nx"] * w["cfg"]["ny"], w["cfg"]["nz"]
+    c = ctx()
+    c.ens_mean(k, nv, npts, w["gues"], 1, npts, npts * nens)
+    c.to_perturbations(k, nv, npts, w["gues"], 1, npts, npts * nens)
+    t_s, keep, order, pts = bw.search_tables(w, pkg, dev)
+    ens, dep = w["ensval"][order].contiguous(), w["dep"][order].contiguous()
+    rig, rjg = pts[0][:nij1].contiguous(), pts[1][:nij1].contiguous()
+    anal = torch.full_like(w["gues"], float("nan"))
+    infl = torch.ones(npts * nv, dtype=torch.float64, device=dev)
+    status = torch.full((npts,), -1, dtype=torch.int32, device=dev)
+    nobs = torch.full((npts,), -1, dtype=torch.int32, device=dev)
+    if route == "columns":
+        c.das_columns(k, nv, t_s, nij1, nlev, rig, rjg, pts[2], pts[3], ens, w["kld"], dep, infl, w["gues"], anal, 1, npts, npts * nens,
+                      nobs_out=nobs, relax_alpha_spread=0.95, status=status)
+    else:
+        off, idx, rd, rl = c.obs_search_columns(t_s, nij1, nlev, rig, rjg, pts[2], pts[3])
+        nobs = (off[1:] - off[:-1]).to(torch.int32)
+        c.das_points(k, nv, off, idx, rd, rl, ens, w["kld"], dep, infl, w["gues"], anal, 1, npts, npts * nens, relax_alpha_spread=0.95,
+                     status=status, warm_stride=nij1)
+    torch.cuda.synchronize()
+    assert int(status.abs().max()) == 0
+    h, alive = _search.host_struct_from_torch(t_s, keep)
+    P = [p.cpu().numpy() for p in pts]
+    off_o, idx_o, rd_o, rl_o, tied = _search.oracle_csr(h, P[0], P[1], P[2], P[3])
+    assert np.array_equal(np.diff(off_o), nobs.cpu().numpy())
+    prm = _oracle.DasParams(k=k, nv=nv, det_run=0, infl_adaptive=0, relax_to_inflated_prior=0, relax_alpha=0.0,
+                            relax_alpha_spread=0.95, q_update_top=0.0, q_sprd_max=0.0, iv_p=4, iv_q_first=5, iv_q_last=10, nthreads=8)
+    gues = w["gues"].cpu().numpy()
+    ref = _oracle.das_points(prm, off_o, idx_o, rd_o, rl_o, ens.cpu().numpy(), dep.cpu().numpy(), None, np.ones(npts * nv), gues, 1,
+                             npts, npts * nens)
+    assert ref["rc"] == 0
+    got = anal.view(nv, nens, npts)[:, :k].cpu().numpy()
+    exp = ref["anal"].reshape(nv, nens, npts)[:, :k]
+    x = gues.reshape(nv, nens, npts)
+    for v in range(nv):
+        scale = max(np.abs(x[v, k]).max(), np.abs(x[v, :k]).max())
+        assert np.isfinite(got[v]).all()
+        assert np.abs(got[v] - exp[v]).max() <= 1e-10 * scale, (v, np.abs(got[v] - exp[v]).max(), scale)
