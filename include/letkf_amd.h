@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LETKF_AMD_ABI_VERSION 6
+#define LETKF_AMD_ABI_VERSION 7
 
 /* host-side errors (function return values) */
 #define LETKF_OK 0
@@ -84,6 +84,12 @@ int letkf_ctx_synchronize(letkf_ctx *ctx);
 #define LETKF_OPT_LIMITED_RINGS 3
 /* LETKF_OPT_RING_BATCH_MB (default 8192): device workspace of the ring route per batch of columns, in MiB. */
 #define LETKF_OPT_RING_BATCH_MB 4
+/* LETKF_OPT_RING_RELEASE (default 0): inside letkf_das_columns_dev the ring-ordered survivors of ALL columns are kept for the
+ * calls of the entry where they fit half of the free device memory (allocated at their exact size; if that allocation fails the
+ * entry falls back to batches of LETKF_OPT_RING_BATCH_MB).  0: the buffer stays with the context for the next analysis;
+ * 1: whatever exceeds the batch budget is freed when the entry returns (a host model that needs the memory between analyses
+ * pays the allocation again every call: ~1.7 s for 64 GB). */
+#define LETKF_OPT_RING_RELEASE 5
 int letkf_ctx_set_option(letkf_ctx *ctx, int option, int value);
 
 /*---------------------------------------------------------------------------
@@ -543,6 +549,34 @@ int letkf_infl_init_dev(letkf_ctx *ctx, int64_t n, double *work3d, double infl_m
  *-------------------------------------------------------------------------*/
 int letkf_obs_allgatherv_dev(letkf_ctx *ctx, void *nccl_comm, int32_t nranks, int32_t myrank, const int64_t *counts,
                              int64_t row_bytes, const void *send, void *recv);
+
+/* (8b, ABI 7) The other exchanges of the path on the same host-owned communicator, so that a Fortran host reaches every one of
+ * them through this library (round 3 had them as torch code only):
+ *   letkf_alltoallv_dev       pairwise exchange with TRUE counts (MPI_ALLTOALLV): send_counts[q] rows from row send_offs[q] of
+ *                             `send` go to rank q, recv_counts[q] rows from rank q land at row recv_offs[q] of `recv`; ONE group of
+ *                             ncclSend / ncclRecv on the context's stream, the own block a device copy (send_counts[myrank] must
+ *                             equal recv_counts[myrank]).  Counts and offsets: HOST [nranks], in rows of row_bytes bytes.  This is
+ *                             the HALO-ONLY exchange of the observation table -- every rank sends rank q just the rows that fall
+ *                             into q's extended subdomain (scale/letkf/letkf_obs.f90:922-976, 1059-1109) instead of the
+ *                             ALLGATHERV of everything (:1036-1046) -- and the transport of the member <-> point transpose below.
+ *                             On a fully connected xGMI node the pairs use different links at the same time.
+ *   letkf_allreduce_sum_i32_dev  MPI_ALLREDUCE(MPI_SUM) in place on dev int32 [count]: the per-mesh-cell observation counts
+ *                             of :826-833, from which every rank derives every rank's row counts (ncclAllReduce).
+ *   letkf_members_alltoall_dev  scatter_grd_mpi_alltoall (dir 0) / gather_grd_mpi_alltoall (dir 1),
+ *                             scale/common/common_mpi_scale.f90:1279-1396: ranks 0 .. mcount-1 each hold ONE member's field
+ *                             v3dg(nlev,nlon,nlat,nv3d) (member mstart + rank; NULL elsewhere); every rank owns the points
+ *                             ij = myrank, myrank + nranks, ... (grd_to_buf, :1428-1455) and keeps, for them, the members in the
+ *                             slots mstart .. mstart + mcount - 1 of x (element (i, lev, m, v) at (i + nij1*lev)*sp + m*sm + v*sv).
+ *                             dir 0 deals the fields to the slots, dir 1 assembles the fields from them; blocks of true size
+ *                             (the reference pads to nij1max), packed / unpacked by the kernel of letkf_member_points_dev.
+ * nranks = 1 needs no communicator (NULL): everything is the own block.  LETKF_E_INVALID when RCCL is not loadable. */
+int letkf_alltoallv_dev(letkf_ctx *ctx, void *nccl_comm, int32_t nranks, int32_t myrank, const int64_t *send_counts,
+                        const int64_t *send_offs, const int64_t *recv_counts, const int64_t *recv_offs, int64_t row_bytes,
+                        const void *send, void *recv);
+int letkf_allreduce_sum_i32_dev(letkf_ctx *ctx, void *nccl_comm, int32_t nranks, int64_t count, int32_t *buf);
+int letkf_members_alltoall_dev(letkf_ctx *ctx, void *nccl_comm, int32_t nranks, int32_t myrank, int32_t dir, int32_t nlev,
+                               int32_t nlon, int32_t nlat, int32_t nv3d, int32_t mstart, int32_t mcount, double *v3dg, double *x,
+                               int64_t sp, int64_t sm, int64_t sv);
 
 /* Name(s) of the kernel(s) the context's last letkf_das_points*_dev / letkf_core_batch_dev call went through, as a
  * NUL-terminated string (truncated to len): what bench.py reports as roofline.kernel. */

@@ -140,7 +140,8 @@ EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", 
            "letkf_obs_gather_rows_dev", "letkf_obs_gather_i32_dev", "letkf_monit_dep_dev",
            "letkf_additive_inflation_dev", "letkf_addinfl_weight_dev",
            "letkf_var_local_classes", "letkf_ctype_merge_groups", "letkf_radar_only", "letkf_relax_beta_dev",
-           "letkf_infl_init_dev", "letkf_obs_allgatherv_dev",
+           "letkf_infl_init_dev", "letkf_obs_allgatherv_dev", "letkf_alltoallv_dev", "letkf_allreduce_sum_i32_dev",
+           "letkf_members_alltoall_dev",
            "letkf_ctx_timing_enable", "letkf_ctx_timing_read", "letkf_ctx_last_path", "letkf_sched_plan_check"]
 
 _lib = None
@@ -203,6 +204,7 @@ class Context:
     OPT_COLUMN_SURVIVORS = 2   # LETKF_OPT_COLUMN_SURVIVORS
     OPT_LIMITED_RINGS = 3      # LETKF_OPT_LIMITED_RINGS
     OPT_RING_BATCH_MB = 4      # LETKF_OPT_RING_BATCH_MB
+    OPT_RING_RELEASE = 5       # LETKF_OPT_RING_RELEASE
 
     def set_option(self, option, value):
         self._check(self._l.letkf_ctx_set_option(self._c, C.c_int(option), C.c_int(value)))
@@ -405,6 +407,24 @@ class Context:
                                                      cnt, C.c_int64(row_bytes), _ptr(send), _ptr(recv)))
 
     # ---- (7) das_letkf set-up
+    def alltoallv(self, nccl_comm, myrank, send_counts, send_offs, recv_counts, recv_offs, row_bytes, send, recv):
+        """letkf_alltoallv_dev: counts / offsets are host lists in rows of row_bytes bytes"""
+        n = len(send_counts)
+        arr = lambda v: (C.c_int64 * n)(*[int(a) for a in v])
+        self._check(self._l.letkf_alltoallv_dev(self._c, C.c_void_p(nccl_comm), C.c_int32(n), C.c_int32(myrank), arr(send_counts),
+                                                arr(send_offs), arr(recv_counts), arr(recv_offs), C.c_int64(row_bytes), _ptr(send),
+                                                _ptr(recv)))
+
+    def allreduce_sum_i32(self, nccl_comm, nranks, buf):
+        self._check(self._l.letkf_allreduce_sum_i32_dev(self._c, C.c_void_p(nccl_comm), C.c_int32(nranks), C.c_int64(buf.numel()),
+                                                        _ptr(buf)))
+
+    def members_alltoall(self, nccl_comm, nranks, myrank, direction, nlev, nlon, nlat, nv3d, mstart, mcount, v3dg, x, sp, sm, sv):
+        self._check(self._l.letkf_members_alltoall_dev(self._c, C.c_void_p(nccl_comm), C.c_int32(nranks), C.c_int32(myrank),
+                                                       C.c_int32(direction), C.c_int32(nlev), C.c_int32(nlon), C.c_int32(nlat),
+                                                       C.c_int32(nv3d), C.c_int32(mstart), C.c_int32(mcount), _ptr(v3dg), _ptr(x),
+                                                       C.c_int64(sp), C.c_int64(sm), C.c_int64(sv)))
+
     def relax_beta(self, params, nij1, nlev, rig, rjg, hgt, beta):
         self._check(self._l.letkf_relax_beta_dev(self._c, C.byref(params), C.c_int64(nij1), C.c_int32(nlev), _ptr(rig),
                                                  _ptr(rjg), _ptr(hgt), _ptr(beta)))

@@ -72,6 +72,7 @@ struct letkf_ctx {
   bool ring_ready = false;
   std::vector<int64_t> ring_hoff;
   int ring_batch_mb = 8192;   // LETKF_OPT_RING_BATCH_MB
+  bool ring_release = false;  // LETKF_OPT_RING_RELEASE
   int limited_rings = 2;      // LETKF_OPT_LIMITED_RINGS: 0 never, 1 wherever eligible, 2 where a group's survivors overflow the column kernel's buffer
   char* staged_ws = nullptr;  // staged path: per-point slabs of a batch + meta / info words
   size_t staged_ws_bytes = 0;
@@ -488,6 +489,7 @@ int letkf_ctx_set_option(letkf_ctx* c, int option, int value) {
       if (value < 1) return fail(LETKF_E_INVALID, "LETKF_OPT_RING_BATCH_MB: >= 1");
       c->ring_batch_mb = value;
       return LETKF_OK;
+    case LETKF_OPT_RING_RELEASE: c->ring_release = value != 0; return LETKF_OK;
     case LETKF_OPT_LIMITED_RINGS:
       if (value < 0 || value > 2) return fail(LETKF_E_INVALID, "LETKF_OPT_LIMITED_RINGS: 0, 1 or 2");
       c->limited_rings = value;
@@ -797,9 +799,11 @@ int letkf_das_columns_dev(letkf_ctx* c, const letkf_das_args* g, const letkf_sea
       c->ring_keep = false;
       c->ring_ready = false;
       c->ring_no_n = -1;
-      // the kept survivors can be a large part of the device (configs[3] with two limited types: 128 GiB): hand back whatever
-      // exceeds the batch budget, the host model shares this GPU (hipFree waits for the work that still reads the buffer)
-      if (c->ring_ws && c->ring_ws_bytes > ((size_t)c->ring_batch_mb << 20) + ((size_t)c->ring_batch_mb << 18) + 8192) {
+      // the kept survivors can be a large part of the device (configs[3] with two limited types: 128 GiB).  By default the buffer
+      // stays with the context for the next analysis (allocating and freeing 64 GB per call cost the MEMBER = 100 tile 1.7 s of a
+      // 4 s analysis); LETKF_OPT_RING_RELEASE = 1 hands back whatever exceeds the batch budget when the entry returns, for a host
+      // model that needs the memory between analyses (hipFree waits for the work that still reads the buffer)
+      if (c->ring_release && c->ring_ws && c->ring_ws_bytes > ((size_t)c->ring_batch_mb << 20) + ((size_t)c->ring_batch_mb << 18) + 8192) {
         (void)hipFree(c->ring_ws);
         c->ring_ws = nullptr;
         c->ring_ws_bytes = 0;
@@ -1224,6 +1228,99 @@ int letkf_obs_allgatherv_dev(letkf_ctx* c, void* nccl_comm, int32_t nranks, int3
   const int rc = letkf::rccl_allgatherv(nccl_comm, nranks, myrank, counts, row_bytes, send, recv, c->stream, &what);
   if (rc == -1) return fail(LETKF_E_INVALID, "RCCL (librccl.so.1) is not available in this process");
   if (rc != 0) return fail(LETKF_E_HIP, std::string("RCCL: ") + what);
+  return LETKF_OK;
+}
+
+namespace {
+int rccl_result(int rc, const char* what) {
+  if (rc == 0) return LETKF_OK;
+  if (rc == -1) return fail(LETKF_E_INVALID, "RCCL (librccl.so.1) is not available in this process");
+  if (rc == -2) return fail(LETKF_E_INVALID, what);
+  return fail(LETKF_E_HIP, std::string("RCCL: ") + what);
+}
+}  // namespace
+
+int letkf_alltoallv_dev(letkf_ctx* c, void* nccl_comm, int32_t nranks, int32_t myrank, const int64_t* send_counts,
+                        const int64_t* send_offs, const int64_t* recv_counts, const int64_t* recv_offs, int64_t row_bytes,
+                        const void* send, void* recv) {
+  if (int rc = check_ctx(c)) return rc;
+  if ((nranks > 1 && !nccl_comm) || nranks < 1 || myrank < 0 || myrank >= nranks || !send_counts || !send_offs || !recv_counts ||
+      !recv_offs || row_bytes < 1)
+    return fail(LETKF_E_INVALID, "bad communicator / rank layout / counts");
+  int64_t ns = 0, nr = 0;
+  for (int r = 0; r < nranks; ++r) {
+    if (send_counts[r] < 0 || recv_counts[r] < 0 || send_offs[r] < 0 || recv_offs[r] < 0) return fail(LETKF_E_INVALID, "negative count / offset");
+    ns += send_counts[r];
+    nr += recv_counts[r];
+  }
+  if ((ns > 0 && !send) || (nr > 0 && !recv)) return fail(LETKF_E_INVALID, "a buffer is NULL");
+  const char* what = "";
+  return rccl_result(letkf::rccl_alltoallv(nccl_comm, nranks, myrank, send_counts, send_offs, recv_counts, recv_offs, row_bytes, send,
+                                           recv, c->stream, &what), what);
+}
+
+int letkf_allreduce_sum_i32_dev(letkf_ctx* c, void* nccl_comm, int32_t nranks, int64_t count, int32_t* buf) {
+  if (int rc = check_ctx(c)) return rc;
+  if ((nranks > 1 && !nccl_comm) || nranks < 1 || count < 0 || (count > 0 && !buf)) return fail(LETKF_E_INVALID, "bad argument");
+  const char* what = "";
+  return rccl_result(letkf::rccl_allreduce_sum_i32(nccl_comm, nranks, count, buf, c->stream, &what), what);
+}
+
+// scatter_grd_mpi_alltoall / gather_grd_mpi_alltoall (scale/common/common_mpi_scale.f90:1279-1396) with the exchange inside the
+// library: per-destination blocks [nv3d][nlev * nij1(d)] dealt out of / assembled into the member field by the kernel of
+// letkf_member_points_dev (grd_to_buf / buf_to_grd), ONE grouped exchange with true counts, the blocks filed into / taken from
+// the member slots of the state.  Workspace: the context's scratch buffer (send blocks | receive blocks).
+int letkf_members_alltoall_dev(letkf_ctx* c, void* nccl_comm, int32_t nranks, int32_t myrank, int32_t dir, int32_t nlev,
+                               int32_t nlon, int32_t nlat, int32_t nv3d, int32_t mstart, int32_t mcount, double* v3dg, double* x,
+                               int64_t sp, int64_t sm, int64_t sv) {
+  if (int rc = check_ctx(c)) return rc;
+  if ((nranks > 1 && !nccl_comm) || nranks < 1 || myrank < 0 || myrank >= nranks || nlev < 1 || nlon < 1 || nlat < 1 || nv3d < 1 ||
+      mstart < 0 || mcount < 0 || mcount > nranks || !x || (dir != 0 && dir != 1))
+    return fail(LETKF_E_INVALID, "bad argument");
+  const bool holder = myrank < mcount;                    // this rank holds / receives the whole field of member mstart + myrank
+  if (holder && !v3dg) return fail(LETKF_E_INVALID, "v3dg is NULL on a rank that holds a member");
+  const long nxy = (long)nlon * nlat;
+  auto share = [&](int r) { return (nxy - r + nranks - 1) / nranks; };   // points r, r + nranks, ... (grd_to_buf)
+  const long nij1 = share(myrank), npl = (long)nlev * nij1;
+  std::vector<int64_t> fc(nranks), fo(nranks), pc(nranks), po(nranks);   // field side (all points of my member), point side (my points of every member)
+  int64_t ftot = 0, ptot = 0;
+  for (int r = 0; r < nranks; ++r) {
+    fc[r] = holder ? (int64_t)nv3d * nlev * share(r) : 0;
+    fo[r] = ftot;
+    ftot += fc[r];
+    pc[r] = r < mcount ? (int64_t)nv3d * npl : 0;
+    po[r] = ptot;
+    ptot += pc[r];
+  }
+  const size_t need = (size_t)(ftot + ptot) * sizeof(double) + 256;
+  if (need > c->scratch_bytes) HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc = ensure_bytes(c, &c->scratch, &c->scratch_bytes, need)) return rc;
+  double* fbuf = reinterpret_cast<double*>(c->scratch);
+  double* pbuf = fbuf + ftot;
+  const char* what = "";
+  if (dir == 0) {   // member fields -> point-major state
+    if (holder)
+      for (int d = 0; d < nranks; ++d) {
+        const long nd = share(d);
+        if (nd > 0) HIP_TRY(letkf::launch_member_points(0, nlev, nlon, nxy, nv3d, nranks, d, nd, v3dg, fbuf + fo[d], 1, 0, nd * nlev, c->stream));
+      }
+    if (int rc = rccl_result(letkf::rccl_alltoallv(nccl_comm, nranks, myrank, fc.data(), fo.data(), pc.data(), po.data(), 8, fbuf, pbuf,
+                                                   c->stream, &what), what))
+      return rc;
+    for (int s_ = 0; s_ < mcount; ++s_)
+      HIP_TRY(letkf::launch_block_slot(0, npl, nv3d, pbuf + po[s_], x, sp, (long)(mstart + s_) * sm, sv, c->stream));
+  } else {          // point-major state -> member fields
+    for (int d = 0; d < mcount; ++d)
+      HIP_TRY(letkf::launch_block_slot(1, npl, nv3d, pbuf + po[d], x, sp, (long)(mstart + d) * sm, sv, c->stream));
+    if (int rc = rccl_result(letkf::rccl_alltoallv(nccl_comm, nranks, myrank, pc.data(), po.data(), fc.data(), fo.data(), 8, pbuf, fbuf,
+                                                   c->stream, &what), what))
+      return rc;
+    if (holder)
+      for (int s_ = 0; s_ < nranks; ++s_) {
+        const long ns = share(s_);
+        if (ns > 0) HIP_TRY(letkf::launch_member_points(1, nlev, nlon, nxy, nv3d, nranks, s_, ns, v3dg, fbuf + fo[s_], 1, 0, ns * nlev, c->stream));
+      }
+  }
   return LETKF_OK;
 }
 

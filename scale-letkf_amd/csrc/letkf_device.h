@@ -211,6 +211,10 @@ hipError_t launch_addinfl_weight(long nij1, const double* rig, const double* rjg
                                  int num_cu, hipStream_t st);
 int rccl_allgatherv(void* comm, int nranks, int myrank, const int64_t* counts, int64_t row_bytes, const void* send,
                     void* recv, hipStream_t st, const char** what);
+int rccl_alltoallv(void* comm, int nranks, int myrank, const int64_t* scount, const int64_t* soff, const int64_t* rcount,
+                   const int64_t* roff, int64_t row_bytes, const void* send, void* recv, hipStream_t st, const char** what);
+hipError_t launch_block_slot(int dir, long npl, int nv3d, double* blk, double* x, long sp, long mo, long sv, hipStream_t st);
+int rccl_allreduce_sum_i32(void* comm, int nranks, int64_t count, int32_t* buf, hipStream_t st, const char** what);
 hipError_t launch_relax_beta(const letkf_beta_params& p, long nij1, int nlev, const double* rig, const double* rjg,
                              const double* hgt, double* beta, int num_cu, hipStream_t st);
 hipError_t launch_infl_init(long n, double* w, double infl_mul, double infl_mul_min, int num_cu, hipStream_t st);

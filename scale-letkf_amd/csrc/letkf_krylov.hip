@@ -138,10 +138,12 @@ struct RingDepth {
 };
 
 // One point.  Returns false when the point has to go to the eigen stage.
-template <int BPW>
+template <int BPW, int NWV>
 __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, const int n, const int ldg, const int k,
-                                             const int nv, const int nbr, const double shift, const bool dual, int* iters_out) {
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
+                                             const int nv, const int nbr, const double shift, const bool dual, const int dcap,
+                                             int* iters_out) {
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int nwv = NWV;
   const int nr16 = (n + 15) & ~15, nblk = nr16 >> 4;
   const int col = lane & 15, rq = lane >> 4;
   double rr[BPW][4], pp[BPW][4], qq[BPW][4], xx[BPW][4];
@@ -201,7 +203,7 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
   for (;; ++j) {
     double rho = 0.0;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) rho += L.red[w * 16 + col];
+    for (int w = 0; w < NWV; ++w) rho += L.red[w * 16 + col];
     if (j == 0) tn2 = rho;
     if (!(rho == rho)) failed = true;                       // NaN anywhere in M or t
     if (!frozen && !(rho > kTol2 * tn2)) {
@@ -261,7 +263,7 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
     __syncthreads();
     double mu = 0.0;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) mu += L.red[128 + w * 16 + col];
+    for (int w = 0; w < NWV; ++w) mu += L.red[128 + w * 16 + col];
     double alpha = 0.0, beta = 0.0;
     if (!frozen) {
       beta = j == 0 ? 0.0 : rho / rho_old;
@@ -307,14 +309,14 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
 #endif
 
   // ================= g_T(T_m) e_1 for the columns b >= 2, m_b = mj rows each
-  // (a) the tridiagonals: wave w takes the columns 2 + w and 2 + w + 8; lane l holds rows 2l and 2l + 1
-  constexpr int NC = 2;
+  // (a) the tridiagonals: wave w takes the columns 2 + w, 2 + w + NWV, ...; lane l holds rows 2l and 2l + 1
+  constexpr int NC = 16 / NWV;
   double a0[NC], a1[NC], bL[NC], bM[NC], bR[NC];
   int mb[NC];
   double gmax = 0.0;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    const int b = 2 + wv + 8 * c;
+    const int b = 2 + wv + NWV * c;
     mb[c] = 0;
     a0[c] = a1[c] = bL[c] = bM[c] = bR[c] = 0.0;
     if (b < nbr) {                                          // (wave-uniform)
@@ -344,7 +346,7 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
   __syncthreads();
   double hi = 0.0;
 #pragma unroll
-  for (int w = 0; w < 8; ++w) hi = fmax(hi, L.misc[w]);
+  for (int w = 0; w < NWV; ++w) hi = fmax(hi, L.misc[w]);
   // (b) interval, degree, Chebyshev coefficients of g_T.  Ritz values lie in [lambda_min(M), lambda_max(M)], and
   // lambda_min(M) >= c; the margin below c covers the rounding of the recurrence
   const double lo = shift * (1.0 - 1e-9);
@@ -352,7 +354,7 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
   const double sk = sqrt(hi / lo), rate = (sk - 1.0) / (sk + 1.0);
   int deg = (int)ceil(log(1e-17) / log(rate)) + 2;
   if (!(deg >= 4)) deg = 4;
-  if (deg > kDcap) return false;                            // (uniform: hi is the same in every thread)
+  if (deg > dcap) return false;                             // (uniform: hi is the same in every thread)
   const int N = deg + 1;
   const double half = 0.5 * (hi - lo), mid = 0.5 * (hi + lo), inv = 1.0 / half;
   const double sqc = sqrt(shift), sqkm1 = sqrt((double)(k - 1));
@@ -384,7 +386,7 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
   // (c) y = sum_d c_d T_d(T~) e_1, T~ = (T_m - mid) / half; then the combination coefficients y_j (-1)^j |t| / |r_j|
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    const int b = 2 + wv + 8 * c;
+    const int b = 2 + wv + NWV * c;
     if (b < nbr) {
       const int m = mb[c];
       const double d0 = (a0[c] - mid) * inv, d1 = (a1[c] - mid) * inv;
@@ -481,11 +483,20 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
 // (the staging copy of X' for the Z x' pass of an observation-space point overlays rbuf .. hr)
 // BPW: 16-row blocks per wave = the orders the instantiation takes (1: m <= 128, 2: <= 256, 4: <= 512); a launch passes over
 // the points of the other classes, so that each class has the registers of its own kernel
-template <int BPW>
-__global__ void __launch_bounds__(kKBlock, 1) letkf_stage_krylov_kernel(const StagedArgs S, const int nr16cap, const int r0) {
+// NWV: waves of the workgroup.  8 (one workgroup per CU) for the orders above 128; orders up to 128 -- MEMBER = 100, the
+// reference's most common ensemble size -- run as FOUR waves with two 16-row blocks each and TWO workgroups per CU (r4): the
+// iteration is latency-bound (two barriers, two LDS reductions, 28 matrix instructions per wave), and with one workgroup per
+// CU a third of the wave cycles were waiting with the vector ALU 19 % busy (profiles/r03_k100_pmc_summary.json) -- the second
+// point fills them.  Same registers per wave (256: two waves per SIMD either way), LDS <= 80 KB per workgroup through a smaller
+// cap of the tridiagonal function's degree (dcap: cond(T_m) ~ 5000 instead of 47000; beyond it the point goes to the eigen
+// stage as before).
+template <int BPW, int NWV>
+__global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) letkf_stage_krylov_kernel(const StagedArgs S, const int nr16cap, const int r0,
+                                                                                         const int dcap, const int cls) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const PointArgs& A = S.A;
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int nwv = NWV;
   const int k = A.k, nv = A.nv, nb = nv + 2;
   KryLds L;
   L.rbuf = smem;
@@ -495,7 +506,7 @@ __global__ void __launch_bounds__(kKBlock, 1) letkf_stage_krylov_kernel(const St
   L.red = smem + r0;                                         // (r0 >= 16 nr16cap + 3 kMmax 16)
   L.cT = L.ha;                                               // (2 kMmax 16 = kDcap + 2 doubles)
   L.fT = L.red + 256;
-  L.swl = L.fT + (kDcap + 2);
+  L.swl = L.fT + (dcap + 2);
   L.misc = L.swl + 512;
   double* xl = smem;                                         // X' block of the Z x' product: overlays rbuf .. hr (r0 doubles)
 
@@ -503,10 +514,7 @@ __global__ void __launch_bounds__(kKBlock, 1) letkf_stage_krylov_kernel(const St
     const long pt = S.pt0 + it;
     const int meta0 = S.meta[2 * it], m = S.meta[2 * it + 1];
     if ((meta0 >> 8) != 3) continue;                         // (uniform for the workgroup)
-    {
-      const int per = (((m + 15) >> 4) + 7) >> 3;            // 16-row blocks per wave
-      if ((per <= 1 ? 1 : per <= 2 ? 2 : 4) != BPW) continue;
-    }
+    if ((m <= 128 ? 0 : m <= 256 ? 1 : 2) != cls) continue;  // (the launch's class of orders: launch_stage_krylov)
     Slab sl = slab_of(A.ws + (size_t)it * A.ws_per_block, k, nv, S.kkout);
     const bool dual = (meta0 & 0xff) == 2;
     const double shift = sl.SC[3];
@@ -590,7 +598,7 @@ __global__ void __launch_bounds__(kKBlock, 1) letkf_stage_krylov_kernel(const St
     }
     __syncthreads();
     int iters = 0;
-    const bool ok = krylov_point<BPW>(sl, L, m, ldg, k, nv, nb, shift, dual, &iters);
+    const bool ok = krylov_point<BPW, NWV>(sl, L, m, ldg, k, nv, nb, shift, dual, dcap, &iters);
     if (tid == 0) {
       if (ok) {
         S.info[2 * it] = -iters;                             // nsweep reports -(iterations) ...
@@ -610,24 +618,33 @@ long stage_krylov_hist_doubles(int k) { return (long)kMmax * 16 * stage_krylov_m
 hipError_t launch_stage_krylov(const StagedArgs& s, size_t lds_max, hipStream_t st) {
   const int k = s.A.k;
   const int nr16cap = stage_krylov_max_n(k);
-  const size_t fixed = (size_t)256 + (kDcap + 2) + 512 + 32;
   static_assert(kDcap + 2 <= 2 * kMmax * 16, "the Chebyshev coefficients overlay ha | hb");
   const size_t over = (size_t)16 * nr16cap + 3 * (size_t)kMmax * 16;   // rbuf .. hr: what the staging copy of X' may overlay
   const size_t budget = (lds_max > 160 * 1024 ? 160 * 1024 : lds_max) - 1024;
   const size_t r0 = over;
-  const size_t lds = (fixed + r0) * sizeof(double);
-  if (lds > budget) return hipErrorInvalidValue;
-  auto go = [&](auto kern) -> hipError_t {
+  auto lds_of = [&](int dcap) { return ((size_t)256 + (size_t)(dcap + 2) + 512 + 32 + r0) * sizeof(double); };
+  if (lds_of(kDcap) > budget) return hipErrorInvalidValue;
+  auto go = [&](auto kern, int nthr, int dcap, int cls) -> hipError_t {
+    const size_t lds = lds_of(dcap);
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)s.nbatch), dim3(kKBlock), lds, st, s, nr16cap, (int)r0);
+    hipLaunchKernelGGL(kern, dim3((unsigned)s.nbatch), dim3(nthr), lds, st, s, nr16cap, (int)r0, dcap, cls);
     return hipGetLastError();
   };
-  hipError_t e = go(&letkf_stage_krylov_kernel<1>);
-  if (e == hipSuccess && nr16cap > 128) e = go(&letkf_stage_krylov_kernel<2>);
-  if (e == hipSuccess && nr16cap > 256) e = go(&letkf_stage_krylov_kernel<4>);
+  // orders <= 128: two workgroups of four waves per CU where half of the CU's LDS leaves the tridiagonal function a degree
+  // worth having (KRYLOV_CLS0_WAVES = 8: the one-workgroup form, for A/B twins)
+#ifndef KRYLOV_CLS0_WAVES
+#define KRYLOV_CLS0_WAVES 4
+#endif
+  const long half = (long)(budget + 1024) / 2 / (long)sizeof(double) - (long)(256 + 512 + 32 + 2) - (long)r0;
+  const int dcap0 = half > kDcap ? kDcap : (int)half;
+  hipError_t e;
+  if (KRYLOV_CLS0_WAVES == 4 && dcap0 >= 512) e = go(&letkf_stage_krylov_kernel<2, 4>, 256, dcap0, 0);
+  else e = go(&letkf_stage_krylov_kernel<1, 8>, kKBlock, kDcap, 0);
+  if (e == hipSuccess && nr16cap > 128) e = go(&letkf_stage_krylov_kernel<2, 8>, kKBlock, kDcap, 1);
+  if (e == hipSuccess && nr16cap > 256) e = go(&letkf_stage_krylov_kernel<4, 8>, kKBlock, kDcap, 2);
   return e;
 }
 

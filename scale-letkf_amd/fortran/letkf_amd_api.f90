@@ -136,6 +136,34 @@ MODULE letkf_amd_api
       INTEGER(c_int64_t), VALUE :: row_bytes
       INTEGER(c_int) :: rc
     END FUNCTION
+    ! (8b) the pairwise exchange with true counts (halo-only observation exchange; transport of the member <-> point transpose),
+    ! the all-reduce of the mesh-cell counts (letkf_obs.f90:826-833) and scatter / gather_grd_mpi_alltoall
+    ! (common_mpi_scale.f90:1279-1396) on the host's RCCL communicator; counts / offsets are HOST arrays
+    FUNCTION letkf_alltoallv_dev(ctx, nccl_comm, nranks, myrank, send_counts, send_offs, recv_counts, recv_offs, row_bytes, &
+        send, recv) BIND(C, name='letkf_alltoallv_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t
+      TYPE(c_ptr), VALUE :: ctx, nccl_comm, send, recv
+      INTEGER(c_int32_t), VALUE :: nranks, myrank
+      INTEGER(c_int64_t), INTENT(IN) :: send_counts(nranks), send_offs(nranks), recv_counts(nranks), recv_offs(nranks)
+      INTEGER(c_int64_t), VALUE :: row_bytes
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_allreduce_sum_i32_dev(ctx, nccl_comm, nranks, count, buf) &
+        BIND(C, name='letkf_allreduce_sum_i32_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t
+      TYPE(c_ptr), VALUE :: ctx, nccl_comm, buf
+      INTEGER(c_int32_t), VALUE :: nranks
+      INTEGER(c_int64_t), VALUE :: count
+      INTEGER(c_int) :: rc
+    END FUNCTION
+    FUNCTION letkf_members_alltoall_dev(ctx, nccl_comm, nranks, myrank, dir, nlev, nlon, nlat, nv3d, mstart, mcount, v3dg, x, &
+        sp, sm, sv) BIND(C, name='letkf_members_alltoall_dev') RESULT(rc)
+      IMPORT :: c_int, c_ptr, c_int32_t, c_int64_t
+      TYPE(c_ptr), VALUE :: ctx, nccl_comm, v3dg, x
+      INTEGER(c_int32_t), VALUE :: nranks, myrank, dir, nlev, nlon, nlat, nv3d, mstart, mcount
+      INTEGER(c_int64_t), VALUE :: sp, sm, sv
+      INTEGER(c_int) :: rc
+    END FUNCTION
     FUNCTION letkf_amd_abi_version() BIND(C, name='letkf_amd_abi_version') RESULT(v)
       IMPORT :: c_int
       INTEGER(c_int) :: v
@@ -154,7 +182,7 @@ MODULE letkf_amd_api
     FUNCTION letkf_ctx_set_option(ctx, option, value) BIND(C, name='letkf_ctx_set_option') RESULT(rc)
       IMPORT :: c_int, c_ptr
       TYPE(c_ptr), VALUE :: ctx
-      INTEGER(c_int), VALUE :: option, value      ! LETKF_OPT_STAGED_POLY = 1, LETKF_OPT_COLUMN_SURVIVORS = 2, LETKF_OPT_LIMITED_RINGS = 3, LETKF_OPT_RING_BATCH_MB = 4 (include/letkf_amd.h)
+      INTEGER(c_int), VALUE :: option, value      ! LETKF_OPT_STAGED_POLY = 1, LETKF_OPT_COLUMN_SURVIVORS = 2, LETKF_OPT_LIMITED_RINGS = 3, LETKF_OPT_RING_BATCH_MB = 4, LETKF_OPT_RING_RELEASE = 5 (include/letkf_amd.h)
       INTEGER(c_int) :: rc
     END FUNCTION
     FUNCTION letkf_ctx_synchronize(ctx) BIND(C, name='letkf_ctx_synchronize') RESULT(rc)

@@ -44,6 +44,37 @@ def _one_rank_exchange():
             c.obs_allgatherv(comm.value, 0, [rows], send, recv)
             torch.cuda.synchronize()
             assert torch.equal(recv[:rows], send)
+        # ---- the other exchanges on the same communicator (C ABI 8b), one rank: everything is the own block
+        import numpy as np
+        send = torch.randn(40, 51, dtype=torch.float64, device="cuda")
+        recv = torch.full((64, 51), -1.0, dtype=torch.float64, device="cuda")
+        c.alltoallv(comm.value, 0, [33], [5], [33], [20], 51 * 8, send, recv)      # rows 5 .. 38 of send -> rows 20 .. 53 of recv
+        torch.cuda.synchronize()
+        assert torch.equal(recv[20:53], send[5:38]) and bool((recv[:20] == -1).all()) and bool((recv[53:] == -1).all())
+        cnt = torch.arange(1000, dtype=torch.int32, device="cuda")
+        c.allreduce_sum_i32(comm.value, 1, cnt)
+        torch.cuda.synchronize()
+        assert torch.equal(cnt.cpu(), torch.arange(1000, dtype=torch.int32))
+        # scatter / gather_grd_mpi_alltoall through the library: member fields -> slots of the point-major state and back
+        nlev, nlon, nlat, nv3d, nens = 9, 13, 7, 3, 5
+        nij1 = nlon * nlat
+        x = torch.full((nv3d * nens * nlev * nij1,), float("nan"), dtype=torch.float64, device="cuda")
+        fields = [torch.from_numpy(np.random.default_rng(50 + m).standard_normal(nv3d * nlat * nlon * nlev)).cuda() for m in range(3)]
+        for m in range(3):
+            c.members_alltoall(comm.value, 1, 0, 0, nlev, nlon, nlat, nv3d, m + 1, 1, fields[m], x, 1, nlev * nij1, nens * nlev * nij1)
+        torch.cuda.synchronize()
+        xv = x.view(nv3d, nens, nlev, nij1)
+        for m in range(3):
+            f = fields[m].view(nv3d, nlat * nlon, nlev)                              # v3dg(nlev,nlon,nlat,nv3d): level-fastest
+            assert torch.equal(xv[:, m + 1], f.permute(0, 2, 1))
+        assert bool(torch.isnan(xv[:, 0]).all()) and bool(torch.isnan(xv[:, 4]).all())
+        back = torch.full_like(fields[0], float("nan"))
+        c.members_alltoall(comm.value, 1, 0, 1, nlev, nlon, nlat, nv3d, 2, 1, back, x, 1, nlev * nij1, nens * nlev * nij1)
+        torch.cuda.synchronize()
+        assert torch.equal(back, fields[1])
+        c.members_alltoall(0, 1, 0, 1, nlev, nlon, nlat, nv3d, 3, 1, back, x, 1, nlev * nij1, nens * nlev * nij1)   # one rank needs no communicator
+        torch.cuda.synchronize()
+        assert torch.equal(back, fields[2])
         # argument errors are reported, not executed
         from _gpu import pkg
         try:
