@@ -145,6 +145,8 @@ def main():
         ctx.set_option(int(o_), int(v_))
 
     if args.scaling == "strong":
+        if args.lists not in ("columns", "pipeline"):
+            sys.exit("--scaling strong: --lists columns (search + loop body) or pipeline (letkf_das_columns_dev)")
         import bench_tiles
         r = bench_tiles.run(args, ctx, pkg, dev, rank, world)
         if rank == 0:
@@ -162,7 +164,8 @@ def main():
                 "config": {"workload": f"{args.workload}: ONE {bw.CONFIGS[args.workload]['nx']}x{bw.CONFIGS[args.workload]['ny']}x"
                                        f"{bw.CONFIGS[args.workload]['nz']} domain as {r['tiles']}, k={k_}, nv={nv_}, mean "
                                        f"{r['n_mean']:.1f} local obs/point, relax={args.relax}; per step and rank: mesh sort, "
-                                       f"obs exchange ({args.exchange}), halo plan, obs_local, loop body",
+                                       f"obs exchange ({args.exchange}), halo plan, "
+                                       + ("obs_local + loop body in one call (letkf_das_columns_dev)" if args.lists == "pipeline" else "obs_local, loop body"),
                            "points_total": r["npts_total"], "obs_rows_global": r["nobs"],
                            "obs_rows_per_rank_with_halo": r["halo_rows_mean"],
                            "obs_rows_received_per_rank": r["rows_received_mean"], "parallelism": f"tiles x{world}"},

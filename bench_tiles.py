@@ -98,6 +98,7 @@ def run(args, ctx, pkg, dev, rank, world):
     infl = torch.ones(npts * nv, dtype=f64, device=dev)
     status = torch.zeros(npts, dtype=torch.int32, device=dev)
     nsweep = torch.zeros(npts, dtype=torch.int32, device=dev)
+    nobs_pt = torch.zeros(npts, dtype=torch.int32, device=dev)
     relax = dict(rtps=dict(relax_alpha_spread=0.95), rtpp=dict(relax_alpha=0.7), none=dict())[args.relax]
     i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
     d64 = lambda v: torch.tensor(v, dtype=f64, device=dev)
@@ -185,11 +186,17 @@ def run(args, ctx, pkg, dev, rank, world):
                   ob_err=torch.full((max(nt, 1),), err, dtype=f64, device=dev))
         for name, v in k2.items():
             setattr(t, name, v.data_ptr())
-        # ---- das_letkf: obs_local for the tile's points, then the loop body
-        off, idx, rd, rl = ctx.obs_search_columns(t, nij1, nz, rig, rjg, prl, prz)
-        ctx.das_points(k, nv, off, idx, rd, rl, ens, kld, dep, infl, gues, anal, 1, npts, npts * nens, status=status,
-                       nsweep=nsweep, warm_stride=wstride, **relax)
-        keep.update(k2=k2, nt=nt, nnz=int(off[-1].item()))
+        # ---- das_letkf: obs_local for the tile's points, then the loop body (--lists pipeline: ONE call of the library, the
+        # lists by level slabs or -- where they would not fit --list-gb -- not at all: BASELINE configs[3]'s tile needs that)
+        if args.lists == "pipeline":
+            ctx.das_columns(k, nv, t, nij1, nz, rig, rjg, prl, prz, ens, kld, dep, infl, gues, anal, 1, npts, npts * nens,
+                            list_bytes=int(args.list_gb * 2 ** 30), nobs_out=nobs_pt, status=status, nsweep=nsweep, **relax)
+            keep.update(k2=k2, nt=nt, nnz=int(nobs_pt.sum(dtype=torch.int64).item()))
+        else:
+            off, idx, rd, rl = ctx.obs_search_columns(t, nij1, nz, rig, rjg, prl, prz)
+            ctx.das_points(k, nv, off, idx, rd, rl, ens, kld, dep, infl, gues, anal, 1, npts, npts * nens, status=status,
+                           nsweep=nsweep, warm_stride=wstride, **relax)
+            keep.update(k2=k2, nt=nt, nnz=int(off[-1].item()))
         if "rows_received" not in keep:
             keep["rows_received"] = int(ntot - counts[rank]) if world > 1 else 0
 

@@ -64,6 +64,14 @@ CONFIGS = {
                ztop=18000.0, seed=20240630),
     "C4-gpu": dict(nx=250, ny=500, nz=80, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=1100.0, err=3.0,
                    ztop=18000.0, seed=20240631, halo=True),
+    # BASELINE configs[3] WHOLE: the 1000 x 1000 x 80 domain for `bench.py --gpus 8 --scaling strong --workload C4 --lists pipeline
+    # --list-gb 24` (4 x 2 tiles of 250 x 500 x 80 = the C4-gpu tile, one per GPU; the state of the whole domain is 2 x 359 GB,
+    # so there is no N = 1 run of it: its one-GPU number is C4-gpu's), and a small domain of the same density to rehearse the
+    # tiling with
+    "C4": dict(nx=1000, ny=1000, nz=80, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=1100.0, err=3.0,
+               ztop=18000.0, seed=20240631),
+    "C4-dom-mini": dict(nx=48, ny=32, nz=6, k=50, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=1100.0, err=3.0,
+                        ztop=18000.0, seed=20240636),
     # configs[3]'s observation density at the ensemble size of 20 of the reference's 38 run configurations (MEMBER = 100), half of
     # the C4-gpu tile (the state of the whole tile at 101 slots would be 2 x 90 GB): meant for --max-nobs 100
     "C4h-k100": dict(nx=250, ny=250, nz=80, k=100, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=1100.0, err=3.0,

@@ -34,10 +34,29 @@ using namespace staged_dev;
 
 namespace {
 
+// primal: the members are dealt to blocks of 16 in groups of 32 -- block 2 g the group's even members, 2 g + 1 the odd ones (one
+// 16-byte load feeds both) -- and a last group of at most 16 members is ONE block of its own (r4: MEMBER = 100 = 3 groups + 4
+// members is 7 blocks instead of 8, 35 tiles instead of 44; two 8-byte loads per entry there)
+#ifndef GRAM_SINGLE_TAIL
+#define GRAM_SINGLE_TAIL 1
+#endif
+__host__ __device__ inline int primal_pairs(int k) { return (GRAM_SINGLE_TAIL && (k & 31) >= 1 && (k & 31) <= 16) ? (k >> 5) : ((k + 31) >> 5); }
+__host__ __device__ inline int primal_blocks(int k) { return 2 * primal_pairs(k) + ((GRAM_SINGLE_TAIL && (k & 31) >= 1 && (k & 31) <= 16) ? 1 : 0); }
+
 constexpr int kGmBlock = 512;
-constexpr int kGmPanel = 68;            // panel entries (1 KB each) the LDS buffer holds: blocks x double-steps per chunk
-constexpr int kGmItems = 9;             // panel entries (dual) / pairs of entries (primal) a wave stages per chunk (registers)
-constexpr int kGmSuper = 1024;          // primal: observation rows whose offsets and scalars are worked out at a time (LDS)
+constexpr int kGmPanelBig = 68;         // panel entries (1 KB each) the LDS buffer holds: blocks x double-steps per chunk
+constexpr int kGmPanelSmall = 40;       // ... of the four-wave instantiation (orders of at most 10 blocks x 4 double-steps)
+constexpr int kGmItemsMax = 9;          // panel entries (dual) / pairs of entries (primal) a wave stages per chunk (registers)
+// (primal: the observation rows whose offsets and scalars are worked out at a time -- a "super-chunk" in LDS -- are 1024, 512 in
+// the four-wave instantiation)
+#ifndef GRAM_SMALL_WAVES
+#define GRAM_SMALL_WAVES 4               // (8: no four-wave instantiation -- A/B twins)
+#endif
+__host__ __device__ inline bool gram_small(int n, int k) {   // the four-wave instantiation's points
+  if (GRAM_SMALL_WAVES != 4) return false;
+  const int nbx = n < k ? (n + 15) >> 4 : primal_blocks(k) + 1;
+  return n < k ? nbx * 4 <= 36 : nbx * 4 <= kGmPanelSmall;
+}
 
 struct alignas(16) d2 {
   double x, y;
@@ -55,12 +74,20 @@ struct alignas(16) d2 {
 // TC4: the instantiation for the points whose chunks hold 4 double-steps (orders <= 256: up to 17 blocks); the other one takes
 // the larger orders with the generic inner loop -- both in one kernel cost the loops 90-130 spilled registers (the k = 100 loop
 // body 1.60 -> 1.74 M solves/s with the split).
-template <bool DUAL, bool TC4>
-__global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(const StagedArgs S) {
-  constexpr int kGmTiles = DUAL ? 12 : 8;     // accumulator tiles per wave and pass
+// NWV: waves of the workgroup.  4 (r4): the small orders -- at most 10 blocks incl. the extra one: MEMBER <= 128, n <= 144 in
+// observation space -- as TWO workgroups of four waves per CU (up to 12 tiles per wave, panel of 40 entries, super-chunks of
+// 512 rows: 56 KB of LDS), so that one point's chunk barriers and staging waits are the other point's matrix-core time; 8: the
+// one-workgroup form for everything larger.
+template <bool DUAL, bool TC4, int NWV>
+__global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) letkf_stage_gram_mfma_kernel(const StagedArgs S) {
+  constexpr int kGmTiles = (DUAL || NWV == 4) ? 12 : 8;     // accumulator tiles per wave and pass
+  constexpr int kGmPanel = NWV == 4 ? kGmPanelSmall : kGmPanelBig;
+  constexpr int kGmSuper = NWV == 4 ? 512 : 1024;
+  constexpr int kGmItems = (NWV == 4 && !DUAL) ? 6 : kGmItemsMax;   // (small primal points: at most 24 items per chunk over four waves)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const PointArgs& A = S.A;
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int nwv = NWV;
   const int col = lane & 15, rq = lane >> 4;
   const int k = A.k;
   const double km1 = (double)(k - 1);
@@ -97,10 +124,12 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
       continue;
     }
     if (n > 0 && !gram_mfma_takes(n, k)) continue;    // letkf_stage_gram_kernel's point (launched behind this kernel)
-    if (n > 0) {                                      // (points without an eigenproblem: the TC4 instantiation's)
-      const int nbx = n < k ? (n + 15) >> 4 : 2 * ((k + 31) >> 5) + 1;
-      if ((kGmPanel / nbx >= 4) != TC4) continue;
-    } else if (!TC4) continue;
+    if (n > 0) {                                      // (points without an eigenproblem: the small TC4 instantiation's)
+      const int nbx = n < k ? (n + 15) >> 4 : primal_blocks(k) + 1;
+      const bool small = gram_small(n, k);
+      if (small != (NWV == 4)) continue;
+      if (!small && (kGmPanelBig / nbx >= 4) != TC4) continue;
+    } else if (!(TC4 && NWV == GRAM_SMALL_WAVES)) continue;
     // inflation slot that drives the solve (first updated variable of the class, letkf_tools.f90:387-418)
     double infl_old;
     {
@@ -152,7 +181,8 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
       }
     }
     // ---- blocks, tiles, chunks
-    const int NB = dual ? (m + 15) >> 4 : 2 * ((k + 31) >> 5);   // blocks of 16 output indices
+    const int NB = dual ? (m + 15) >> 4 : primal_blocks(k);     // blocks of 16 output indices
+    const int NP = dual ? 0 : primal_pairs(k);                   // primal: groups of 32 members = pairs of blocks; NB - 2 NP = 0 / 1 single block
     const int NBX = dual ? NB : NB + 1;                          // + the block column [sqrt(w) dep | sqrt(w) dep_det]
     const int Lc = dual ? k : n;                                 // contraction length
     int Tc = TC4 ? 4 : kGmPanel / NBX;                           // double-steps per chunk
@@ -161,7 +191,7 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
     const int ntri = NB * (NB + 1) / 2, ntile = dual ? ntri : ntri + NB;
     // panel entries of a chunk, dealt round-robin to the waves: dual NB x Tc loads; primal (NB / 2) x Tc pairs of loads
     // (two entries each) + Tc entries of the extra block
-    const int nitem = dual ? NB * Tc : (NB / 2) * Tc + Tc;
+    const int nitem = dual ? NB * Tc : (NB - NP) * Tc + Tc;      // (pairs, then the single block, then the extra block)
     __syncthreads();                                  // (swl, roff)
 
     double trp = 0.0;
@@ -227,13 +257,20 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
               int e0 = (ch * Tc + t) * 8 + 2 * rq;
               e0 = e0 < k - 1 ? e0 : k - 1;           // (a row holds k + 1 doubles)
               st0[u] = *reinterpret_cast<const d2u*>(A.ensval + roff[i < n ? i : n - 1] + e0);
-            } else if (item < (NB / 2) * Tc) {
+            } else if (item < NP * Tc) {
               const int g = item / Tc, t = item - g * Tc;
               int mm = 32 * g + 2 * col;
               mm = mm < k - 1 ? mm : k - 1;
               const int r0 = (ch * rows_ch) % kGmSuper + 8 * t + 2 * rq;   // super-chunk-relative rows r0, r0 + 1
               st0[u] = *reinterpret_cast<const d2u*>(A.ensval + roff[r0] + mm);
               st1[u] = *reinterpret_cast<const d2u*>(A.ensval + roff[r0 + 1] + mm);
+            } else if (item < (NB - NP) * Tc) {       // the single last block: member 32 NP + col of rows r0, r0 + 1
+              const int t = item - NP * Tc;
+              int mm = 32 * NP + col;
+              mm = mm < k ? mm : k;                   // (a row holds k + 1 doubles)
+              const int r0 = (ch * rows_ch) % kGmSuper + 8 * t + 2 * rq;
+              st0[u].x = A.ensval[roff[r0] + mm];
+              st1[u].x = A.ensval[roff[r0 + 1] + mm];
             }
           }
         }
@@ -252,7 +289,15 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
               v.x = e0 < k ? st0[u].x * sw : 0.0;     // (e0 >= k - 1: the clamped load fetched [k - 1, k])
               v.y = e0 + 1 < k ? st0[u].y * sw : 0.0;
               panel[(size_t)(b * Tc + t) * 64 + lane] = v;
-            } else if (item < (NB / 2) * Tc) {
+            } else if (item >= NP * Tc && item < (NB - NP) * Tc) {
+              const int t = item - NP * Tc;
+              const int mm = 32 * NP + col;
+              const int r0 = (ch * rows_ch) % kGmSuper + 8 * t + 2 * rq;
+              d2 v;
+              v.x = mm < k ? st0[u].x * swl[r0] : 0.0;
+              v.y = mm < k ? st1[u].x * swl[r0 + 1] : 0.0;
+              panel[(size_t)((2 * NP) * Tc + t) * 64 + lane] = v;
+            } else if (item < NP * Tc) {
               const int g = item / Tc, t = item - g * Tc;
               const int mm = 32 * g + 2 * col;
               const int r0 = (ch * rows_ch) % kGmSuper + 8 * t + 2 * rq;
@@ -271,7 +316,7 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
               panel[(size_t)((2 * g) * Tc + t) * 64 + lane] = ve;
               panel[(size_t)((2 * g + 1) * Tc + t) * 64 + lane] = vo;
             } else {                                  // extra block: column 0 = sqrt(w) dep, 1 = sqrt(w) dep_det
-              const int t = item - (NB / 2) * Tc;
+              const int t = item - (NB - NP) * Tc;
               const int r0 = (ch * rows_ch) % kGmSuper + 8 * t + 2 * rq;
               d2 v;
               v.x = col == 0 ? csd[r0] : col == 1 ? csd[kGmSuper + r0] : 0.0;
@@ -377,11 +422,11 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
                 }
               }
             } else {
-              const int gi = 32 * (I >> 1) + 2 * li + (I & 1);   // member of (block, local index)
+              const int gi = I < 2 * NP ? 32 * (I >> 1) + 2 * li + (I & 1) : 32 * NP + li;   // member of (block, local index)
               if (J == NB) {
                 if (gi < k && col < 2) (col == 0 ? sl.V0 : sl.V1)[gi] = v;
               } else {
-                const int gj = 32 * (J >> 1) + 2 * col + (J & 1);
+                const int gj = J < 2 * NP ? 32 * (J >> 1) + 2 * col + (J & 1) : 32 * NP + col;
                 if (gi < k && gj < k) {
                   if (gi == gj) {
                     trp += v;
@@ -414,18 +459,22 @@ __global__ void __launch_bounds__(kGmBlock, 1) letkf_stage_gram_mfma_kernel(cons
 }
 
 hipError_t launch_stage_gram_mfma(const StagedArgs& s, hipStream_t st) {
-  const size_t lds = ((size_t)kGmPanel * 128 + 4 * (size_t)kGmSuper + 8) * sizeof(double);
-  auto go = [&](auto kern) -> hipError_t {
+  auto go = [&](auto kern, int nwv) -> hipError_t {
+    const size_t lds = ((size_t)(nwv == 4 ? kGmPanelSmall : kGmPanelBig) * 128 + 4 * (size_t)(nwv == 4 ? 512 : 1024) + 8) * sizeof(double);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)s.nbatch), dim3(kGmBlock), lds, st, s);
+    hipLaunchKernelGGL(kern, dim3((unsigned)s.nbatch), dim3(64 * nwv), lds, st, s);
     return hipGetLastError();
   };
-  hipError_t e = go(&letkf_stage_gram_mfma_kernel<true, true>);    // n < k (and every point without an eigenproblem)
-  if (e == hipSuccess) e = go(&letkf_stage_gram_mfma_kernel<false, true>);
-  if (e == hipSuccess && s.A.k > 256) {                             // orders beyond 17 blocks: chunks of fewer double-steps
-    e = go(&letkf_stage_gram_mfma_kernel<true, false>);
-    if (e == hipSuccess) e = go(&letkf_stage_gram_mfma_kernel<false, false>);
+  hipError_t e = go(&letkf_stage_gram_mfma_kernel<true, true, 4>, 4);   // small orders; n < k first (and every point without an eigenproblem)
+  if (e == hipSuccess) e = go(&letkf_stage_gram_mfma_kernel<false, true, 4>, 4);
+  if (e == hipSuccess && !gram_small(s.A.k, s.A.k)) {                   // (MEMBER <= 128: every point is small)
+    e = go(&letkf_stage_gram_mfma_kernel<true, true, 8>, 8);
+    if (e == hipSuccess) e = go(&letkf_stage_gram_mfma_kernel<false, true, 8>, 8);
+  }
+  if (e == hipSuccess && s.A.k > 256) {                                 // orders beyond 17 blocks: chunks of fewer double-steps
+    e = go(&letkf_stage_gram_mfma_kernel<true, false, 8>, 8);
+    if (e == hipSuccess) e = go(&letkf_stage_gram_mfma_kernel<false, false, 8>, 8);
   }
   return e;
 }

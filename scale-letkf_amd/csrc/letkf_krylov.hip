@@ -79,7 +79,11 @@ struct KryLds {
 // and waits for all of them (vmcnt(0)) in front of every matrix-core step (found in the ISA); a padding step fetches
 // step 0 again.  wrap: the last refills fetch the FIRST steps again (the same product is repeated: CG on one matrix).
 // olim: largest element offset a lane may fetch from its row (clamped beyond: such columns meet zero rows of B).
-template <int BPW, int PF, int NA>
+// RES (the product of the iteration at orders <= 128, r4): the ring holds the wave's WHOLE operand (T <= PF double-steps), filled
+// once per point -- no refill, the matrix stays in registers from the first iteration to the last.  The counters of the
+// streaming form (profiles/r04_k100_pmc_summary.json): 1.35 MB per point = 14 iterations x the 96 KB matrix through
+// L2 <-> fabric at 4.8 TB/s, the rate that bounds C3's stage too.
+template <int BPW, int PF, int NA, bool RES = false>
 __device__ __forceinline__ void ring_steps(d2u (&ring)[PF][BPW], const double* const (&abase)[BPW], const int olim, const int T,
                                            const bool wrap, const double* __restrict__ bbuf, const int lane, d4 (&acc)[BPW]) {
   const int Tp = (T + PF - 1) / PF * PF;
@@ -95,6 +99,7 @@ __device__ __forceinline__ void ring_steps(d2u (&ring)[PF][BPW], const double* c
           acc[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u][bi].y, b1, acc[bi], 0, 0, 0);
         }
       }
+      if constexpr (RES) continue;
       int tn = t + PF;
       if (tn >= Tp) tn = wrap ? tn - Tp : 0;
       if (tn >= T) tn = 0;
@@ -116,14 +121,14 @@ __device__ __forceinline__ void ring_fill(d2u (&ring)[PF][BPW], const double* co
   }
 }
 // nact (wave-uniform) of the BPW blocks are real: the instantiation without the idle ones
-template <int BPW, int PF>
+template <int BPW, int PF, bool RES = false>
 __device__ __forceinline__ void ring_product(const int nact, d2u (&ring)[PF][BPW], const double* const (&abase)[BPW], const int olim,
                                              const int T, const bool wrap, const double* __restrict__ bbuf, const int lane, d4 (&acc)[BPW]) {
   if constexpr (BPW == 1) {
-    ring_steps<BPW, PF, 1>(ring, abase, olim, T, wrap, bbuf, lane, acc);
+    ring_steps<BPW, PF, 1, RES>(ring, abase, olim, T, wrap, bbuf, lane, acc);
   } else if constexpr (BPW == 2) {
-    if (nact == 2) ring_steps<BPW, PF, 2>(ring, abase, olim, T, wrap, bbuf, lane, acc);
-    else ring_steps<BPW, PF, 1>(ring, abase, olim, T, wrap, bbuf, lane, acc);
+    if (nact == 2) ring_steps<BPW, PF, 2, RES>(ring, abase, olim, T, wrap, bbuf, lane, acc);
+    else ring_steps<BPW, PF, 1, RES>(ring, abase, olim, T, wrap, bbuf, lane, acc);
   } else {
     if (nact == 4) ring_steps<BPW, PF, 4>(ring, abase, olim, T, wrap, bbuf, lane, acc);
     else if (nact == 3) ring_steps<BPW, PF, 3>(ring, abase, olim, T, wrap, bbuf, lane, acc);
@@ -172,7 +177,11 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
   // wraps around into the NEXT iteration -- M is the same every time --, so the latency of L2 / Infinity Cache is paid once
   // per point, not once per iteration.  Rows beyond n are clamped to row n - 1 (dropped at the use), columns beyond n read
   // the neighbouring slab words (finite: zeroed by the caller) against zero rows of the residual block.
-  constexpr int PF = RingDepth<BPW>::value;
+#ifndef KRYLOV_RESIDENT
+#define KRYLOV_RESIDENT 1
+#endif
+  constexpr bool RES = KRYLOV_RESIDENT && NWV == 4 && BPW == 2;   // orders <= 128: T <= 16 double-steps
+  constexpr int PF = RES ? 16 : RingDepth<BPW>::value;
   const int nact_ = (nblk - wv + nwv - 1) / nwv;           // this wave's active blocks (wave-uniform), <= BPW
   const int nact = __builtin_amdgcn_readfirstlane(nact_ < 0 ? 0 : nact_ > BPW ? BPW : nact_);
   const int T = nr16 >> 3;
@@ -237,7 +246,7 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
       }
     }
 #endif
-    if (nact > 0) ring_product<BPW, PF>(nact, ring, KRY_ABASE, 1 << 30, KRY_T, true, KRY_B, lane, acc);
+    if (nact > 0) ring_product<BPW, PF, RES>(nact, ring, KRY_ABASE, 1 << 30, KRY_T, true, KRY_B, lane, acc);
     // ---- r_j to the history (lane-private; issued here, behind the product's loads, so that the next product's first
     // wait does not sit on these stores), mu = r . w per column
     double wreg[BPW][4];

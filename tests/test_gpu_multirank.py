@@ -53,3 +53,28 @@ def test_halo_only_exchange_gives_the_all_gather_analysis():
         assert h["config"]["obs_rows_per_rank_with_halo"] == a["config"]["obs_rows_per_rank_with_halo"]
         assert h["config"]["obs_rows_received_per_rank"] < a["config"]["obs_rows_received_per_rank"]
         assert abs(h["anal_checksum"] - a["anal_checksum"]) <= 1e-12 * abs(a["anal_checksum"]), (h["anal_checksum"], a["anal_checksum"])
+
+
+def test_configs3_tiling_rehearsed_with_six_ranks():
+    """`bench.py --gpus 8 --scaling strong --workload C4 --lists pipeline` is the line for BASELINE configs[3] the day an 8-GPU
+    node runs it (4 x 2 tiles, one call of letkf_das_columns_dev per tile and step).  Rehearsed here on a small domain of
+    configs[3]'s observation density with as many ranks as a one-GPU box admits on its card (6: a 3 x 2 tiling; the process guard
+    stops 8): same local observations as the single domain, every status 0, the analysis of the all-gather run."""
+    import bench_workload as bw
+    assert bw.CONFIGS["C4"]["nx"] == 1000 and bw.CONFIGS["C4"]["nx"] // 4 == bw.CONFIGS["C4-gpu"]["nx"] and bw.CONFIGS["C4"]["ny"] // 2 == bw.CONFIGS["C4-gpu"]["ny"]
+
+    def run(*extra):
+        env = dict(os.environ, LETKF_BENCH_BACKEND="gloo")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "C4-dom-mini", "--steps", "1", "--warmup", "0",
+                              "--no-cpu-baseline", "--scaling", "strong", "--lists", "pipeline", "--list-gb", "0.05", *extra], env=env,
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    one = run()
+    six = run("--gpus", "6")
+    n1 = float(one["config"]["workload"].split("mean ")[1].split(" ")[0])
+    n6 = float(six["config"]["workload"].split("mean ")[1].split(" ")[0])
+    assert n1 == n6 and n1 > 2000, (n1, n6)
+    assert six["n_gpus"] == 6 and six["nonzero_status_points"] == 0 and "3x2 tiles" in six["config"]["workload"]
+    assert "letkf_das_columns_dev" in six["config"]["workload"]
+    assert six["config"]["points_total"] == one["config"]["points_total"] == 48 * 32 * 6
