@@ -369,7 +369,11 @@ __device__ __forceinline__ int ov_n_of(const PointArgs& A, long pt) {
 }
 
 // LDS: lam [k] | tau [k] | pi [k] | om [k] | swl [k] | small [8 nv + 32] | P / C, q
-__global__ void __launch_bounds__(kABlock, STAGE_APPLY_MINWG) letkf_stage_apply_kernel(const StagedArgs S, const int pcq_doubles) {
+// NTHR / MINW (r4): 256 threads at >= 4 waves per SIMD (128 registers: up to four workgroups per CU) for k <= 512 -- the stage is a
+// chain of short dependent passes over strided state and slab words, and more points in flight per CU is what hides them
+// (A/B: MEMBER = 100 +10 %, k = 320 +5.6 %); 512 threads, one workgroup's worth of registers, for the larger orders (k = 1000: -2.7 % with 256).
+template <int NTHR, int MINW>
+__global__ void __launch_bounds__(NTHR, MINW) letkf_stage_apply_kernel(const StagedArgs S, const int pcq_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const PointArgs& A = S.A;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
@@ -892,13 +896,19 @@ hipError_t launch_stage_apply(const StagedArgs& s, hipStream_t st) {
   const size_t fixed = (size_t)5 * (k + 2) + 8 * (size_t)s.A.nv + 32;
   const size_t pcq = (size_t)stage_apply_pcq_doubles(k, s.A.nv);
   const size_t lds = (fixed + pcq) * sizeof(double);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_stage_apply_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(letkf_stage_apply_kernel, dim3((unsigned)s.nbatch), dim3(kABlock), lds, st, s, (int)pcq);
-  return hipGetLastError();
+  auto go = [&](auto kern, int nthr) -> hipError_t {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)s.nbatch), dim3(nthr), lds, st, s, (int)pcq);
+    return hipGetLastError();
+  };
+#ifndef STAGE_APPLY_SMALL_K
+#define STAGE_APPLY_SMALL_K 512
+#endif
+  if (k <= STAGE_APPLY_SMALL_K) return go(&letkf_stage_apply_kernel<256, 4>, 256);
+  return go(&letkf_stage_apply_kernel<kABlock, STAGE_APPLY_MINWG>, kABlock);
 }
 
 }  // namespace letkf
