@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "letkf_device.h"
 #include "letkf_search_dev.h"
@@ -527,7 +528,7 @@ int sched_plan_check(long npts, long stride, int run_len, int grid, int ppw, int
 
 // smallest k the instantiation <KR, NW> is dispatched for (launch_wave_kernel walks the instances in this order)
 __host__ __device__ constexpr int wave_kmin(int KR, int NW) {
-  return NW == 1 ? (KR == 16 ? 1 : KR == 32 ? 17 : KR == 48 ? 33 : KR == 50 ? 49 : KR == 64 ? 51 : 1)
+  return NW == 1 ? (KR == 16 ? 1 : KR == 20 ? 17 : KR == 32 ? 17 : KR == 48 ? 33 : KR == 50 ? 49 : KR == 64 ? 51 : 1)
                  : (KR == 64 ? 63 : KR == 80 ? 65 : KR == 100 ? 81 : 1);
 }
 
@@ -576,6 +577,21 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
 #define PROF_FLUSH
 #define PROF_UNIT
 #endif
+
+// acc += (ys of lane A of this lane's row of 16) * y: ONE instruction -- FP64 instructions take exactly one DPP control on
+// gfx950, row_newbcast (tools/ubench_newbcast.hip: correct in every row, ~10 cycles of a SIMD per instruction beside the matrix
+// instructions).  NOP: two wait states in front (a DPP read of a register a vector instruction has just written; the compiler's
+// hazard recogniser does not see into inline asm) -- set on the first one of a group.
+template <int A, bool NOP>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, const double ys, const double y) {
+#define LETKF_FMAC_BCAST(N)                                                                                                      \
+  if constexpr (A == N) {                                                                                                        \
+    if constexpr (NOP) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(ys), "v"(y)); \
+    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(ys), "v"(y)); \
+  }
+  LETKF_FMAC_BCAST(0) LETKF_FMAC_BCAST(1) LETKF_FMAC_BCAST(2) LETKF_FMAC_BCAST(3) LETKF_FMAC_BCAST(4) LETKF_FMAC_BCAST(5)
+#undef LETKF_FMAC_BCAST
+}
 
 // Checked build (make CHECKED=1 -> lib/libletkf_amd_checked.so, run by tests/test_gpu_checked.py): every index the column-survivor
 // mode derives from device data -- the run's column, the column's survivor range, the wave's slot, each list entry -- is tested
@@ -894,10 +910,26 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
     if (n != 0) {
       constexpr int NBLK = (KR + 2 + 15) / 16;                 // member blocks incl. the 2 augmented columns
       constexpr int KMIN = (NW == 1) ? wave_kmin(KR, NW) : 1;  // launch_wave_kernel: this instantiation serves wave_kmin <= k <= KR
-      constexpr int NTILE = NBLK * (NBLK + 1) / 2;
+      // STRIP (r4): where the last block is narrow at compile time -- KR = 50: members 48, 49 and the two augmented columns, 4 of 16;
+      // KR = 20: members 16 .. 19 + 2 -- its row / column of tiles does not go to the matrix cores (four 16 x 16 tiles of which
+      // 3/4 are padding: 4 of the 10 instructions of a step at k = 50) but to RS x NBLK broadcast-FMAs per step: lane (q, c)
+      // accumulates accS[a][I] += Ya[obs_q][16 S + a] * Ya[obs_q][16 I + c] over its own observations (summed over q at the end).
+#ifndef LETKF_GRAM_STRIP
+#define LETKF_GRAM_STRIP 1
+#endif
+      constexpr bool STRIP = LETKF_GRAM_STRIP && NW == 1 && (KR == 50 || KR == 20);
+      constexpr int NBF = STRIP ? NBLK - 1 : NBLK;             // blocks whose tiles are on the matrix cores
+      constexpr int RS = STRIP ? KR + 2 - 16 * (NBLK - 1) : 1;  // live columns of the narrow block (KR = 50: 4, KR = 20: 6)
+      static_assert(!STRIP || (RS >= 1 && RS <= 6 && KMIN + 2 > 16 * (NBLK - 1)), "the narrow block must be the last one for every k of the instantiation");
+      constexpr int NTILE = NBF * (NBF + 1) / 2;
       v4d acc[NTILE];
+      [[maybe_unused]] double accS[RS][NBLK];
 #pragma unroll
       for (int t = 0; t < NTILE; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int a = 0; a < RS; ++a)
+#pragma unroll
+        for (int I = 0; I < NBLK; ++I) accS[a][I] = 0.0;
       int q = wlane >> 4, c16 = wlane & 15;
       asm volatile("" : "+v"(q), "+v"(c16));   // (not loop-invariant for hipcc: see the apply phase)
 
@@ -958,12 +990,30 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
           }
           int tt = 0;
 #pragma unroll
-          for (int I = 0; I < NBLK; ++I)
+          for (int I = 0; I < NBF; ++I)
 #pragma unroll
-            for (int J = I; J < NBLK; ++J) {
+            for (int J = I; J < NBF; ++J) {
               acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[I], y[J], acc[tt], 0, 0, 0);
               ++tt;
             }
+          if constexpr (STRIP) {
+            auto strip_row = [&](auto a_) {
+              constexpr int a = decltype(a_)::value;
+              if constexpr (a < RS) {
+#pragma unroll
+                for (int I = 0; I < NBLK; ++I) {
+                  if (a == 0 && I == 0) fmac_row_bcast<a, true>(accS[a][I], y[NBLK - 1], y[I]);
+                  else fmac_row_bcast<a, false>(accS[a][I], y[NBLK - 1], y[I]);
+                }
+              }
+            };
+            strip_row(std::integral_constant<int, 0>{});
+            strip_row(std::integral_constant<int, 1>{});
+            strip_row(std::integral_constant<int, 2>{});
+            strip_row(std::integral_constant<int, 3>{});
+            strip_row(std::integral_constant<int, 4>{});
+            strip_row(std::integral_constant<int, 5>{});
+          }
         };
         // PD steps in flight.  Three things keep the pipeline the way it is written (each found in the ISA):
         //  * no conditions around the fetches (a step past the end has sw = dsw = ddsw = 0 and adds nothing): with
@@ -1223,6 +1273,15 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
       // lane l holds rows (l>>4) + 4*reg, column l&15 of its 16x16 tile.
       constexpr int LDA = 18;
       double* abuf = slice;                                    // [64 NW][LDA], spans the tile + bmat regions
+      if constexpr (STRIP) {                                   // the narrow block's sums over the four observation residues q
+#pragma unroll
+        for (int a = 0; a < RS; ++a)
+#pragma unroll
+          for (int I = 0; I < NBLK; ++I) {
+            accS[a][I] += wshfl_xor(accS[a][I], 16);
+            accS[a][I] += wshfl_xor(accS[a][I], 32);
+          }
+      }
 #pragma unroll
       for (int I = 0; I < NBLK; ++I) {
         psync<NW>();
@@ -1231,10 +1290,26 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
         for (int pass = 0; pass < NW; ++pass) {
           if (pass == 1) __syncthreads();
           if (wvp == pass) {
+            if constexpr (STRIP) {
+              // rows of block I < S: the columns 16 S + a are accS[a][I] (lane c = the row); rows of block S (a < RS): every
+              // column 16 J + c is accS[a][J] -- element (row, col) at abuf[col * LDA + row-in-block], as the tiles below
+              if (q == 0) {
+                if (I < NBLK - 1) {
 #pragma unroll
-            for (int J = 0; J < NBLK; ++J) {
+                  for (int a = 0; a < 16; ++a) abuf[(16 * (NBLK - 1) + a) * LDA + c16] = a < RS ? accS[a][I] : 0.0;   // (the padding columns: zeros, as the tiles left them)
+                } else {
+#pragma unroll
+                  for (int J = 0; J < NBLK; ++J)
+#pragma unroll
+                    for (int a = 0; a < RS; ++a) abuf[(16 * J + c16) * LDA + a] = accS[a][J];
+                }
+              }
+            }
+#pragma unroll
+            for (int J = 0; J < NBF; ++J) {
+              if (STRIP && I == NBLK - 1) continue;            // (the narrow block's rows: written above)
               const int ti = I <= J ? I : J, tj = I <= J ? J : I;
-              const int t = ti * NBLK - ti * (ti - 1) / 2 + (tj - ti);
+              const int t = ti * NBF - ti * (ti - 1) / 2 + (tj - ti);
 #pragma unroll
               for (int reg = 0; reg < 4; ++reg) {
                 const int a = q + 4 * reg, b = c16;            // tile-local (row, col) of this element
