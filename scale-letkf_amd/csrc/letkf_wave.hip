@@ -919,11 +919,16 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
 #endif
       constexpr bool STRIP = LETKF_GRAM_STRIP && NW == 1 && (KR == 50 || KR == 20);
       constexpr int NBF = STRIP ? NBLK - 1 : NBLK;             // blocks whose tiles are on the matrix cores
-      constexpr int RS = STRIP ? KR + 2 - 16 * (NBLK - 1) : 1;  // live columns of the narrow block (KR = 50: 4, KR = 20: 6)
-      static_assert(!STRIP || (RS >= 1 && RS <= 6 && KMIN + 2 > 16 * (NBLK - 1)), "the narrow block must be the last one for every k of the instantiation");
+      // The two departure columns do not ride in the narrow block either: sqrt(w) dep is the same number in every lane of an
+      // observation's row, so r = Ya^T (sqrt(w) dep) is a plain FMA per block (accD, accDD; entry (k, k) = sum w dep^2 likewise:
+      // accP) -- no per-step selects that put the departures into the block's lanes, two broadcast rows fewer.
+      constexpr int RS = STRIP ? KR - 16 * (NBLK - 1) : 1;      // member columns of the narrow block (KR = 50: 2, KR = 20: 4)
+      static_assert(!STRIP || (RS >= 1 && RS <= 6 && KMIN > 16 * (NBLK - 1)), "the narrow block must be the last one for every k of the instantiation");
       constexpr int NTILE = NBF * (NBF + 1) / 2;
       v4d acc[NTILE];
-      [[maybe_unused]] double accS[RS][NBLK];
+      [[maybe_unused]] double accS[RS][NBLK], accD[NBLK], accDD[NBLK], accP = 0.0;
+#pragma unroll
+      for (int I = 0; I < NBLK; ++I) accD[I] = accDD[I] = 0.0;
 #pragma unroll
       for (int t = 0; t < NTILE; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -983,10 +988,20 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
             // time: hipcc turns the wave-uniform test into 9 v_cndmask per block and step otherwise)
             if (16 * (I + 1) > KMIN && 16 * (I + 1) > k) {     // wave-uniform: block reaches past the members
               v = rowok[I] ? v : 0.0;
-              if (I == blk_d && is_d) v = t.dsw;
-              if (I == blk_dd && is_dd) v = t.ddsw;
+              if constexpr (!STRIP) {
+                if (I == blk_d && is_d) v = t.dsw;
+                if (I == blk_dd && is_dd) v = t.ddsw;
+              }
             }
             y[I] = v;
+          }
+          if constexpr (STRIP) {
+#pragma unroll
+            for (int I = 0; I < NBLK; ++I) {
+              accD[I] = fma(y[I], t.dsw, accD[I]);
+              accDD[I] = fma(y[I], t.ddsw, accDD[I]);
+            }
+            accP = fma(t.dsw, t.dsw, accP);
           }
           int tt = 0;
 #pragma unroll
@@ -1281,6 +1296,24 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
             accS[a][I] += wshfl_xor(accS[a][I], 16);
             accS[a][I] += wshfl_xor(accS[a][I], 32);
           }
+#pragma unroll
+        for (int I = 0; I < NBLK; ++I) {
+          accD[I] += wshfl_xor(accD[I], 16);
+          accD[I] += wshfl_xor(accD[I], 32);
+          accDD[I] += wshfl_xor(accDD[I], 16);
+          accDD[I] += wshfl_xor(accDD[I], 32);
+        }
+        accP += wshfl_xor(accP, 16);
+        accP += wshfl_xor(accP, 32);
+        // lane j = 16 q + c owns column j: its r_j, r_det_j are block q's sums (every lane (., c) holds the sums of all blocks)
+        racc = rdacc = 0.0;
+#pragma unroll
+        for (int I = 0; I < NBLK; ++I)
+          if (q == I) {
+            racc = accD[I];
+            rdacc = accDD[I];
+          }
+        p1 = accP;                                             // A_aug[k][k] = sum w dep^2
       }
 #pragma unroll
       for (int I = 0; I < NBLK; ++I) {
@@ -1331,10 +1364,14 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
               g[16 * I + e + 1] = v2.y;
             }
           }
-          if ((k >> 4) == I) racc = abuf[lane * LDA + (k & 15)];
-          if (((k + 1) >> 4) == I) rdacc = abuf[lane * LDA + ((k + 1) & 15)];
+          if constexpr (!STRIP) {
+            if ((k >> 4) == I) racc = abuf[lane * LDA + (k & 15)];
+            if (((k + 1) >> 4) == I) rdacc = abuf[lane * LDA + ((k + 1) & 15)];
+          }
         }
-        if ((k >> 4) == I) p1 = abuf[k * LDA + (k & 15)];      // A_aug[k][k] = sum w dep^2
+        if constexpr (!STRIP) {
+          if ((k >> 4) == I) p1 = abuf[k * LDA + (k & 15)];    // A_aug[k][k] = sum w dep^2
+        }
       }
       psync<NW>();
       // rows >= k of a column (the augmented rows) and whole columns >= k play no part in the eigenproblem
