@@ -278,3 +278,17 @@ def test_das_points_large_k_block_jacobi(k, name):
     assert (status == 0).all()
     compare_anal(c, ref, got, k, 11, bool(cfg.get("det_run", 0)))
     assert np.abs(infl - ref["infl"]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("k,nv,name", [(50, 16, "rtps_det"), (20, 15, "rtpp"), (120, 16, "rtps_adaptive_det"), (50, 7, "rtps"), (100, 5, "rtps_det")])
+def test_das_points_other_variable_counts(k, nv, name):
+    """nv != 11: the register kernels are instantiated for the reference's nv3d = 11 (common_nml.f90:19); other counts go to the
+    staged path (nv + 2 <= 16 right-hand sides) and, beyond that, to round 1's workgroup kernel (letkf_point_kernel) -- the one
+    production route that kernel still has.  Against the oracle like every other route."""
+    from _gpu import ctx
+    cfg = CONFIGS[name]
+    c, ref, got, infl, status, _, _ = run_both(k, nv, 24, 600, 150, seed=77 + k + nv, cfg=cfg)
+    assert (status == 0).all(), status
+    compare_anal(c, ref, got, k, nv, bool(cfg.get("det_run", 0)))
+    assert np.abs(infl - ref["infl"]).max() <= 1e-12
+    assert ("letkf_point_kernel" in ctx().last_path()) == (nv + 2 > 16), ctx().last_path()
