@@ -243,9 +243,11 @@ int letkf_ens_mean_dev(letkf_ctx *ctx, int32_t k, int32_t nv, int64_t npts, doub
  *     limit the selected SET equals the reference's (the N best inside the cut-off; the incremental search of
  *     :1527-1602 is a pure speed heuristic) up to ties; the order inside the list is
  *     implementation-defined in the reference too (unstable quick-select).
- *     Dense observations under a limit (thousands of rows inside the horizontal cut-off, distance criterion): the column entry
- *     keeps a group's horizontal survivors in global memory by rings of nd_h^2 and takes the nearest rings only
- *     (LETKF_OPT_LIMITED_RINGS; letkf_search.hip) -- same selection up to ties.
+ *     Dense observations under a limit (thousands of rows inside the horizontal cut-off): the column entry keeps a group's
+ *     horizontal survivors in global memory by rings and takes the nearest rings only (LETKF_OPT_LIMITED_RINGS;
+ *     letkf_search.hip) -- same selection up to ties.  Rings of nd_h^2 for the distance criterion (and the weight criterion
+ *     where a group has one variable-localisation factor), of nd_h^2 + an offset per entry for the weight criterion with
+ *     several factors in a group and for the error criterion (2 ln(err^2 / varloc)): all three criteria are served (ABI 7).
  *     The cut-off constants are the reference's single-precision literals (letkf_obs.f90:27-28).
  *-------------------------------------------------------------------------*/
 typedef struct {

@@ -943,7 +943,7 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
                          const int64_t* obs_off, int32_t* obs_idx, double* rdiag_l, double* rloc_l, int32_t* nobs_ctype,
                          double* cutd_ctype, bool* taken) {
   *taken = false;
-  if (c->limited_rings == 0 || t->criterion > 2 || t->nctype > 64 || nij1 * (int64_t)t->ngroup >= 0x7fffffff) return LETKF_OK;
+  if (c->limited_rings == 0 || t->criterion > 3 || t->nctype > 64 || nij1 * (int64_t)t->ngroup >= 0x7fffffff) return LETKF_OK;
   const void* key[5] = {t->ob_ri, t->ac_ext, t->max_nobs, rig, rjg};
   if (c->limited_rings == 2 && c->ring_no_n == nij1 && c->ring_no_crit == t->criterion && std::equal(key, key + 5, c->ring_no)) {
     if (!c->ring_keep) c->ring_no_n = -1;   // (a count -> fill pair: used once)
@@ -958,7 +958,11 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
   HIP_TRY(hipMemcpy(gmem.data(), t->group_member, sizeof(int32_t) * gmem.size(), hipMemcpyDeviceToHost));
   int nlim = 0;
   std::vector<double> vl;
-  if (t->criterion == 2) {   // the weight criterion orders like the distance where a group has ONE variable-localisation factor
+  // The weight criterion orders like the distance where a group has ONE variable-localisation factor: the plain rings serve.
+  // Several factors in a group, and the error criterion (3), take the GENERAL ring key (r4, letkf_search.hip ring_offset): an
+  // offset per entry, the group's smallest one as its reference.
+  bool gen = t->criterion == 3;
+  if (t->criterion >= 2) {
     vl.resize(t->nctype);
     HIP_TRY(hipMemcpy(vl.data(), t->varloc, sizeof(double) * t->nctype, hipMemcpyDeviceToHost));
   }
@@ -968,7 +972,7 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
     nlim += nm > 0;
     if (nm > 0 && t->criterion == 2)
       for (int m = gstart[g] + 1; m < gstart[g + 1]; ++m)
-        if (vl[gmem[m]] != vl[gmem[gstart[g]]]) return LETKF_OK;
+        if (vl[gmem[m]] != vl[gmem[gstart[g]]]) gen = true;
   }
   if (nlim == 0) return LETKF_OK;
   const int ng = t->ngroup;
@@ -983,23 +987,48 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
   const size_t o_off = ((ncg + 1) * 4 + 255) & ~(size_t)255, o_scan = o_off + (((ncg + 1) * 8 + 255) & ~(size_t)255);
   const size_t o_roff = o_scan + ((scan_b + 255) & ~(size_t)255);
   const size_t nring1 = (size_t)letkf::search_rings_count() + 1;   // ring starts per (column, group)
-  const size_t roff_b = ncg * nring1 * 4;
-  const size_t need_aux = o_roff + roff_b + 256;
+  const size_t roff_b = (ncg * nring1 * 4 + 255) & ~(size_t)255;
+  const size_t o_kref = o_roff + roff_b;                            // kref [ngroup] | min err [nctype] (general ring key)
+  const size_t need_aux = o_kref + ((size_t)ng + (size_t)t->nctype) * 8 + 256;
   if (need_aux > c->ring_aux_bytes) HIP_TRY(hipStreamSynchronize(c->stream));
   if (int rc = ensure_bytes(c, &c->ring_aux, &c->ring_aux_bytes, need_aux)) return rc;
   int32_t* cnt = reinterpret_cast<int32_t*>(c->ring_aux);
   int64_t* goff = reinterpret_cast<int64_t*>(c->ring_aux + o_off);
   int32_t* roff = reinterpret_cast<int32_t*>(c->ring_aux + o_roff);
+  double* kref = nullptr;
+  if (gen) {
+    // reference offsets: the smallest offset an entry of the group can have -- criterion 2: -2 ln(largest factor); criterion 3:
+    // 2 ln(smallest error^2 / factor) over the group's types (the smallest error of a type: one small kernel + a read-back)
+    kref = reinterpret_cast<double*>(c->ring_aux + o_kref);
+    std::vector<double> emin(t->nctype, 1.0), kr(ng);
+    if (t->criterion == 3) {
+      HIP_TRY(letkf::launch_ctype_min_err(*t, kref + ng, c->stream));
+      HIP_TRY(hipMemcpyAsync(emin.data(), kref + ng, sizeof(double) * t->nctype, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    for (int g = 0; g < ng; ++g) {
+      double lo = 1e300;
+      for (int m = gstart[g]; m < gstart[g + 1]; ++m) {
+        const int ic = gmem[m];
+        if (!(vl[ic] > 0.0)) continue;
+        const double off = t->criterion == 2 ? -2.0 * std::log(vl[ic]) : 2.0 * std::log(emin[ic] * emin[ic] / vl[ic]);
+        if (off == off && off < lo) lo = off;
+      }
+      kr[g] = lo < 1e299 ? lo : 0.0;
+    }
+    HIP_TRY(hipMemcpyAsync(kref, kr.data(), sizeof(double) * ng, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // (kr goes out of scope)
+  }
   if (c->ring_keep && c->ring_ready) {
     // (a later call of the same letkf_das_columns_dev: same tables, same columns -- the ring-ordered survivors are still there)
     *taken = true;
     HIP_TRY(letkf::launch_search_rings(*t, 0, nij1, nij1, nlev, rlev, rz, fill, counts, reinterpret_cast<const long*>(obs_off), obs_idx,
                                        rdiag_l, rloc_l, nobs_ctype, cutd_ctype, reinterpret_cast<const long*>(goff),
-                                       reinterpret_cast<double*>(c->ring_ws), roff, c->num_cu, c->stream));
+                                       reinterpret_cast<double*>(c->ring_ws), roff, kref, c->num_cu, c->stream));
     return LETKF_OK;
   }
   HIP_TRY(hipMemsetAsync(cnt + ncg, 0, 4, c->stream));
-  HIP_TRY(letkf::launch_ring_survivors(*t, 0, nij1, rig, rjg, 0, cnt, nullptr, nullptr, nullptr, c->num_cu, c->stream));
+  HIP_TRY(letkf::launch_ring_survivors(*t, 0, nij1, rig, rjg, 0, cnt, nullptr, nullptr, nullptr, nullptr, c->num_cu, c->stream));
   {
     auto in = rocprim::make_transform_iterator(static_cast<const int32_t*>(cnt), [] __device__(int32_t v) { return (int64_t)v; });
     HIP_TRY(rocprim::exclusive_scan(c->ring_aux + o_scan, scan_b, in, goff, (int64_t)0, ncg + 1, rocprim::plus<int64_t>(), c->stream));
@@ -1062,9 +1091,9 @@ int search_columns_rings(letkf_ctx* c, const letkf_search_tables* t, int64_t nij
     double* sv = reinterpret_cast<double*>(c->ring_ws) - 4 * hoff[(size_t)c0 * ng];
     const long* gq = reinterpret_cast<const long*>(goff + (size_t)c0 * ng);
     int32_t* rq = roff + (size_t)c0 * ng * nring1;
-    HIP_TRY(letkf::launch_ring_survivors(*t, c0, c1 - c0, rig, rjg, 1, nullptr, gq, sv, rq, c->num_cu, c->stream));
+    HIP_TRY(letkf::launch_ring_survivors(*t, c0, c1 - c0, rig, rjg, 1, nullptr, gq, sv, rq, kref, c->num_cu, c->stream));
     HIP_TRY(letkf::launch_search_rings(*t, c0, c1 - c0, nij1, nlev, rlev, rz, fill, counts, reinterpret_cast<const long*>(obs_off),
-                                       obs_idx, rdiag_l, rloc_l, nobs_ctype, cutd_ctype, gq, sv, rq, c->num_cu, c->stream));
+                                       obs_idx, rdiag_l, rloc_l, nobs_ctype, cutd_ctype, gq, sv, rq, kref, c->num_cu, c->stream));
     c0 = c1;
   }
   c->ring_ready = keep;

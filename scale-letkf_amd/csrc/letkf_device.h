@@ -161,12 +161,14 @@ struct SearchArgs {
   int limited;         // some max_nobs > 0 (host knowledge: sizes the LDS candidate cache)
 };
 hipError_t launch_search(const SearchArgs& a, int num_cu, hipStream_t st);
+// kref: null = the distance criterion's rings (nd_h^2); else [ngroup] reference offsets of the general ring key (criteria 2, 3)
 hipError_t launch_ring_survivors(const letkf_search_tables& t, long col0, long ncol, const double* rig, const double* rjg, int fill,
-                                 int* counts, const long* goff, double* sv, int* roff, int num_cu, hipStream_t st);
+                                 int* counts, const long* goff, double* sv, int* roff, const double* kref, int num_cu, hipStream_t st);
 hipError_t launch_search_rings(const letkf_search_tables& t, long col0, long ncol, long nij1, int nlev, const double* rlev,
                                const double* rz, int fill, int* counts, const long* obs_off, int* obs_idx, double* rdiag_l,
                                double* rloc_l, int* nobs_ctype, double* cutd_ctype, const long* goff, const double* sv,
-                               const int* roff, int num_cu, hipStream_t st);
+                               const int* roff, const double* kref, int num_cu, hipStream_t st);
+hipError_t launch_ctype_min_err(const letkf_search_tables& t, double* out, hipStream_t st);
 int search_rings_max_nobs();
 int search_rings_count();
 int search_rings_lds_survivors();

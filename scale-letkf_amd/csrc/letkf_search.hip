@@ -1225,7 +1225,20 @@ struct RingBuildArgs {
   const long* goff;      // FILL = 1: [ncol * ngroup + 1] entry offsets (absolute), group-fastest
   double* sv;            // entries: (row | ctype << 32 as bits, nd_h, v_obs, err)
   int* roff;             // FILL = 1: [ncol * ngroup][kRings + 1] ring starts relative to the (column, group)'s first entry
+  int gen;               // general ring key (r4, see ring_offset): criterion 3, and criterion 2 with several factors in a group
+  const double* kref;    // gen: [ngroup] the group's reference offset (a lower estimate of its entries' offsets)
 };
+
+// The general ring key (r4).  Selection by weight (criterion 2: largest rloc = varloc exp(-nd / 2)) and by error (criterion 3:
+// smallest rdiag = err^2 / rloc) order like  nd + off  with an offset per ENTRY,
+//     criterion 2: off = -2 ln varloc(ctype)          criterion 3: off = 2 ln(err^2 / varloc(ctype)),
+// so the survivors are ringed by  nd_h^2 + off - kref(group)  (kref: the smallest offset the host could find for the group;
+// an entry below it lands in ring 0, which has no lower bound anyway) and a ring's lower edge bounds the exact key of
+// everything behind it: rdiag >= exp((edge + kref) / 2), rloc <= exp(-(edge + kref) / 2).  The SELECTION itself compares the
+// reference's own numbers (rloc, rdiag as obs_local_cal computes them), never the ring key.
+__device__ __forceinline__ double ring_offset(const int criterion, const double varloc, const double err) {
+  return criterion == 2 ? -2.0 * log(varloc) : 2.0 * log(err * err / varloc);
+}
 
 template <bool FILL>
 __global__ void __launch_bounds__(256) letkf_ring_survivors_kernel(const RingBuildArgs A) {
@@ -1275,12 +1288,14 @@ __global__ void __launch_bounds__(256) letkf_ring_survivors_kernel(const RingBui
                 ok = !(nd_h > kDistZeroFac);                        // :1881
               }
               const unsigned long long mk = __ballot(ok);
+              double hk = nd_h * nd_h;
+              if (A.gen && what != 0 && ok) hk = fmax(hk + ring_offset(t.criterion, t.varloc[ic], t.ob_err[row]) - A.kref[ig], 0.0);
               if (what == 1 && mk) {
                 // the histogram: one LDS atomic per survivor (the ORDER of the additions is irrelevant here)
-                const int ring = ringed ? min(kRings - 1, (int)(nd_h * nd_h * kRingScale)) : 0;
+                const int ring = ringed ? min(kRings - 1, (int)(hk * kRingScale)) : 0;
                 if (ok) atomicAdd(&rpos[ring], 1);
               } else if (what == 2 && mk) {
-                const int ring = ringed ? min(kRings - 1, (int)(nd_h * nd_h * kRingScale)) : 0;
+                const int ring = ringed ? min(kRings - 1, (int)(hk * kRingScale)) : 0;
                 // lane order inside a ring: deterministic positions (an LDS atomic per lane would scatter them run by run)
                 for (int r = 0; r < kRings; ++r) {
                   const unsigned long long mr = __ballot(ok && ring == r);
@@ -1352,10 +1367,15 @@ struct RingSearchArgs {
   const long* goff;      // [ncol * ngroup + 1] absolute entry offsets of this batch's columns
   const double* sv;      // (base shifted so that the absolute offsets address it)
   const int* roff;       // [ncol * ngroup][kRings + 1]
+  const double* kref;    // GEN: [ngroup] (RingBuildArgs)
 };
 constexpr int kRingSlots = 6;    // slots of 64 keys per lane a tile takes (carried selection + new entries): with the 9 of the LDS kernel the tile spilled 1.2 KB per lane
 constexpr int kRingSel = 128;    // largest MAX_NOBS_PER_GRID this kernel serves (the carried selection lives in LDS and re-enters every tile)
 
+// GEN: the general ring key (ring_offset): the tile's keys are the reference's own selection numbers -- key_bits of rloc
+// (criterion 2) / rdiag (criterion 3), computed for every entry of a visited ring --, the value carried beside a key is the
+// observation error (2) / rloc (3), and the stop test compares the ring edge's bound in those units.
+template <bool GEN>
 __global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSearchArgs A) {
 #pragma clang fp contract(off)
   __shared__ __attribute__((aligned(16))) unsigned int hist_all[4][kSurvL / 2];
@@ -1462,8 +1482,16 @@ __global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSe
             while (rp + 1 < kRings && ro[rp + 1] <= pos) ++rp;      // the ring the next entry lies in
             if (count_only && tot >= nmax) break;
             if (nB == nmax) {
-              const double lb = (double)rp * (1.0 / kRingScale) * (1.0 - 1e-12);   // nd >= nd_h^2 >= lb for everything from here on
-              if ((unsigned long long)__double_as_longlong(lb) >= tau) break;
+              if constexpr (!GEN) {
+                const double lb = (double)rp * (1.0 / kRingScale) * (1.0 - 1e-12);   // nd >= nd_h^2 >= lb for everything from here on
+                if ((unsigned long long)__double_as_longlong(lb) >= tau) break;
+              } else if (rp > 0) {                                   // (ring 0 also holds what lies below the reference offset)
+                const double edge = (double)rp * (1.0 / kRingScale) + A.kref[ig];
+                const unsigned long long lbk =
+                    t.criterion == 2 ? 0x7FFFFFFFFFFFFFFFull - (unsigned long long)__double_as_longlong(exp(-0.5 * edge) * (1.0 + 1e-9))
+                                     : (unsigned long long)__double_as_longlong(exp(0.5 * edge) * (1.0 - 1e-9));
+                if (lbk >= tau) break;
+              }
             }
             const int nbs = (nB + 63) >> 6;                          // slots the carried selection takes
             unsigned long long keyr[kRingSlots];
@@ -1497,9 +1525,20 @@ __global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSe
                 const int e = pos + (u - nbs) * 64 + lane;
                 double nd;
                 if (e < n_g && entry_key(ta[u], tb[u], nd)) {
-                  keyr[u] = (unsigned long long)__double_as_longlong(nd);
                   rwr[u] = __double_as_longlong(ta[u].x);
-                  errr[u] = tb[u].y;
+                  if constexpr (!GEN) {
+                    keyr[u] = (unsigned long long)__double_as_longlong(nd);
+                    errr[u] = tb[u].y;
+                  } else {
+                    const double rloc = s_varloc[(int)(rwr[u] >> 32)] * exp(-0.5 * nd);          // :1899
+                    if (t.criterion == 2) {
+                      keyr[u] = 0x7FFFFFFFFFFFFFFFull - (unsigned long long)__double_as_longlong(rloc);
+                      errr[u] = tb[u].y;
+                    } else {
+                      keyr[u] = (unsigned long long)__double_as_longlong(tb[u].y * tb[u].y / rloc);   // :1903
+                      errr[u] = rloc;
+                    }
+                  }
                 }
               }
               const int c = __popcll(__ballot(keyr[u] != kNoKey));
@@ -1512,7 +1551,7 @@ __global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSe
             wave_lds_sync();                                         // (everybody has read the carried selection)
             unsigned long long thresh = kNoKey;
             int tie_budget = 0;
-            if (nreal > nmax) hist_thresh<kRingSlots>(keyr, kRingSlots * 64, nreal, nmax, hist, thresh, tie_budget, 256.0 / 13.5);
+            if (nreal > nmax) hist_thresh<kRingSlots>(keyr, kRingSlots * 64, nreal, nmax, hist, thresh, tie_budget, GEN ? 0.0 : 256.0 / 13.5);
             tie_budget = uni(tie_budget);
             const bool ties = thresh != kNoKey;
             int nl = 0;
@@ -1555,17 +1594,29 @@ __global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSe
             lmx = wave_max_u32(lmx);
             const double kv = __longlong_as_double((long long)(((unsigned long long)hmx << 32) | lmx));
             // (criterion 2: the smallest selected weight -- one variable-localisation factor per group, the host checked)
-            cutd = (t.criterion == 1) ? t.hori_loc[icm] * sqrt(kv) : s_varloc[icm] * exp(-0.5 * kv);
+            if constexpr (!GEN) cutd = (t.criterion == 1) ? t.hori_loc[icm] * sqrt(kv) : s_varloc[icm] * exp(-0.5 * kv);
+            else   // the smallest selected weight / the largest selected error variance (:1716-1727): the largest key itself
+              cutd = t.criterion == 2 ? __longlong_as_double((long long)(0x7FFFFFFFFFFFFFFFull - (((unsigned long long)hmx << 32) | lmx))) : kv;
           }
           if (A.fill) {
             for (int j = lane; j < nB; j += 64) {
               const long rw = brw[j];
               const int ic = (int)(rw >> 32);
-              const double nd = __longlong_as_double((long long)bkey[j]);
-              const double rloc = s_varloc[ic] * exp(-0.5 * nd);                         // :1899
+              double rloc, rdiag;
+              if constexpr (!GEN) {
+                const double nd = __longlong_as_double((long long)bkey[j]);
+                rloc = s_varloc[ic] * exp(-0.5 * nd);                                    // :1899
+                rdiag = berr[j] * berr[j] / rloc;                                         // :1903
+              } else if (t.criterion == 2) {
+                rloc = __longlong_as_double((long long)(0x7FFFFFFFFFFFFFFFull - bkey[j]));
+                rdiag = berr[j] * berr[j] / rloc;
+              } else {
+                rloc = berr[j];
+                rdiag = __longlong_as_double((long long)bkey[j]);
+              }
               const long o = out0 + emitted + j;
               A.obs_idx[o] = (int)(rw & 0xffffffffL);
-              A.rdiag_l[o] = berr[j] * berr[j] / rloc;                                    // :1903
+              A.rdiag_l[o] = rdiag;
               A.rloc_l[o] = rloc;
             }
           }
@@ -1582,10 +1633,33 @@ __global__ void __launch_bounds__(256, 2) letkf_search_rings_kernel(const RingSe
   }
 }
 
+// smallest observation error of every combined type (one workgroup per type; the rows of a type are one range of the table:
+// from the first to the last prefix sum of its mesh) -- for the reference offsets of the general ring key (criterion 3)
+__global__ void __launch_bounds__(256) letkf_ctype_min_err_kernel(const letkf_search_tables t, double* out) {
+  __shared__ double red[256];
+  const int ic = blockIdx.x;
+  const long acb = t.ac_off[ic];
+  const long nac = (long)(t.ngrdext_i[ic] + 1) * t.ngrdext_j[ic];
+  const int lo = t.ac_ext[acb], hi = t.ac_ext[acb + nac - 1];
+  double m = 1e300;
+  for (int r = lo + threadIdx.x; r < hi; r += 256) m = fmin(m, t.ob_err[r]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s_ = 128; s_ > 0; s_ >>= 1) {
+    if ((int)threadIdx.x < s_) red[threadIdx.x] = fmin(red[threadIdx.x], red[threadIdx.x + s_]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[ic] = red[0];
+}
+hipError_t launch_ctype_min_err(const letkf_search_tables& t, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(letkf_ctype_min_err_kernel, dim3(t.nctype), dim3(256), 0, st, t, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_ring_survivors(const letkf_search_tables& t, long col0, long ncol, const double* rig, const double* rjg, int fill,
-                                 int* counts, const long* goff, double* sv, int* roff, int num_cu, hipStream_t st) {
+                                 int* counts, const long* goff, double* sv, int* roff, const double* kref, int num_cu, hipStream_t st) {
   if (ncol <= 0) return hipSuccess;
-  RingBuildArgs a{t, col0, ncol, rig, rjg, counts, goff, sv, roff};
+  RingBuildArgs a{t, col0, ncol, rig, rjg, counts, goff, sv, roff, kref != nullptr ? 1 : 0, kref};
   const long nwg = (ncol + 3) / 4;
   const long g = (long)num_cu * 8;
   const int grid = (int)(nwg < g ? nwg : g);
@@ -1597,14 +1671,15 @@ hipError_t launch_ring_survivors(const letkf_search_tables& t, long col0, long n
 hipError_t launch_search_rings(const letkf_search_tables& t, long col0, long ncol, long nij1, int nlev, const double* rlev,
                                const double* rz, int fill, int* counts, const long* obs_off, int* obs_idx, double* rdiag_l,
                                double* rloc_l, int* nobs_ctype, double* cutd_ctype, const long* goff, const double* sv,
-                               const int* roff, int num_cu, hipStream_t st) {
+                               const int* roff, const double* kref, int num_cu, hipStream_t st) {
   if (ncol <= 0) return hipSuccess;
   RingSearchArgs a{t, col0, ncol, nij1, nlev, rlev, rz, fill, counts, obs_off, obs_idx, rdiag_l, rloc_l, nobs_ctype, cutd_ctype,
-                   goff, sv, roff};
+                   goff, sv, roff, kref};
   const long nwg = (ncol + 3) / 4;
   const long g = (long)num_cu * 4;
   const int grid = (int)(nwg < g ? nwg : g);
-  hipLaunchKernelGGL(letkf_search_rings_kernel, dim3(grid), dim3(256), 0, st, a);
+  if (kref) hipLaunchKernelGGL(letkf_search_rings_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(letkf_search_rings_kernel<false>, dim3(grid), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -98,8 +98,9 @@ def test_column_search_with_obs_number_limit(criterion, nlev, max_nobs, rings):
     """MAX_NOBS_PER_GRID on the column path (letkf_tools.f90:1479-1729; merged group (0, 1) under its master's limit,
     :1434-1436): per point the same SET as the per-point kernel -- which the oracle tests pin to the reference's
     selection -- with the same weights, plus the NOBS_OUT inputs nobsl_t and cutd_t (:1633-1640, :1713-1727).
-    rings = 1: the route for DENSE observations forced on (LETKF_OPT_LIMITED_RINGS; the distance criterion, and the weight criterion
-    where a merged group has one variable-localisation factor as here -- criterion 3 keeps the LDS-buffered kernel whatever the option says): survivors by rings of nd_h^2 in global memory, tiles, early stop."""
+    rings = 1: the route for DENSE observations forced on (LETKF_OPT_LIMITED_RINGS): survivors by rings in global memory, tiles, early
+    stop -- rings of nd_h^2 for the distance criterion and the weight criterion with one factor per group (as here), of the general
+    key nd_h^2 + offset for the error criterion (r4)."""
     from _gpu import ctx, dev
     case = build_case(33 + criterion, npts=70, max_nobs=max_nobs, criterion=criterion)
     t, keep = device_struct(case, "cuda")
@@ -163,6 +164,97 @@ def test_column_search_with_obs_number_limit(criterion, nlev, max_nobs, rings):
                 for ic in g:
                     assert nct[pt, ic] == int((which == ic).sum())
     assert hit > 20                                             # the limit was actually reached
+
+
+@pytest.mark.parametrize("criterion", [2, 3])
+def test_ring_route_general_key_several_factors_in_a_group(criterion):
+    """The general ring key (r4, letkf_search.hip ring_offset): a merged group whose types differ in their variable-localisation
+    factor under the weight criterion, and the error criterion with errors of 1, 3 and 5 in one group -- the orders are no longer
+    the distance's.  The ring route forced on against the per-point kernel: same rows, same weights to the last bit, same nobsl_t
+    and cut-off measure."""
+    from _gpu import ctx, dev
+    nlev, max_nobs = 9, (30, 30, 12, 6)
+    case = build_case(71 + criterion, npts=60, max_nobs=max_nobs, criterion=criterion, nobs_per_ctype=(2500, 1500, 900, 500))
+    case["arr"]["varloc"] = np.array([1.0, 0.55, 0.8, 0.3])        # group (0, 1): two factors
+    t, keep = device_struct(case, "cuda")
+    p = case["pts"]
+    nij1 = 60
+    rng = np.random.default_rng(nlev + criterion)
+    rlev = rng.uniform(2.5e4, 1.0e5, nij1 * nlev)
+    rz = rng.uniform(0.0, 12000.0, nij1 * nlev)
+    c = ctx()
+    o1, i1, d1, l1 = c.obs_search(t, dev(np.tile(p["ri"], nlev)), dev(np.tile(p["rj"], nlev)), dev(rlev), dev(rz))
+    res = []
+    for rings in (0, 1):
+        nct = torch.full((nij1 * nlev, 4), -1, dtype=torch.int32, device="cuda")
+        cut = torch.full((nij1 * nlev, 4), -1.0, dtype=torch.float64, device="cuda")
+        c.set_option(c.OPT_LIMITED_RINGS, rings)
+        try:
+            o2, i2, d2, l2 = c.obs_search_columns(t, nij1, nlev, dev(p["ri"]), dev(p["rj"]), dev(rlev), dev(rz), nobs_ctype=nct,
+                                                  cutd_ctype=cut)
+            torch.cuda.synchronize()
+        finally:
+            c.set_option(c.OPT_LIMITED_RINGS, 2)
+        res.append([x.cpu().numpy() for x in (o2, i2, d2, l2, nct, cut)])
+    o1, i1, d1, l1 = (x.cpu().numpy() for x in (o1, i1, d1, l1))
+    hit = 0
+    for (o2, i2, d2, l2, nct, cut) in res:
+        assert np.array_equal(o1, o2)
+        for pt in range(nij1 * nlev):
+            s_ = slice(o1[pt], o1[pt + 1])
+            assert sorted(zip(i1[s_].tolist(), d1[s_].tolist(), l1[s_].tolist())) == sorted(zip(i2[s_].tolist(), d2[s_].tolist(), l2[s_].tolist())), pt
+        hit += int((nct[:, 0] == max_nobs[0]).sum())
+    assert np.array_equal(res[0][4], res[1][4]) and np.array_equal(res[0][5], res[1][5])   # nobsl_t, cutd_t: both routes alike
+    assert hit > 200                                                                    # the limit was reached
+
+
+def test_dense_observations_error_criterion_rings_against_the_oracle():
+    """MAX_NOBS_PER_GRID_CRITERION = 3 (scale/letkf/letkf_tools.f90:1663-1729) on BASELINE configs[3]'s density: ~5000 candidates
+    per point and type with observation errors drawn at random, the 100 smallest error variances rdiag = err^2 / rloc selected --
+    through the ring route with the general key (survivors ringed by nd_h^2 + 2 ln(err^2 / varloc)) against the ORACLE's own
+    obs_local (orc_obs_local: every candidate evaluated, sorted): the same rows and weights for every sampled point, and the lists
+    of the LDS-buffered kernel's fall-back for all of them."""
+    import bench_workload as bw
+    import _search
+    from _gpu import ctx, pkg
+    dev_ = torch.device("cuda:0")
+    w = bw.build("C4-slab", dev_, lists=False)
+    nij1, nlev = w["cfg"]["nx"] * w["cfg"]["ny"], w["cfg"]["nz"]
+    t_s, keep, order, pts = bw.search_tables(w, pkg, dev_, max_nobs=100)
+    g = torch.Generator(device=dev_)
+    g.manual_seed(5)
+    keep["ob_err"] = (0.5 + 4.5 * torch.rand(keep["ob_err"].numel(), generator=g, device=dev_, dtype=torch.float64)).contiguous()
+    t_s.ob_err = keep["ob_err"].data_ptr()
+    t_s.criterion = 3
+    c = ctx()
+    rig, rjg = pts[0][:nij1].contiguous(), pts[1][:nij1].contiguous()
+    res = []
+    for rings in (1, 0):
+        c.set_option(c.OPT_LIMITED_RINGS, rings)
+        try:
+            o, i, d, l = c.obs_search_columns(t_s, nij1, nlev, rig, rjg, pts[2], pts[3])
+            torch.cuda.synchronize()
+        finally:
+            c.set_option(c.OPT_LIMITED_RINGS, 2)
+        res.append([x.cpu().numpy() for x in (o, i, d, l)])
+    (o1, i1, d1, l1), (o0, i0, d0, l0) = res
+    assert np.array_equal(o0, o1) and int(np.diff(o1).max()) == 200 and int(np.diff(o1).min()) == 200
+    for pt in range(nij1 * nlev):
+        s_ = slice(o1[pt], o1[pt + 1])
+        assert sorted(zip(i1[s_].tolist(), d1[s_].tolist(), l1[s_].tolist())) == sorted(zip(i0[s_].tolist(), d0[s_].tolist(), l0[s_].tolist())), pt
+    h, alive = _search.host_struct_from_torch(t_s, keep)
+    rng = np.random.default_rng(8)
+    sample = np.sort(rng.choice(nij1 * nlev, size=40, replace=False))
+    P = [x.cpu().numpy() for x in pts]
+    off, idx, rd, rl, tied = _search.oracle_csr(h, P[0][sample], P[1][sample], P[2][sample], P[3][sample])
+    assert not tied.any()
+    for j, pt in enumerate(sample):
+        s_ = slice(o1[pt], o1[pt + 1])
+        e = slice(off[j], off[j + 1])
+        # (the same ROWS; the weights to rounding: the device's exp against libm's)
+        a, b = np.argsort(i1[s_]), np.argsort(idx[e])
+        assert np.array_equal(i1[s_][a], idx[e][b]), pt
+        assert np.allclose(d1[s_][a], rd[e][b], rtol=1e-14, atol=0) and np.allclose(l1[s_][a], rl[e][b], rtol=1e-14, atol=0), pt
 
 
 def test_search_limit_hint_spares_the_sync():
