@@ -319,17 +319,29 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
 
   // ================= g_T(T_m) e_1 for the columns b >= 2, m_b = mj rows each
   // (a) the tridiagonals: wave w takes the columns 2 + w, 2 + w + NWV, ...; lane l holds rows 2l and 2l + 1
+  // PACKED (r4): with at most 2 GS iterations (GS = 64 / NC lanes) the wave's NC columns run side by side, one per group of GS
+  // lanes, instead of one after the other on 64 lanes of which m / 2 are busy -- at MEMBER = 100 (14 iterations, four columns per
+  // wave) the recurrence below was a third of this kernel's instructions.  The wave-wide shifts stay: at a group's first and
+  // last row the off-diagonal coefficient that meets the neighbouring group's value is zero.
   constexpr int NC = 16 / NWV;
+  constexpr int GS = 64 / NC;
+#ifndef KRYLOV_PACKED
+#define KRYLOV_PACKED 1
+#endif
+  const bool packed = KRYLOV_PACKED && NC > 1 && iters <= 2 * GS;   // (wave-uniform)
+  const int ncl = packed ? 1 : NC;                                   // passes over the columns
+  const int rl = packed ? (lane & (GS - 1)) : lane;                  // row pair of this lane
   double a0[NC], a1[NC], bL[NC], bM[NC], bR[NC];
   int mb[NC];
   double gmax = 0.0;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    const int b = 2 + wv + NWV * c;
+    const int b = 2 + wv + NWV * (packed ? lane / GS : c);
     mb[c] = 0;
     a0[c] = a1[c] = bL[c] = bM[c] = bR[c] = 0.0;
-    if (b < nbr) {                                          // (wave-uniform)
-      mb[c] = __shfl(mj, b, 64);                            // lane b (rq = 0) carries column b's count
+    const int mcol = __shfl(mj, b < nbr ? b : 0, 64);      // lane b (rq = 0) carries column b's count
+    if (c < ncl && b < nbr) {                               // (wave-uniform unless packed)
+      mb[c] = mcol;
       const int m = mb[c];
       auto diag = [&](int jj) -> double {
         if (jj >= m) return 0.0;
@@ -341,11 +353,11 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
         if (jj < 0 || jj + 1 >= m) return 0.0;
         return sqrt(L.hb[(jj + 1) * 16 + b]) / L.ha[jj * 16 + b];
       };
-      a0[c] = diag(2 * lane);
-      a1[c] = diag(2 * lane + 1);
-      bL[c] = offd(2 * lane - 1);
-      bM[c] = offd(2 * lane);
-      bR[c] = offd(2 * lane + 1);
+      a0[c] = diag(2 * rl);
+      a1[c] = diag(2 * rl + 1);
+      bL[c] = offd(2 * rl - 1);
+      bM[c] = offd(2 * rl);
+      bR[c] = offd(2 * rl + 1);
       gmax = fmax(gmax, fmax(a0[c] + bL[c] + bM[c], a1[c] + bM[c] + bR[c]));
     }
   }
@@ -395,13 +407,13 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
   // (c) y = sum_d c_d T_d(T~) e_1, T~ = (T_m - mid) / half; then the combination coefficients y_j (-1)^j |t| / |r_j|
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    const int b = 2 + wv + NWV * c;
-    if (b < nbr) {
+    const int b = 2 + wv + NWV * (packed ? lane / GS : c);
+    if (c < ncl && b < nbr) {
       const int m = mb[c];
       const double d0 = (a0[c] - mid) * inv, d1 = (a1[c] - mid) * inv;
       const double eL = bL[c] * inv, eM = bM[c] * inv, eR = bR[c] * inv;
-      const bool r0 = 2 * lane < m, r1 = 2 * lane + 1 < m;
-      double u0 = lane == 0 && m > 0 ? 1.0 : 0.0, u1 = 0.0;   // T_0 e_1
+      const bool r0 = 2 * rl < m, r1 = 2 * rl + 1 < m;
+      double u0 = rl == 0 && m > 0 ? 1.0 : 0.0, u1 = 0.0;     // T_0 e_1
       double y0 = L.cT[0] * u0, y1 = 0.0;
       // T_1
       double nL = dpp_shift0<0x138>(u1), nR = dpp_shift0<0x130>(u0);
@@ -424,9 +436,9 @@ __device__ __forceinline__ bool krylov_point(const Slab& sl, const KryLds& L, co
         y1 = fma(cdv, v1, y1);
       }
       const double t2 = L.hr[b];                             // rho_0 = |t|^2
-      const double rj0 = r0 ? L.hr[(2 * lane) * 16 + b] : 1.0, rj1 = r1 ? L.hr[(2 * lane + 1) * 16 + b] : 1.0;
-      if (2 * lane < iters) L.hr[(2 * lane) * 16 + b] = r0 ? y0 * sqrt(t2 / rj0) : 0.0;
-      if (2 * lane + 1 < iters) L.hr[(2 * lane + 1) * 16 + b] = r1 ? -y1 * sqrt(t2 / rj1) : 0.0;
+      const double rj0 = r0 ? L.hr[(2 * rl) * 16 + b] : 1.0, rj1 = r1 ? L.hr[(2 * rl + 1) * 16 + b] : 1.0;
+      if (2 * rl < iters) L.hr[(2 * rl) * 16 + b] = r0 ? y0 * sqrt(t2 / rj0) : 0.0;
+      if (2 * rl + 1 < iters) L.hr[(2 * rl + 1) * 16 + b] = r1 ? -y1 * sqrt(t2 / rj1) : 0.0;
     }
   }
   __syncthreads();
