@@ -351,9 +351,21 @@ int launch_staged(letkf_ctx* c, letkf::PointArgs& a) {
   if (nb > want) nb = want;
   if (nb < 1) nb = 1;
   if (nb > a.npts) nb = a.npts;
-  {   // equal batches (a last batch of a few points would leave the chip idle for a whole eigen-solve)
+  {   // equal batches (a last batch of a few points would leave the chip idle for a whole eigen-solve) ...
     const long nbat = (a.npts + nb - 1) / nb;
+    const long cap = nb;
     nb = (a.npts + nbat - 1) / nbat;
+#ifndef STAGED_BATCH_ROUND
+#define STAGED_BATCH_ROUND 1
+#endif
+    // ... of whole rounds of workgroups: the stages run 2 (Gram, eigen-free stage at small orders) to 4 (apply) workgroups per CU,
+    // and a batch that is no multiple of 2 x #CU ends every one of its kernels on a partly filled round (27648 points in 7
+    // batches of 3950 = 7.7 rounds of 512: r4, MEMBER = 100)
+    if (STAGED_BATCH_ROUND) {
+      const long q = 2L * c->num_cu;
+      const long up = (nb + q - 1) / q * q;
+      if (up <= cap) nb = up;
+    }
   }
   const size_t slab_bytes = (size_t)nb * (size_t)wpp * sizeof(double);
   const size_t need = slab_bytes + (size_t)nb * 4 * sizeof(int) + 256;
