@@ -1355,7 +1355,34 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
           }
         }
         psync<NW>();
-        if (lane < 16 * NBLK) {
+        if constexpr (NW == 1) {
+          // Every lane reads (the lanes past the last block a copy of its last row; their g is zeroed below, racc / rdacc keep
+          // their value through a select): NOT `if (lane < 16 * NBLK)`.  Behind the join of that branch hipcc (ROCm 7.2) put the
+          // copies of a live-range split IN FRONT of the instruction that re-enables the lanes which skipped it -- found in
+          // letkf_wave_kernel<16, 11, true> and <20, 0, true>: the run scheduler's `pend` saved for lanes 0..31 only and restored
+          // for all 64, lanes 32..63 walked on into points that were not theirs with a stale slice (memory fault).  tools/
+          // isa_exec_audit.py looks for that pattern in every unit's ISA; the Makefile runs it on every build.
+          const int lrow = lane < 16 * NBLK ? lane : 16 * NBLK - 1;
+          const bool mine = lane < 16 * NBLK;
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            if (16 * I + e < KR) {
+              const double2 v2 = *reinterpret_cast<const double2*>(&abuf[lrow * LDA + e]);
+              g[16 * I + e] = v2.x;
+              g[16 * I + e + 1] = v2.y;
+            }
+          }
+          if constexpr (!STRIP) {
+            if ((k >> 4) == I) {
+              const double t = abuf[lrow * LDA + (k & 15)];
+              racc = mine ? t : racc;
+            }
+            if (((k + 1) >> 4) == I) {
+              const double t = abuf[lrow * LDA + ((k + 1) & 15)];
+              rdacc = mine ? t : rdacc;
+            }
+          }
+        } else if (lane < 16 * NBLK) {
 #pragma unroll
           for (int e = 0; e < 16; e += 2) {
             if (16 * I + e < KR) {

@@ -57,6 +57,13 @@ def test_core_batch(k, nobs, nb, wloc, iu, det):
     assert int(nsweep.max()) < 30
 
 
+@pytest.mark.parametrize("k", [2, 3, 15, 16, 17, 21, 32, 33, 47, 48, 49, 51, 62, 63, 65, 80, 81, 99])
+def test_core_batch_ensemble_sizes_at_the_instantiation_bounds(k):
+    """every KR instantiation of the register kernel at its smallest and largest ensemble size, T / Pa / w-bar out (the KKOUT
+    twins: r4 found a hipcc defect in two of them, DESIGN.md section 8 -- sizes the parametrisation above never launched)"""
+    test_core_batch(k, 44, 7, True, True, True)
+
+
 def test_core_batch_without_transm_folds_wbar():
     """transm absent -> w-bar is added to every column of trans (common/common_letkf.f90:218-226)."""
     from _gpu import ctx, dev

@@ -292,3 +292,24 @@ def test_das_points_other_variable_counts(k, nv, name):
     compare_anal(c, ref, got, k, nv, bool(cfg.get("det_run", 0)))
     assert np.abs(infl - ref["infl"]).max() <= 1e-12
     assert ("letkf_point_kernel" in ctx().last_path()) == (nv + 2 > 16), ctx().last_path()
+
+
+@pytest.mark.parametrize("k", [17, 18, 19, 49, 51, 62, 16, 21])
+def test_das_points_ensemble_sizes_inside_an_instantiation(k):
+    """Ensemble sizes that do not fill their instantiation of the wave kernel (KR = 20 serves 17 .. 20, KR = 50 serves 49 and 50,
+    KR = 64 serves 51 .. 62): the narrow last block of the Gram -- on the vector ALU at KR = 20 / 50 (r4) -- carries fewer members
+    than the instantiation allows for, the departure columns sit elsewhere.  DET_RUN + adaptive inflation, against the oracle; and
+    the letkf_core batch entry (mode 1: dense hdxb) for the same sizes through its golden-style check."""
+    cfg = CONFIGS["rtps_adaptive_det"]
+    c, ref, got, infl, status, _, _ = run_both(k, 11, 36, 500, 120, seed=900 + k, cfg=cfg)
+    assert (status == 0).all(), status
+    compare_anal(c, ref, got, k, 11, True)
+    assert np.abs(infl - ref["infl"]).max() <= 1e-12
+    # the same with the k x k outputs requested (the KKOUT instantiation): T and w-bar against the oracle
+    c, ref, got, infl, status, trans, transm = run_both(k, 11, 12, 300, 90, seed=950 + k, cfg=CONFIGS["rtps"], want_trans=True)
+    assert (status == 0).all(), status
+    t = trans.cpu().numpy()
+    for p in range(12):
+        e = ref["trans"][p]
+        assert np.abs(t[p] - e).max() <= 1e-11 * np.abs(e).max(), (p, np.abs(t[p] - e).max())
+    assert np.abs(transm.cpu().numpy() - ref["transm"]).max() <= 1e-11 * max(np.abs(ref["transm"]).max(), 1e-300)
