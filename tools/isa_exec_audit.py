@@ -12,7 +12,9 @@ import re
 import sys
 
 LABEL = re.compile(r"^([.\w$]+):")
-RESTORE = re.compile(r"^\s+s_or_b64 exec, exec, ")
+# the exec restores of a join block: after an `if` (s_or_b64 exec, exec, saved) and in front of an `else` (s_or_saveexec_b64 sN, sM);
+# `s_or_saveexec_b64 sN, -1` is whole-wave mode around an SGPR-spill register, not a join
+RESTORE = re.compile(r"^\s+(s_or_b64 exec, exec, |s_or_saveexec_b64 s\[\d+:\d+\], s\[)")
 EXEC_FREE = ("v_readlane_b32", "v_writelane_b32", "v_readfirstlane_b32")
 
 
