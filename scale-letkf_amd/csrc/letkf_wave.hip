@@ -532,7 +532,22 @@ __host__ __device__ constexpr int wave_kmin(int KR, int NW) {
                  : (KR == 64 ? 63 : KR == 80 ? 65 : KR == 100 ? 81 : 1);
 }
 
-// per-wave LDS slice (doubles); mirrored by wave_lds_doubles() in letkf_api.hip
+// Small ensembles (KR <= 20: C1, the k = 20 workloads) are issue- and latency-bound with 20 of 64 lanes carrying a column (one wave
+// per SIMD -> two: x 1.47 on C2-k20, measured with padded LDS), so their slice is cut to what such a point needs -- the Jacobi's
+// conversion chunk is KR rows (not 24), the apply phase's output buffer 32 rows (not 64): 12.5 KB per wave, 50 KB per workgroup,
+// room for THREE workgroups per CU.  Measured (r4, A/B in one gpurun call, -DLETKF_SMALL_OCC=3 against 2): the register budget
+// of three waves per SIMD (168) costs this kernel 464 B/lane of scratch instead of 136 -- C2-k20 -6 %, C1 +4 %.  The default
+// stays at two; the slice stays small.
+__host__ __device__ constexpr bool wave_small(int KR, int NW) { return NW == 1 && KR <= 20; }
+__host__ __device__ constexpr int wave_base_doubles(int KR, int NW) { return wave_small(KR, NW) ? 1280 : 1536 * NW; }
+__host__ __device__ constexpr int wave_jacobi_rc(int KR, int NW) { return wave_small(KR, NW) ? KR : 24; }   // rows per conversion chunk
+__host__ __device__ constexpr int wave_ob_rows(int KR) { return KR <= 20 ? 32 : 64; }                        // rows of the MAPPLY output buffer
+#ifndef LETKF_SMALL_OCC
+#define LETKF_SMALL_OCC 2
+#endif
+__host__ __device__ constexpr int wave_occupancy(int KR, int NW) { return NW == 1 ? (wave_small(KR, NW) ? LETKF_SMALL_OCC : 2) : 1; }
+
+// per-wave LDS slice (doubles)
 __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
   const int nb = nv + 2;
   int tile = kTnW * 64;                       // obs tile, also reused as vbuf (KR * kVld) and kk-output C chunk
@@ -542,11 +557,11 @@ __host__ __device__ inline int wave_slice_doubles(int KR, int nv, int NW) {
   if (kChunk * KR > bmat) bmat = kChunk * KR;
   const int cb = kChunk * ((nb + 1) & ~1);
   const int small = 3 * kTnW + 8 * nv + 16;
-  if (tile + bmat < 1536 * NW) bmat = 1536 * NW - tile;   // Gram transposition buffer abuf[64 NW][18] and the Jacobi
-                                                         // exchange slots (64 NW * 24 doubles) span tile + bmat
+  if (tile + bmat < wave_base_doubles(KR, NW)) bmat = wave_base_doubles(KR, NW) - tile;   // Gram transposition buffer abuf[64 NW][18] and
+                                                         // the Jacobi exchange slots (64 NW * RC doubles) span tile + bmat
   int tot = tile + bmat + cb + small + 8;                // + 4 doubles of reduction scratch (two-wave points)
   if (NW == 1 && KR <= 50 && tot < (KR - 1) * KR + 64) tot = (KR - 1) * KR + 64;   // A whole: warm_start_product_mfma
-  if (NW == 1 && KR < 32 && tot < 32 * KR + 64 * ((KR + 3) / 4) + 128 + 1024) tot = 32 * KR + 64 * ((KR + 3) / 4) + 128 + 1024;   // + [64][16] output buffer
+  if (NW == 1 && KR < 32 && tot < 32 * KR + 64 * ((KR + 3) / 4) + 128 + 16 * wave_ob_rows(KR)) tot = 32 * KR + 64 * ((KR + 3) / 4) + 128 + 16 * wave_ob_rows(KR);   // + [rows][16] output buffer
   if (NW == 1 && KR <= 50 && tot < 32 * KR + 64 * ((KR + 3) / 4) + 128)               // half of V + padded B + spectra: the apply phase on the matrix cores
     tot = 32 * KR + 64 * ((KR + 3) / 4) + 128;
   return (tot + 1) & ~1;
@@ -613,7 +628,7 @@ __device__ __forceinline__ bool letkf_check_fail(unsigned long long* rec, const 
 #endif
 
 template <int KR, int NV, bool KKOUT, int NW, int FUSED>
-__global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER_SIMD(KR, NW)) ? 2 : 1) letkf_wave_kernel(const PointArgs A) {
+__global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? wave_occupancy(KR, NW) : (LETKF_TWO_PER_SIMD(KR, NW) ? 2 : 1)) letkf_wave_kernel(const PointArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NB = NV + 2;
   constexpr int NBP = (NB + 1) & ~1;
@@ -631,7 +646,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
   if (KR * kVld > tile_sz) tile_sz = KR * kVld;
   int bmat_sz = NBP * KR;
   if (kChunk * KR > bmat_sz) bmat_sz = kChunk * KR;
-  if (tile_sz + bmat_sz < 1536 * NW) bmat_sz = 1536 * NW - tile_sz;
+  if (tile_sz + bmat_sz < wave_base_doubles(KR, NW)) bmat_sz = wave_base_doubles(KR, NW) - tile_sz;
   double* vbuf = slice;                       // [KR][kVld]          (after the Gram phase)
   double* bmat = slice + tile_sz;             // [KR][NBP]
   double* cbuf = bmat + bmat_sz;              // [kChunk][NBP]
@@ -944,7 +959,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
       // its load pipeline, as much SIMD time as a Jacobi sweep per point:
       //   stage: lane i -> obs i: row base, sqrt(w), sqrt(w) dep, sqrt(w) dep_det into LDS (4 doubles per obs)
       //   MFMA : per 4-obs step 2 ds_read_b128 + NBLK row loads (three steps in flight) + NBLK multiplies
-      constexpr int kSC = 256;                                 // obs per batch (4 kSC doubles <= 1536 NW of the slice)
+      constexpr int kSC = 256;                                 // obs per batch (4 kSC doubles <= wave_base_doubles of the slice)
       double* stg = slice;
       const bool mode0 = A.mode != 1;                          // rows come from the obs table (member-fastest)
       const double* ybase = mode0 ? A.ensval : A.hdxb;
@@ -1431,7 +1446,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
         }
       }
       PROF_MARK(3)
-      sweeps = jacobi_split<KR, NW, 24, LETKF_EARLY_NW(KR, NW), LETKF_INPLACE_NW(KR, NW)>(g, k, A.max_sweep, slice, nullptr, &jconv);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
+      sweeps = jacobi_split<KR, NW, wave_jacobi_rc(KR, NW), LETKF_EARLY_NW(KR, NW), LETKF_INPLACE_NW(KR, NW)>(g, k, A.max_sweep, slice, nullptr, &jconv);   // exchange buffer: 64*10 + 64*4 doubles of the tile+bmat region
       // per-lane values that were spilled around the eigensolve come back HERE, in one batch: reloaded lazily, each
       // scratch load sits behind the 50 workspace stores below and its s_waitcnt vmcnt(0) waits for all of them
       asm volatile("" : "+v"(racc), "+v"(rdacc), "+v"(moff));
@@ -1673,14 +1688,16 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
       }
       // Out tiles -> lane m holds row m: register `reg` of tile I, lane (q, c) is Out[16 reg + 4 q + I][c]
       wave_lds_sync();
-      double* ob = slice + kObOff;             // [64][16], on top of the V half (behind B and the spectra when the half is smaller)
+      double* ob = slice + kObOff;             // [64][16] ([32][16] for KR <= 20: rows >= KR are never read), on top of the V half (behind B and the spectra when the half is smaller)
+      constexpr int OBR = wave_ob_rows(KR);
 #pragma unroll
       for (int I = 0; I < 4; ++I)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) ob[(16 * reg + 4 * q + I) * 16 + c] = accO[I][reg];
+        for (int reg = 0; reg < 4; ++reg)
+          if (16 * reg < OBR) ob[(16 * reg + 4 * q + I) * 16 + c] = accO[I][reg];
       wave_lds_sync();
       {
-        const double* row = ob + lane * 16;
+        const double* row = ob + (OBR == 64 || lane < OBR ? lane : OBR - 1) * 16;
 #pragma unroll
         for (int b = 0; b < NB; b += 2) {
           const double2 o2 = *reinterpret_cast<const double2*>(&row[b]);
@@ -1879,7 +1896,11 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, (NW == 1 || LETKF_TWO_PER
 // ------------------------------------------------------------------ host launcher
 template <int KR, int NV, bool KKOUT, int NW, int FUSED = 0>
 static hipError_t launch_wave(const PointArgs& a, int num_cu, hipStream_t st) {
+#ifdef LETKF_LDS_PAD   // A/B knob (make VARIANT=...): extra LDS per workgroup -- what does a workgroup less per CU cost?
+  const size_t lds = (size_t)(NW == 1 ? 4 : 1) * wave_slice_doubles(KR, NV, NW) * sizeof(double) + LETKF_LDS_PAD;
+#else
   const size_t lds = (size_t)(NW == 1 ? 4 : 1) * wave_slice_doubles(KR, NV, NW) * sizeof(double);
+#endif
   if (a.k < wave_kmin(KR, NW) || a.k > KR) return hipErrorInvalidValue;   // the Gram assumes its full member blocks
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_wave_kernel<KR, NV, KKOUT, NW, FUSED>),
@@ -1916,7 +1937,7 @@ static hipError_t launch_wave(const PointArgs& a, int num_cu, hipStream_t st) {
   }
   PointArgs b = a;
   if (a.sched) {
-    sched_make_plan(b.plan, a.npts, a.warm_stride, a.run_len, grid, NW == 1 ? 4 : 1, NW == 1 ? 256 : 64);
+    sched_make_plan(b.plan, a.npts, a.warm_stride, a.run_len, grid, NW == 1 ? 4 : 1, NW == 1 ? 128 * wave_occupancy(KR, NW) : 64);   // wave-slots in flight per XCD (32 CUs)
     // the counters start at zero -- unless every unit is given out by position (a small batch): then nothing is drawn,
     // and whatever non-negative counts an earlier launch left behind read as "nothing left"
     bool draws = false;
