@@ -25,6 +25,9 @@ CONFIGS = {
                          ztop=18000.0, seed=20240611),
     "C2-mini-k20": dict(nx=48, ny=48, nz=12, k=20, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
                         ztop=18000.0, seed=20240612),
+    # the other register-kernel instantiations (KR = 16, 32, 48, 64) on a smaller grid: tests of the list-free and fused routes
+    **{f"C2-tiny-k{k_}": dict(nx=24, ny=20, nz=7, k=k_, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=3200.0, err=3.0,
+                             ztop=18000.0, seed=20240620 + k_) for k_ in (16, 17, 30, 40, 51, 60)},
     # profiling stand-in: same grid, no observation in range (isolates state I/O + transform)
     "C2-mini-noobs": dict(nx=48, ny=48, nz=12, k=50, dx=1000.0, hloc=40.0, vloc=20.0, spacing=3200.0, err=3.0,
                           ztop=18000.0, seed=20240610),

@@ -90,6 +90,10 @@ int letkf_ctx_synchronize(letkf_ctx *ctx);
  * 1: whatever exceeds the batch budget is freed when the entry returns (a host model that needs the memory between analyses
  * pays the allocation again every call: ~1.7 s for 64 GB). */
 #define LETKF_OPT_RING_RELEASE 5
+/* LETKF_OPT_SMALL_K_TRIO (default 1): loop-body calls with lists, k <= 20, nv = 11 and no per-point matrix outputs run three grid
+ * points per wavefront (csrc/letkf_trio.hip: one eigensolve for the three, cold starts); 0: the one-point register kernel with
+ * its warm-started runs, as for every other ensemble size.  Same analysis to rounding either way. */
+#define LETKF_OPT_SMALL_K_TRIO 6
 int letkf_ctx_set_option(letkf_ctx *ctx, int option, int value);
 
 /*---------------------------------------------------------------------------

@@ -205,6 +205,7 @@ class Context:
     OPT_LIMITED_RINGS = 3      # LETKF_OPT_LIMITED_RINGS
     OPT_RING_BATCH_MB = 4      # LETKF_OPT_RING_BATCH_MB
     OPT_RING_RELEASE = 5       # LETKF_OPT_RING_RELEASE
+    OPT_SMALL_K_TRIO = 6       # LETKF_OPT_SMALL_K_TRIO
 
     def set_option(self, option, value):
         self._check(self._l.letkf_ctx_set_option(self._c, C.c_int(option), C.c_int(value)))

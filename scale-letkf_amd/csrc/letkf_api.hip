@@ -79,6 +79,7 @@ struct letkf_ctx {
   std::string last_path;      // kernels the last loop-body / letkf_core launch went through (bench.py reports it)
   bool timing = false;
   bool staged_poly = true;    // LETKF_OPT_STAGED_POLY
+  bool trio = true;           // LETKF_OPT_SMALL_K_TRIO
   int col_survivors = 2;      // LETKF_OPT_COLUMN_SURVIVORS: 0 never, 1 wherever the one-wave kernel serves the call, 2 where the lists would not fit
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 };
@@ -293,9 +294,14 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, int warm_run = 0, long warm_stride
       HIP_TRY(letkf::launch_trivial_points(a, c->stream));
       a.skip_trivial = 1;
     }
+    if (c->trio && letkf::trio_kernel_supports(a)) {
+      HIP_TRY(letkf::launch_trio_kernel(a, c->num_cu, c->stream));
+      c->last_path = std::string("letkf_trio_kernel<KR=") + (a.k <= 16 ? "16" : "20") + ">";
+    } else {
     HIP_TRY(letkf::launch_wave_kernel(a, c->num_cu, c->stream));
     c->last_path = "letkf_wave_kernel<KR=" + std::to_string(letkf::wave_kernel_kr(a.k)) + ",NV=" + std::to_string(a.nv) +
                    ",NW=" + (a.k <= 62 ? "1" : "2") + (a.mode == 2 ? ",FUSED" : a.mode == 3 ? ",FUSED: column survivors" : "") + ">";
+    }
 #ifdef LETKF_WAVE_PROF
     {
       unsigned long long h[26];
@@ -502,6 +508,7 @@ int letkf_ctx_set_option(letkf_ctx* c, int option, int value) {
       c->ring_batch_mb = value;
       return LETKF_OK;
     case LETKF_OPT_RING_RELEASE: c->ring_release = value != 0; return LETKF_OK;
+    case LETKF_OPT_SMALL_K_TRIO: c->trio = value != 0; return LETKF_OK;
     case LETKF_OPT_LIMITED_RINGS:
       if (value < 0 || value > 2) return fail(LETKF_E_INVALID, "LETKF_OPT_LIMITED_RINGS: 0, 1 or 2");
       c->limited_rings = value;

@@ -189,6 +189,9 @@ int wave_kernel_kr(int k);   // rows of the instantiation that serves k
 void wave_launch_shape(int k, int mode, long npts, int num_cu, int run_req, long stride, int* run_len, int* grid,
                        size_t* ws_bytes);
 hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st);
+// three points per wave for k <= 20 (letkf_trio.hip)
+bool trio_kernel_supports(const PointArgs& a);
+hipError_t launch_trio_kernel(const PointArgs& a, int num_cu, hipStream_t st);
 int sched_plan_check(long npts, long stride, int run_len, int grid, int ppw, int resident_per_xcd);
 bool trivial_pass_supports(const PointArgs& a);
 hipError_t launch_trivial_points(const PointArgs& a, hipStream_t st);

@@ -195,13 +195,15 @@ __device__ __forceinline__ int sched_next(const SchedPlan& P, unsigned* cnt, con
 
 // host: the plan for a grid of `grid` workgroups with ppw wave-slots each, `resident` wave-slots in flight per XCD
 static void sched_make_plan(SchedPlan& P, const long npts, const long stride, const int run_len, const int grid, const int ppw,
-                            const int resident_per_xcd) {
+                            const int resident_per_xcd, const int ub_of = 1) {
   const long S = stride > 1 ? stride : 1, rl = run_len > 1 ? run_len : 1;
   const long nruns = S * ((npts / S + rl - 1) / rl);
   // short runs are bundled (a draw should cover ~16 points), as long as that leaves every wave-slot of the grid four units
   int ub = rl >= 16 ? 1 : (int)((16 + rl - 1) / rl);
   const long most = nruns / (4L * grid * ppw);
   if (ub > most) ub = most < 1 ? 1 : (int)most;
+  // ub_of > 1 (letkf_trio.hip: three runs are walked in step): whole multiples of it
+  if (ub_of > 1) ub = (ub + ub_of - 1) / ub_of * ub_of;
   const long n = (nruns + ub - 1) / ub;
   // whole runs of 8 points or more may be quartered at the end of a range: as many as the XCD has wave-slots in flight
   const int fs = (ub == 1 && rl >= 8) ? ((long)grid * ppw / 8 < resident_per_xcd ? (int)((long)grid * ppw / 8) : resident_per_xcd) : 0;
@@ -497,7 +499,7 @@ __device__ __forceinline__ void warm_start_product_mfma(double (&g)[KR], const d
 
 }  // namespace
 
-#ifndef LETKF_WAVE_UNIT2
+#if !defined(LETKF_WAVE_UNIT2) && !defined(LETKF_WAVE_UNIT3)
 // include/letkf_amd.h, letkf_sched_plan_check: every run exactly once (whole or as four quarters)?
 int sched_plan_check(long npts, long stride, int run_len, int grid, int ppw, int resident_per_xcd) {
   if (npts < 0 || grid < 1 || ppw < 1 || run_len < 1) return -1;
@@ -1951,6 +1953,7 @@ static hipError_t launch_wave(const PointArgs& a, int num_cu, hipStream_t st) {
   return hipGetLastError();
 }
 
+#ifndef LETKF_WAVE_UNIT3   // (letkf_trio.hip includes this file for its device helpers and the run scheduler only)
 #ifndef LETKF_WAVE_UNIT2
 bool wave_kernel_supports(int k, int nv, int mode) {
   // one wave per point up to k = 62 (k + 2 augmented Gram columns in 64 lanes); two waves for 63..100 (at k >= 65 the
@@ -2041,5 +2044,6 @@ hipError_t launch_wave_kernel_two(const PointArgs& a, int num_cu, hipStream_t st
 }
 #endif
 #undef LETKF_WAVE_CASE
+#endif   // LETKF_WAVE_UNIT3
 
 }  // namespace letkf

@@ -182,7 +182,7 @@ MODULE letkf_amd_api
     FUNCTION letkf_ctx_set_option(ctx, option, value) BIND(C, name='letkf_ctx_set_option') RESULT(rc)
       IMPORT :: c_int, c_ptr
       TYPE(c_ptr), VALUE :: ctx
-      INTEGER(c_int), VALUE :: option, value      ! LETKF_OPT_STAGED_POLY = 1, LETKF_OPT_COLUMN_SURVIVORS = 2, LETKF_OPT_LIMITED_RINGS = 3, LETKF_OPT_RING_BATCH_MB = 4, LETKF_OPT_RING_RELEASE = 5 (include/letkf_amd.h)
+      INTEGER(c_int), VALUE :: option, value      ! LETKF_OPT_STAGED_POLY = 1, LETKF_OPT_COLUMN_SURVIVORS = 2, LETKF_OPT_LIMITED_RINGS = 3, LETKF_OPT_RING_BATCH_MB = 4, LETKF_OPT_RING_RELEASE = 5, LETKF_OPT_SMALL_K_TRIO = 6 (include/letkf_amd.h)
       INTEGER(c_int) :: rc
     END FUNCTION
     FUNCTION letkf_ctx_synchronize(ctx) BIND(C, name='letkf_ctx_synchronize') RESULT(rc)

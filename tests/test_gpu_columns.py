@@ -62,7 +62,7 @@ def test_column_pipeline_equals_search_plus_loop_body(name, list_mb):
         assert bool(torch.isnan(g1[:, k]).all())              # the mean slot is not the loop body's to write
 
 
-@pytest.mark.parametrize("name", ["C2-mini", "C2-mini-disc", "C2-mini-k20"])
+@pytest.mark.parametrize("name", ["C2-mini", "C2-mini-disc", "C2-mini-k20", "C2-tiny-k16", "C2-tiny-k17", "C2-tiny-k30", "C2-tiny-k40", "C2-tiny-k51", "C2-tiny-k60"])
 def test_list_free_route_equals_the_lists_bit_for_bit(name):
     """Same runs (up whole columns), same weights (search_dev::column_vertical_cal is the column search's arithmetic), same order
     of the local observations: the analysis of the list-free route IS the list route's, to the last bit."""
@@ -81,8 +81,12 @@ def test_list_free_route_equals_the_lists_bit_for_bit(name):
     off, idx, rd, rl = cx.obs_search_columns(t_s, nij1, nlev, rig, rjg, pts[2], pts[3])
     a0 = torch.full_like(w["gues"], float("nan"))
     i0 = torch.ones(npts * nv, dtype=torch.float64, device=dev)
-    cx.das_points(k, nv, off, idx, rd, rl, ens, w["kld"], dep, i0, w["gues"], a0, 1, npts, npts * nens, relax_alpha_spread=0.95,
-                  warm_stride=nij1)
+    cx.set_option(cx.OPT_SMALL_K_TRIO, 0)        # (k <= 20: the list route of the SAME kernel, not three points per wave)
+    try:
+        cx.das_points(k, nv, off, idx, rd, rl, ens, w["kld"], dep, i0, w["gues"], a0, 1, npts, npts * nens, relax_alpha_spread=0.95,
+                      warm_stride=nij1)
+    finally:
+        cx.set_option(cx.OPT_SMALL_K_TRIO, 1)
     a1 = torch.full_like(w["gues"], float("nan"))
     i1 = torch.ones(npts * nv, dtype=torch.float64, device=dev)
     cx.set_option(cx.OPT_COLUMN_SURVIVORS, 1)

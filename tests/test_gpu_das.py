@@ -77,6 +77,27 @@ def test_das_points_vs_oracle(name, k, npts, nobs_tot, n_mean):
     assert np.abs(infl - ref["infl"]).max() <= 1e-12
 
 
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("k,npts,nobs_tot,n_mean,warm_run", [(20, 150, 500, 70, 0), (19, 131, 500, 60, 7), (16, 100, 400, 50, 5), (9, 77, 300, 30, 4), (2, 50, 100, 9, 3)])
+def test_das_points_small_ensembles_on_both_kernels(name, k, npts, nobs_tot, n_mean, warm_run):
+    """k <= 20: three points per wave (letkf_trio.hip, the default: one eigensolve for three neighbouring runs, warm starts from
+    the park; k = 19, 20 fill all 32 slots of the line, k = 9 and 2 a few) and the one-point register kernel
+    (LETKF_OPT_SMALL_K_TRIO = 0), both against the oracle, every switch; runs of several lengths, batches that are not a multiple
+    of three runs, points without observations and beta = 0 points inside the runs."""
+    from _gpu import ctx
+    cfg = CONFIGS[name]
+    for trio in (1, 0):
+        ctx().set_option(ctx().OPT_SMALL_K_TRIO, trio)
+        try:
+            c, ref, got, infl, status, _, _ = run_both(k, 11, npts, nobs_tot, n_mean, seed=500 + k, cfg=cfg, warm_run=warm_run)
+            assert ctx().last_path().startswith("letkf_trio_kernel" if trio else "letkf_wave_kernel"), ctx().last_path()
+        finally:
+            ctx().set_option(ctx().OPT_SMALL_K_TRIO, 1)
+        assert (status == 0).all(), status
+        compare_anal(c, ref, got, k, 11, bool(cfg.get("det_run", 0)))
+        assert np.abs(infl - ref["infl"]).max() <= 1e-12
+
+
 def test_das_points_weights_match():
     """the optional per-point trans / transm outputs equal what letkf_core returns inside the oracle"""
     cfg = CONFIGS["rtps"]

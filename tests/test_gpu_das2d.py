@@ -133,7 +133,7 @@ def test_level1_with_2d_variables_fast_path(name, k):
     das_call(cfg, k, 11, c, lists[1], i2, g2, a2, nij1, det, 0b0011, q_on=False)    # class 1: representative + variable 12
     das_call(cfg, k, 11, c, lists[3], i2, g2, a2, nij1, det, 0b1100, q_on=False)    # class 3: variables 13, 14
     # (k = 100: the loop body without k x k outputs takes the staged path's eigen-free route since r2, tests/test_gpu_poly.py)
-    assert ctx().last_path().startswith("letkf_wave_kernel" if k < 63 else "staged")
+    assert ctx().last_path().startswith("letkf_trio_kernel" if k <= 20 else "letkf_wave_kernel" if k < 63 else "staged")
     # ---- the 3-D call, one per class
     g3, a3, i3 = dev(gues3), torch.full((gues3.size,), float("nan"), dtype=torch.float64, device="cuda"), dev(work3d)
     for cl in (1, 2):

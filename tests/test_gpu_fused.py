@@ -1,6 +1,6 @@
 """obs_local fused into the loop body (letkf_das_points_fused_dev) against the two-step path it replaces
-(letkf_obs_search_dev lists -> letkf_das_points_dev): same candidate order, same 4-obs MFMA grouping, so the analysis,
-inflation and status must be BIT-identical (points without observations: equal to rounding, they take different
+(letkf_obs_search_dev lists -> letkf_das_points_dev): same candidate order, same 4-obs MFMA grouping, so the analysis
+and status must be BIT-identical, the adaptive inflation to the last place or one unit of it (points without observations: equal to rounding, they take different
 kernels), and nobs_out must be the list lengths; the two-step path itself is checked
 against the oracle elsewhere (test_gpu_search.py, test_gpu_das.py)."""
 import numpy as np
@@ -25,7 +25,11 @@ def _state(k, nv, npts, det, seed):
 @pytest.mark.parametrize("k,det,cfg", [(50, False, dict(relax_alpha_spread=0.95)),
                                        (20, True, dict(relax_alpha_spread=0.9, infl_adaptive=1, relax_to_inflated_prior=1)),
                                        (33, True, dict(relax_alpha=0.6, q_update_top=6.0e4)),
-                                       (62, False, dict())])
+                                       (62, False, dict()),
+                                       (16, True, dict(relax_alpha_spread=0.95, infl_adaptive=1)),
+                                       (17, False, dict(relax_alpha_spread=0.95)),
+                                       (30, True, dict(relax_alpha_spread=0.9)),
+                                       (51, False, dict(relax_alpha=0.5))])
 def test_fused_search_equals_search_then_solve(k, det, cfg):
     from _gpu import ctx, dev
     c = ctx()
@@ -53,7 +57,11 @@ def test_fused_search_equals_search_then_solve(k, det, cfg):
         nob = torch.full((npts,), -1, dtype=torch.int32, device="cuda")
         kw = dict(beta=dev(beta), det_run=det, status=st, iv_p=4, iv_q_first=5, iv_q_last=10, warm_run=5, **cfg)
         if mode == "lists":
-            c.das_points(k, nv, off, idx, rd, rl, dev(ensval), kld, dev(dep), infl, dev(gues), anal, sp, sm, sv, **kw)
+            c.set_option(c.OPT_SMALL_K_TRIO, 0)  # (k <= 20: the list route of the SAME kernel, not three points per wave)
+            try:
+                c.das_points(k, nv, off, idx, rd, rl, dev(ensval), kld, dev(dep), infl, dev(gues), anal, sp, sm, sv, **kw)
+            finally:
+                c.set_option(c.OPT_SMALL_K_TRIO, 1)
         else:
             c.das_points(k, nv, None, None, None, None, dev(ensval), kld, dev(dep), infl, dev(gues), anal, sp, sm, sv,
                          fused=(t, *pts), nobs_out=nob, **kw)
@@ -76,7 +84,10 @@ def test_fused_search_equals_search_then_solve(k, det, cfg):
     if int(empty.sum()) > 0:
         e0, e1 = m0[:, members][:, :, empty], m1[:, members][:, :, empty]
         assert float(((e0 - e1).abs() / e1.abs().clamp_min(1.0)).max()) <= 4e-16 * 8
-    assert torch.equal(i0, i1)
+    # the adaptive inflation takes sum(rloc) (parm(3), common_letkf.f90:233) from per-lane partial sums: the fused search packs a
+    # point's second and later staging batches behind the left-over entries of the one before, the list path does not -- the
+    # same numbers summed in another order, one unit in the last place on a point in a few hundred
+    assert float((i0 - i1).abs().max()) <= 4.5e-16, (float((i0 - i1).abs().max()), int((i0 != i1).sum()), i0.numel())
 
 
 def test_fused_search_refuses_what_it_does_not_cover():
