@@ -84,6 +84,9 @@ CONFIGS = {
     # C2's grid at k = 20 (the memory-bound regime of configs[0]: arithmetic intensity ~5 flop/B)
     "C2-k20": dict(nx=240, ny=240, nz=60, k=20, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2900.0, err=3.0,
                    ztop=18000.0, seed=20240633),
+    # C2's grid at the small ensemble sizes of the reference's test configurations (MEMBER = 10 in 11, 8 in 9, 3 in 11 of its 58 config files)
+    **{f"C2-k{k_}": dict(nx=240, ny=240, nz=60, k=k_, dx=1000.0, hloc=4000.0, vloc=2000.0, spacing=2900.0, err=3.0,
+                        ztop=18000.0, seed=20240640 + k_) for k_ in (10, 8, 3)},
     # BASELINE configs[0] as SURVEY.md section 8(d) specifies it: 40 x 40 x 30 at DX = 15 km, k = 20, 500 observations at
     # uniformly random positions, conventional upper-air type (ADPUPA): vertical localisation in ln p (letkf_tools.f90:1864,
     # scale 0.4), HORI_LOCAL 500 km -- the horizontal cut-off covers the whole domain, so n is whatever the ln-p test leaves of

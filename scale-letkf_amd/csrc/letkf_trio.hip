@@ -40,6 +40,21 @@ struct TrioLds {
 };
 enum { ST_INFL = 0, ST_P1, ST_P2, ST_P3, ST_N, ST_SWEEPS, ST_CONV, ST_BETA };
 
+// profiling twin (make PROF=1): wave time per phase from s_memtime -- 0 set-up + staging, 1 Gram steps, 2 park / warm product,
+// 3 eigensolve, 4 spectra + state loads, 5 apply products, 6 analysis members -- summed over all waves into PointArgs::prof
+struct TrioProf {
+#ifdef LETKF_WAVE_PROF
+  unsigned long long t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last = __builtin_amdgcn_s_memtime(), t0 = last;
+  __device__ __forceinline__ void mark(const int i) {
+    const unsigned long long n = __builtin_amdgcn_s_memtime();
+    t[i] += n - last;
+    last = n;
+  }
+#else
+  __device__ __forceinline__ void mark(const int) {}
+#endif
+};
+
 // ---------------------------------------------------------------------------------------------
 // The eigensolve of up to three parked matrices at once (see the head of the file; the iteration itself is jacobi_split's,
 // letkf_jacobi_dev.h, copy-free form).  valid: bit p = point p is parked.
@@ -251,7 +266,7 @@ __device__ __forceinline__ void jacobi_trio(double* slice, const int k, const un
 // leaves no eigenvectors behind for the next point of its run) / beta = 0 (it does not touch the run's).  warm: the park holds
 // the eigenvectors of the previous point of this run.
 template <int KR>
-__device__ __forceinline__ int trio_front(const PointArgs& A, const long pt, const int sub, double* slice, const int k, const bool warm) {
+__device__ __forceinline__ int trio_front(const PointArgs& A, const long pt, const int sub, double* slice, const int k, const bool warm, TrioProf& pf) {
   using L = TrioLds<KR>;
   constexpr int RS = KR - 16;                  // members of the narrow second block (letkf_wave.hip STRIP): 4 or 0
   constexpr int NBLK = RS > 0 ? 2 : 1;
@@ -339,7 +354,10 @@ __device__ __forceinline__ int trio_front(const PointArgs& A, const long pt, con
         strip_row(std::integral_constant<int, 3>{});
       }
     };
-    constexpr int PD = 3;                                      // steps in flight (letkf_wave.hip run_steps: why it is written so)
+#ifndef TRIO_GRAM_DEPTH
+#define TRIO_GRAM_DEPTH 5
+#endif
+    constexpr int PD = TRIO_GRAM_DEPTH;                        // steps in flight (letkf_wave.hip run_steps: why it is written so)
     Step ts[PD];
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
@@ -405,7 +423,9 @@ __device__ __forceinline__ int trio_front(const PointArgs& A, const long pt, con
       }
     }
     wave_lds_sync();
+    pf.mark(0);
     run_steps(nsp);
+    pf.mark(1);
   }
   // the sums over the four observation residues q (the tile is summed by the matrix instruction itself)
 #pragma unroll
@@ -507,13 +527,14 @@ __device__ __forceinline__ int trio_front(const PointArgs& A, const long pt, con
     st[ST_BETA] = beta;
   }
   wave_lds_sync();
+  pf.mark(2);
   return 2;
 }
 
 // ---------------------------------------------------------------------------------------------
 // back: spectra, status, inflation, apply phase on the matrix cores (letkf_wave.hip MAPPLY), analysis members.
 template <int KR>
-__device__ __forceinline__ int trio_back(const PointArgs& A, const long pt, const int sub, double* slice, const int k) {
+__device__ __forceinline__ int trio_back(const PointArgs& A, const long pt, const int sub, double* slice, const int k, TrioProf& pf) {
   using L = TrioLds<KR>;
   constexpr int NV = 11, NB = NV + 2;
   constexpr int KS = (KR + 3) / 4, BR = 4 * KS;
@@ -567,6 +588,7 @@ __device__ __forceinline__ int trio_back(const PointArgs& A, const long pt, cons
       xd_l = A.det_run ? g0[(k + 1) * A.sm + lane * A.sv] : 0.0;
     }
   }
+  pf.mark(4);
   double* bm = slice + L::work;                    // [BR][16]
   double* scl = bm + BR * 16;                      // [64][2]
   double* ob = scl + 128;                          // [32][16]
@@ -668,6 +690,7 @@ __device__ __forceinline__ int trio_back(const PointArgs& A, const long pt, cons
       if (b + 1 < NB) out[b + 1] = o2.y;
     }
   }
+  pf.mark(5);
   // ------------------------------------------------------------ analysis members (letkf_tools.f90:472-513)
   {
     double* ap = a0 + moff;
@@ -715,6 +738,7 @@ __device__ __forceinline__ int trio_back(const PointArgs& A, const long pt, cons
     if (A.nobs_out) A.nobs_out[pt] = n;
   }
   wave_lds_sync();
+  pf.mark(6);
   return __builtin_amdgcn_readfirstlane(st);
 }
 
@@ -733,6 +757,7 @@ __global__ void __launch_bounds__(256, 2) letkf_trio_kernel(const PointArgs A) {
   const int run_len = A.run_len;
   const long S = A.warm_stride, nA = A.npts / S;
   bool first_draw = true;
+  TrioProf pf;
   for (;;) {
     // a unit = plan.ub consecutive runs (three, or a multiple: launch_trio), taken three at a time and walked in step
     const int slot0 = first_draw ? (int)(blockIdx.x >> 3) * PPW + wv : -1;
@@ -765,19 +790,21 @@ __global__ void __launch_bounds__(256, 2) letkf_trio_kernel(const PointArgs A) {
         for (int sub = 0; sub < nsub; ++sub) {
           const long ra = sub == 0 ? ras[0] : sub == 1 ? ras[1] : ras[2], rb = sub == 0 ? rbs[0] : sub == 1 ? rbs[1] : rbs[2];
           if (ra + ir < nA) {
-            const int r = trio_front<KR>(A, (ra + ir) * S + rb, sub, slice, k, (warm >> sub) & 1u);
+            const int r = trio_front<KR>(A, (ra + ir) * S + rb, sub, slice, k, (warm >> sub) & 1u, pf);
             if (r == 2) valid |= 1u << sub;
             else if (r == 1) warm &= ~(1u << sub);
           }
         }
         valid = __builtin_amdgcn_readfirstlane(valid);
         if (valid == 0) continue;
+        pf.mark(0);
         jacobi_trio<KR>(slice, k, valid, A.max_sweep);
+        pf.mark(3);
 #pragma unroll 1
         for (int sub = 0; sub < nsub; ++sub) {
           if ((valid >> sub) & 1u) {
             const long ra = sub == 0 ? ras[0] : sub == 1 ? ras[1] : ras[2], rb = sub == 0 ? rbs[0] : sub == 1 ? rbs[1] : rbs[2];
-            const int st = trio_back<KR>(A, (ra + ir) * S + rb, sub, slice, k);
+            const int st = trio_back<KR>(A, (ra + ir) * S + rb, sub, slice, k, pf);
             if (st == 0) warm |= 1u << sub;
             else warm &= ~(1u << sub);
           }
@@ -785,6 +812,14 @@ __global__ void __launch_bounds__(256, 2) letkf_trio_kernel(const PointArgs A) {
       }
     }
   }
+#ifdef LETKF_WAVE_PROF
+  if (A.prof && lane == 0) {
+    pf.mark(9);
+    for (int i = 0; i < 10; ++i) atomicAdd(&A.prof[i], pf.t[i]);
+    atomicMax(&A.prof[10], ~pf.t0);
+    atomicMax(&A.prof[11], (unsigned long long)__builtin_amdgcn_s_memtime());
+  }
+#endif
 }
 
 template <int KR>

@@ -55,20 +55,54 @@ __device__ __forceinline__ double dpp_mov(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// Reductions over the 64 lanes (every lane active).  (r4) The xor butterfly through __shfl_xor compiles to two ds_bpermute per
+// stage -- six dependent LDS round trips per sum, and the analysis members take 11 .. 33 sums per point (found in the ISA of
+// letkf_trio.hip: 636 ds_bpermute; the phase was 14 % of its wave time).  Same tree without LDS: inside a row of 16 lanes by DPP
+// (lane ^ 1, lane ^ 2, then the mirrors: lanes of a quad / of eight hold the same partial sum by then, so lane ^ 7 and lane ^ 15
+// deliver what lane ^ 4 and lane ^ 8 would), the four rows by v_readlane -- ((r0 + r1) + (r2 + r3)), the butterfly's own
+// association: bitwise the same result.
+#ifndef LETKF_WAVE_SUM_SHFL
+#define LETKF_WAVE_SUM_SHFL 0
+#endif
+__device__ __forceinline__ double readlane_d(double v, int src);
 __device__ __forceinline__ double wave_sum(double v) {
+  if constexpr (LETKF_WAVE_SUM_SHFL) {
 #pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v += wshfl_xor(v, m);
-  return v;
+    for (int m = 1; m < 64; m <<= 1) v += wshfl_xor(v, m);
+    return v;
+  } else {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+  }
 }
 __device__ __forceinline__ double wave_max(double v) {
+  if constexpr (LETKF_WAVE_SUM_SHFL) {
 #pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v = fmax(v, wshfl_xor(v, m));
-  return v;
+    for (int m = 1; m < 64; m <<= 1) v = fmax(v, wshfl_xor(v, m));
+    return v;
+  } else {
+    v = fmax(v, dpp_mov<0xB1>(v));
+    v = fmax(v, dpp_mov<0x4E>(v));
+    v = fmax(v, dpp_mov<0x141>(v));
+    v = fmax(v, dpp_mov<0x140>(v));
+    return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
+  }
 }
 __device__ __forceinline__ double wave_min(double v) {
+  if constexpr (LETKF_WAVE_SUM_SHFL) {
 #pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v = fmin(v, wshfl_xor(v, m));
-  return v;
+    for (int m = 1; m < 64; m <<= 1) v = fmin(v, wshfl_xor(v, m));
+    return v;
+  } else {
+    v = fmin(v, dpp_mov<0xB1>(v));
+    v = fmin(v, dpp_mov<0x4E>(v));
+    v = fmin(v, dpp_mov<0x141>(v));
+    v = fmin(v, dpp_mov<0x140>(v));
+    return fmin(fmin(readlane_d(v, 0), readlane_d(v, 16)), fmin(readlane_d(v, 32), readlane_d(v, 48)));
+  }
 }
 
 // a value known to be identical in every lane -> SGPR pair (frees VGPRs, lets FMAs take a scalar operand)
@@ -1342,8 +1376,11 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 128, NW == 1 ? wave_occupancy(
           if (wvp == pass) {
             if constexpr (STRIP) {
               // rows of block I < S: the columns 16 S + a are accS[a][I] (lane c = the row); rows of block S (a < RS): every
-              // column 16 J + c is accS[a][J] -- element (row, col) at abuf[col * LDA + row-in-block], as the tiles below
-              if (q == 0) {
+              // column 16 J + c is accS[a][J] -- element (row, col) at abuf[col * LDA + row-in-block], as the tiles below.
+              // (Every q row writes -- the same values, folded above: NOT `if (q == 0)`.  At the join of that branch hipcc put a
+              // register spill in front of the exec restore in letkf_wave_kernel<20, 11, false> -- the defect of DESIGN.md section 8,
+              // caught by tools/isa_exec_audit.py at build time when wave_sum changed the allocation.)
+              {
                 if (I < NBLK - 1) {
 #pragma unroll
                   for (int a = 0; a < 16; ++a) abuf[(16 * (NBLK - 1) + a) * LDA + c16] = a < RS ? accS[a][I] : 0.0;   // (the padding columns: zeros, as the tiles left them)
