@@ -334,3 +334,48 @@ def test_das_points_ensemble_sizes_inside_an_instantiation(k):
         e = ref["trans"][p]
         assert np.abs(t[p] - e).max() <= 1e-11 * np.abs(e).max(), (p, np.abs(t[p] - e).max())
     assert np.abs(transm.cpu().numpy() - ref["transm"]).max() <= 1e-11 * max(np.abs(ref["transm"]).max(), 1e-300)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_das_points_small_ensembles_soak(seed):
+    """Randomised soak of the three-points-per-wave kernel (k = 2 .. 20) against the oracle: observation errors from 0.05 to 30
+    (cond(A) up to ~1e5), local lists from empty to several staging batches (> 256), batches that are not multiples of three runs,
+    random run lengths, every relaxation / inflation switch."""
+    from _gpu import ctx, dev
+    rng = np.random.default_rng(4000 + seed)
+    k = int(rng.integers(2, 21))
+    npts = int(rng.integers(40, 230))
+    n_mean = int(rng.choice([4, 50, 170, 330]))
+    nobs_tot = 720
+    name = list(CONFIGS)[int(rng.integers(0, len(CONFIGS)))]
+    cfg = CONFIGS[name]
+    det = bool(cfg.get("det_run", 0))
+    c = das_case(k=k, nv=11, npts=npts, nobs_tot=nobs_tot, n_mean=n_mean, seed=4100 + seed, det_run=det, infl0=1.05)
+    f = rng.choice([0.05, 1.0, 6.0], size=nobs_tot)
+    c["rdiag"] = c["rdiag"] * f[c["obs_idx"]] ** 2
+    prm = _oracle.DasParams(k=k, nv=11, det_run=int(det), infl_adaptive=cfg.get("infl_adaptive", 0),
+                            relax_to_inflated_prior=cfg.get("relax_to_inflated_prior", 0), relax_alpha=cfg.get("relax_alpha", 0.0),
+                            relax_alpha_spread=cfg.get("relax_alpha_spread", 0.0), q_update_top=cfg.get("q_update_top", 0.0),
+                            q_sprd_max=cfg.get("q_sprd_max", 0.0), iv_p=4, iv_q_first=5, iv_q_last=10, nthreads=4)
+    ref = _oracle.das_points(prm, c["obs_off"], c["obs_idx"], c["rdiag"], c["rloc"], c["ensval"], c["dep"], c["beta"], c["infl"],
+                             c["gues"], c["sp"], c["sm"], c["sv"])
+    assert ref["rc"] == 0
+    anal = torch.full((c["gues"].size,), float("nan"), dtype=torch.float64, device="cuda")
+    infl = dev(c["infl"])
+    status = torch.full((npts,), -1, dtype=torch.int32, device="cuda")
+    nsweep = torch.full((npts,), -1, dtype=torch.int32, device="cuda")
+    ctx().das_points(k, 11, dev(c["obs_off"]), dev(c["obs_idx"]), dev(c["rdiag"]), dev(c["rloc"]), dev(c["ensval"]), c["kld"],
+                     dev(c["dep"]), infl, dev(c["gues"]), anal, c["sp"], c["sm"], c["sv"], beta=dev(c["beta"]), det_run=det,
+                     infl_adaptive=cfg.get("infl_adaptive", 0), relax_to_inflated_prior=cfg.get("relax_to_inflated_prior", 0),
+                     relax_alpha=cfg.get("relax_alpha", 0.0), relax_alpha_spread=cfg.get("relax_alpha_spread", 0.0),
+                     q_update_top=cfg.get("q_update_top", 0.0), q_sprd_max=cfg.get("q_sprd_max", 0.0), iv_p=4, iv_q_first=5,
+                     iv_q_last=10, status=status, nsweep=nsweep, warm_run=int(rng.choice([0, 1, 2, 5, 16])))
+    torch.cuda.synchronize()
+    assert ctx().last_path().startswith("letkf_trio_kernel"), ctx().last_path()
+    st = status.cpu().numpy()
+    assert set(st.tolist()) <= {0, 3}, st                     # (3: the conditioning warning of common_mtx.f90:66-78 -- the analysis is still made)
+    live = (np.diff(c["obs_off"]) > 0) & (c["beta"] != 0.0)
+    sw = nsweep.cpu().numpy()
+    assert (sw[live] >= 1).all() and (sw[live] < 40).all() and (sw[~live] == 0).all()
+    compare_anal(c, ref, anal.cpu().numpy(), k, 11, det)
+    assert np.abs(infl.cpu().numpy() - ref["infl"]).max() <= 1e-11
