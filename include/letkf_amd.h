@@ -599,6 +599,8 @@ int letkf_ctx_timing_read(letkf_ctx *ctx, double *avg_ms, int64_t *nlaunch, int 
  * same code the kernel runs, and returns 0 iff every run is handed out exactly once -- whole, or as its four quarters.
  * For the CPU test suite (tests/test_sched_plan.py). */
 int letkf_sched_plan_check(int64_t npts, int64_t stride, int32_t run_len, int32_t grid, int32_t ppw, int32_t resident_per_xcd);
+/* ... with units that are whole multiples of ub_of runs (csrc/letkf_trio.hip walks three runs in step: ub_of = 3). */
+int letkf_sched_plan_check_units(int64_t npts, int64_t stride, int32_t run_len, int32_t grid, int32_t ppw, int32_t resident_per_xcd, int32_t ub_of);
 
 #ifdef __cplusplus
 }

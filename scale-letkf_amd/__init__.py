@@ -142,7 +142,7 @@ EXPORTS = ["letkf_amd_abi_version", "letkf_amd_last_error", "letkf_ctx_create", 
            "letkf_var_local_classes", "letkf_ctype_merge_groups", "letkf_radar_only", "letkf_relax_beta_dev",
            "letkf_infl_init_dev", "letkf_obs_allgatherv_dev", "letkf_alltoallv_dev", "letkf_allreduce_sum_i32_dev",
            "letkf_members_alltoall_dev",
-           "letkf_ctx_timing_enable", "letkf_ctx_timing_read", "letkf_ctx_last_path", "letkf_sched_plan_check"]
+           "letkf_ctx_timing_enable", "letkf_ctx_timing_read", "letkf_ctx_last_path", "letkf_sched_plan_check", "letkf_sched_plan_check_units"]
 
 _lib = None
 

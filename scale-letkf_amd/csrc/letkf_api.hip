@@ -536,7 +536,10 @@ int letkf_ctx_synchronize(letkf_ctx* c) {
 }
 
 int letkf_sched_plan_check(int64_t npts, int64_t stride, int32_t run_len, int32_t grid, int32_t ppw, int32_t resident_per_xcd) {
-  return letkf::sched_plan_check((long)npts, (long)stride, run_len, grid, ppw, resident_per_xcd);
+  return letkf::sched_plan_check((long)npts, (long)stride, run_len, grid, ppw, resident_per_xcd, 1);
+}
+int letkf_sched_plan_check_units(int64_t npts, int64_t stride, int32_t run_len, int32_t grid, int32_t ppw, int32_t resident_per_xcd, int32_t ub_of) {
+  return letkf::sched_plan_check((long)npts, (long)stride, run_len, grid, ppw, resident_per_xcd, ub_of);
 }
 
 int letkf_ctx_last_path(letkf_ctx* c, char* buf, int32_t len) {

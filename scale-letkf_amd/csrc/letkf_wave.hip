@@ -535,11 +535,12 @@ __device__ __forceinline__ void warm_start_product_mfma(double (&g)[KR], const d
 
 #if !defined(LETKF_WAVE_UNIT2) && !defined(LETKF_WAVE_UNIT3)
 // include/letkf_amd.h, letkf_sched_plan_check: every run exactly once (whole or as four quarters)?
-int sched_plan_check(long npts, long stride, int run_len, int grid, int ppw, int resident_per_xcd) {
-  if (npts < 0 || grid < 1 || ppw < 1 || run_len < 1) return -1;
+int sched_plan_check(long npts, long stride, int run_len, int grid, int ppw, int resident_per_xcd, int ub_of) {
+  if (npts < 0 || grid < 1 || ppw < 1 || run_len < 1 || ub_of < 1) return -1;
   SchedPlan P;
-  sched_make_plan(P, npts, stride, run_len, grid, ppw, resident_per_xcd);
+  sched_make_plan(P, npts, stride, run_len, grid, ppw, resident_per_xcd, ub_of);
   if (P.nruns > (1L << 27)) return -2;
+  if (P.ub % ub_of != 0) return -9;                            // (letkf_trio.hip: units are whole multiples of three runs)
   std::vector<unsigned char> seen((size_t)P.nruns, 0);   // bit 7: whole, bits 0-3: quarters
   for (int x = 0; x < 8; ++x) {
     if (P.nstat[x] < 0 || P.nstat[x] > P.whole[x] + 4 * P.f[x]) return -3;

@@ -56,3 +56,25 @@ def test_random_shapes(check):
 
 def test_rejects_nonsense(check):
     assert check(100, 1, 0, 8, 4, 256) != 0 and check(100, 1, 4, 0, 4, 256) != 0 and check(-1, 1, 1, 8, 4, 256) != 0
+
+
+def test_units_of_three_runs():
+    """csrc/letkf_trio.hip (k <= 20) walks three neighbouring runs in step: its plan hands out units that are whole multiples of
+    three runs, every run exactly once, no quartered runs."""
+    p = load_package()
+    f = C.CDLL(p.LIB_PATH).letkf_sched_plan_check_units
+    f.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    f.restype = C.c_int
+    shapes = [(240 * 240 * 60, 240 * 240, 60, 512, 4, 256), (40 * 40 * 30, 1600, 4, 512, 4, 256), (40 * 40 * 30, 1600, 30, 134, 4, 256),
+              (48 * 48 * 12, 1, 6, 512, 4, 256), (150, 1, 1, 13, 4, 256), (1, 1, 1, 1, 4, 256), (0, 1, 1, 1, 4, 256), (100_000_000, 1, 16, 512, 4, 256)]
+    for s in shapes:
+        assert f(*s, 3) == 0, s
+    rng = np.random.default_rng(7)
+    for _ in range(1500):
+        grid = int(rng.choice([1, 2, 7, 8, 9, 64, 255, 512]))
+        if rng.random() < 0.5:
+            nij, nlev = int(rng.integers(1, 3000)), int(rng.integers(1, 130))
+            npts, stride, run_len = nij * nlev, nij, int(min(nlev, rng.choice([nlev, 4, 7, 16, 128])))
+        else:
+            npts, stride, run_len = int(rng.integers(0, 400000)), 1, int(rng.choice([1, 2, 5, 16]))
+        assert f(npts, stride, run_len, grid, 4, 256, 3) == 0, (npts, stride, run_len, grid)
