@@ -841,8 +841,14 @@ hipError_t launch_trio(const PointArgs& a, int num_cu, hipStream_t st) {
   }
   if (!a.sched) return hipErrorInvalidValue;
   const long res = (long)occ * num_cu;
-  long rl_ = a.npts / (6 * res * 4);
-  if (rl_ < 4) rl_ = 4;
+#ifndef TRIO_MIN_RUN
+#define TRIO_MIN_RUN 4
+#endif
+#ifndef TRIO_UNITS_PER_WAVE
+#define TRIO_UNITS_PER_WAVE 2
+#endif
+  long rl_ = a.npts / (3 * TRIO_UNITS_PER_WAVE * res * 4);
+  if (rl_ < TRIO_MIN_RUN) rl_ = TRIO_MIN_RUN;
   if (rl_ > a.run_len) rl_ = a.run_len;
   const long S = a.warm_stride > 1 ? a.warm_stride : 1, rl = rl_ > 1 ? rl_ : 1;
   const long nruns = S * ((a.npts / S + rl - 1) / rl);
@@ -855,8 +861,8 @@ hipError_t launch_trio(const PointArgs& a, int num_cu, hipStream_t st) {
   // shorter runs then (the first point of a run starts cold), down to 4 points, until there are two units per wave
   {
     const long slots = res * 4;
-    long want = a.npts / (6 * slots);
-    if (want < 4) want = 4;
+    long want = a.npts / (3 * TRIO_UNITS_PER_WAVE * slots);
+    if (want < TRIO_MIN_RUN) want = TRIO_MIN_RUN;
     if (b.run_len > want) b.run_len = (int)want;
   }
   sched_make_plan(b.plan, a.npts, a.warm_stride, b.run_len, grid, 4, 256, kTrioP);   // units of three runs
