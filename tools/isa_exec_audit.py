@@ -8,6 +8,7 @@ Usage: isa_exec_audit.py file.s [...]   (the device assembly: hipcc -save-temps=
 block -- a label that the skip branch (s_cbranch_execz) of a divergent `if` jumps to -- in which an instruction that depends on exec
 (vector ALU, LDS, global, scratch) stands between the label and the block's exec restore; exit code 1 if there is one.  (A then-block
 that merely falls through into the restore is not a join block: its instructions are meant for its own lanes.)"""
+import os
 import re
 import sys
 
@@ -108,6 +109,14 @@ def audit_loop_exits(path):
 def main():
     args = [a for a in sys.argv[1:] if a != "-q"]
     quiet = len(args) != len(sys.argv) - 1
+    if len(args) == 2 and args[0] == "--dir":
+        # every unit's assembly that is present beside the objects: a unit without it was not compiled in this tree (its object
+        # arrived built -- gpurun ships objects, not their assembly -- and was audited where it was built)
+        import glob
+        args = sorted(glob.glob(os.path.join(args[1], "*-hip-amdgcn-amd-amdhsa-gfx950.s")))
+        if not args:
+            print("isa_exec_audit: no device assembly beside the objects (built elsewhere): nothing to audit")
+            return 0
     rc = 0
     total = 0
     for p in args:
