@@ -11,7 +11,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,list_mb", [("C2-mini", 0.5), ("C2-mini", 3.0), ("C2-mini", 0), ("C2-mini-k100", 2.0), ("C2-mini-disc", 1.0)])
+@pytest.mark.parametrize("name,list_mb", [("C2-mini", 0.5), ("C2-mini", 3.0), ("C2-mini", 0), ("C2-mini-k100", 2.0), ("C2-mini-disc", 1.0),
+                                          ("C2-mini-k20", 0.4), ("C2-tiny-k17", 0.1), ("C2-tiny-k16", 0)])
 def test_column_pipeline_equals_search_plus_loop_body(name, list_mb):
     import bench_workload as bw
     from _gpu import ctx, pkg
