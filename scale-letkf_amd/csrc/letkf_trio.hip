@@ -623,7 +623,10 @@ __device__ __forceinline__ int trio_back(const PointArgs& A, const long pt, cons
 #pragma unroll
       for (int il = 0; il < 2; ++il) {
         if (16 * il < KR) {
-          const double a = vh[(16 * il + c) * KR + 4 * s_ + q];
+          // (columns past KR of the second tile: zero, not whatever follows the park -- a neighbour's matrix; finite or not, it
+          // must not reach this point's U, whose rows past k meet zero spectra but NaN * 0 is NaN)
+          double a = vh[(16 * il + c) * KR + 4 * s_ + q];
+          if (il > 0) a = (16 * il + c < KR) ? a : 0.0;
           accU[il] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, accU[il], 0, 0, 0);
         }
       }

@@ -379,3 +379,39 @@ def test_das_points_small_ensembles_soak(seed):
     assert (sw[live] >= 1).all() and (sw[live] < 40).all() and (sw[~live] == 0).all()
     compare_anal(c, ref, anal.cpu().numpy(), k, 11, det)
     assert np.abs(infl.cpu().numpy() - ref["infl"]).max() <= 1e-11
+
+
+@pytest.mark.parametrize("k,trio", [(20, 1), (20, 0), (17, 1), (50, 1)])
+def test_a_point_with_a_nan_observation_poisons_no_other_point(k, trio):
+    """One observation row whose ensemble perturbations are NaN, in the list of ONE grid point: that point's analysis is NaN (as the
+    reference's would be), every other point's is what it is without the row -- also the points solved beside it in the same wave
+    (three per wave at k <= 20: their padded matrix operands read past their own park) and the next point of its run."""
+    from _gpu import ctx, dev
+    npts = 90
+    c = das_case(k=k, nv=11, npts=npts, nobs_tot=400, n_mean=60, seed=8800 + k, det_run=False, infl0=1.02)
+    n = np.diff(c["obs_off"])
+    victim = int(np.argmax((n > 20) & (c["beta"] == 1.0) & (np.arange(npts) > 30)))
+    ens_bad = np.vstack([c["ensval"].reshape(-1, c["kld"]), np.full((1, c["kld"]), np.nan)])
+    dep_bad = np.concatenate([c["dep"], [0.5]])
+    idx_bad = c["obs_idx"].copy()
+    idx_bad[c["obs_off"][victim]] = ens_bad.shape[0] - 1
+
+    def run(ens, dep, idx):
+        anal = torch.full((c["gues"].size,), float("nan"), dtype=torch.float64, device="cuda")
+        infl = dev(c["infl"])
+        ctx().das_points(k, 11, dev(c["obs_off"]), dev(idx), dev(c["rdiag"]), dev(c["rloc"]), dev(np.ascontiguousarray(ens).reshape(-1)),
+                         c["kld"], dev(dep), infl, dev(c["gues"]), anal, c["sp"], c["sm"], c["sv"], beta=dev(c["beta"]),
+                         relax_alpha_spread=0.95, warm_run=8)
+        torch.cuda.synchronize()
+        return anal.cpu().numpy().reshape(11, c["nens"], npts)[:, :k]
+    ctx().set_option(ctx().OPT_SMALL_K_TRIO, trio)
+    try:
+        clean = run(c["ensval"].reshape(-1, c["kld"]), c["dep"], c["obs_idx"])
+        bad = run(ens_bad, dep_bad, idx_bad)
+    finally:
+        ctx().set_option(ctx().OPT_SMALL_K_TRIO, 1)
+    others = np.arange(npts) != victim
+    assert np.isnan(bad[:, :, victim]).all()
+    assert np.isfinite(bad[:, :, others]).all(), np.argwhere(~np.isfinite(bad[:, :, others]).all(axis=(0, 1))).ravel()
+    scale = np.abs(clean[:, :, others]).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(bad[:, :, others] - clean[:, :, others]) / scale).max() <= 1e-11
