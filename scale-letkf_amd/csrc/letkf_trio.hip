@@ -262,20 +262,68 @@ __device__ __forceinline__ void jacobi_trio(double* slice, const int k, const un
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rolling prefetch (r4): a point's front starts with three dependent memory round trips -- list offsets, the list, the departures
+// (7 .. 12 % of the wave time, PROF twin).  The offsets of the point after next and the first 256 list entries of the next point are
+// requested before the current point's Gram runs; across the eigensolve and the backs of a level they stay in flight for the first
+// point of the next level.  Nothing is waited for where it is requested: the values are touched one slot later.
+struct TrioHead {
+  long pt;                    // < 0: no point
+  long o0, o1;                // obs_off[pt], obs_off[pt + 1] as loaded
+  double beta;
+};
+struct TrioList {
+  int iob[4];
+  double rlv[4], rdv[4];
+};
+__device__ __forceinline__ TrioHead trio_head(const PointArgs& A, const long pt) {
+  TrioHead h;
+  h.pt = pt;
+  h.o0 = h.o1 = 0;
+  h.beta = 1.0;
+  if (pt >= 0) {
+    h.o0 = A.obs_off[pt];
+    h.o1 = A.obs_off[pt + 1];
+    if (A.beta) h.beta = A.beta[pt];
+  }
+  return h;
+}
+__device__ __forceinline__ TrioList trio_list(const PointArgs& A, const TrioHead& h) {
+  TrioList l;
+  const int lane = threadIdx.x & 63;
+  const int n = (int)(h.o1 - h.o0);
+  const int ns = (h.pt >= 0 && h.beta != 0.0) ? (n < 256 ? n : 256) : 0;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int i = ps * 64 + lane;
+    l.iob[ps] = 0;
+    l.rdv[ps] = 1.0;
+    l.rlv[ps] = 0.0;
+    if (i < ns) {
+      const long e = h.o0 + i;
+      l.iob[ps] = A.obs_idx[e];
+      l.rlv[ps] = A.rloc_l[e];
+      l.rdv[ps] = A.rdiag_l[e];
+    }
+  }
+  return l;
+}
+
+// ---------------------------------------------------------------------------------------------
 // front: Gram of one point into its park.  Returns 2: parked; 1 / 0: a point the streaming pass has done -- no observations (it
 // leaves no eigenvectors behind for the next point of its run) / beta = 0 (it does not touch the run's).  warm: the park holds
 // the eigenvectors of the previous point of this run.
 template <int KR>
-__device__ __forceinline__ int trio_front(const PointArgs& A, const long pt, const int sub, double* slice, const int k, const bool warm, TrioProf& pf) {
+__device__ __forceinline__ int trio_front(const PointArgs& A, const TrioHead& hd, const TrioList& pl, const int sub, double* slice, const int k, const bool warm, TrioProf& pf) {
   using L = TrioLds<KR>;
   constexpr int RS = KR - 16;                  // members of the narrow second block (letkf_wave.hip STRIP): 4 or 0
   constexpr int NBLK = RS > 0 ? 2 : 1;
   constexpr int RSA = RS > 0 ? RS : 1;
   const int lane = threadIdx.x & 63;
   const double km1 = (double)(k - 1);
-  const long o0 = A.obs_off[pt];
-  const int n = __builtin_amdgcn_readfirstlane((int)(A.obs_off[pt + 1] - o0));
-  const double beta = A.beta ? A.beta[pt] : 1.0;
+  const long pt = hd.pt;
+  const long o0 = hd.o0;
+  const int n = __builtin_amdgcn_readfirstlane((int)(hd.o1 - hd.o0));
+  const double beta = uniform(hd.beta);
   if (beta == 0.0) return 0;
   if (n == 0) return 1;
   const double* g0 = A.gues + pt * A.sp;
@@ -392,7 +440,11 @@ __device__ __forceinline__ int trio_front(const PointArgs& A, const long pt, con
       rlv[ps] = 0.0;
       dv[ps] = 0.0;
       ddv[ps] = 0.0;
-      if (i < ns) {
+      if (s0 == 0) {                                          // (the first batch was requested a slot ago)
+        iob[ps] = pl.iob[ps];
+        rlv[ps] = pl.rlv[ps];
+        rdv[ps] = pl.rdv[ps];
+      } else if (i < ns) {
         const long e = o0 + s0 + i;
         iob[ps] = A.obs_idx[e];
         rlv[ps] = A.rloc_l[e];
@@ -786,17 +838,39 @@ __global__ void __launch_bounds__(256, 2) letkf_trio_kernel(const PointArgs A) {
         ras[sub] = rchunk * run_len;
       }
       unsigned warm = 0;                         // bit p: park p holds the eigenvectors of the previous point of run p
+      // the points of the group in front order: (level, run) = (ir0, 0), (ir0, 1), ..., (ir0 + 1, 0), ...
+      auto point_at = [&](const int ir, const int sub) -> long {
+        if (ir >= ir1) return -1;
+        const long ra = sub == 0 ? ras[0] : sub == 1 ? ras[1] : ras[2], rb = sub == 0 ? rbs[0] : sub == 1 ? rbs[1] : rbs[2];
+        return ra + ir < nA ? (ra + ir) * S + rb : -1;
+      };
+      int ir_a = ir0, sub_a = 0;                 // the slot whose offsets are requested next
+      auto next_head = [&]() -> TrioHead {
+        const TrioHead h = trio_head(A, point_at(ir_a, sub_a));
+        if (++sub_a == nsub) {
+          sub_a = 0;
+          ++ir_a;
+        }
+        return h;
+      };
+      TrioHead h0 = next_head(), h1 = next_head();
+      TrioList l0 = trio_list(A, h0);
       for (int ir = ir0; ir < ir1; ++ir) {
         unsigned valid = 0;
         // (one copy of the front and of the back in the code: the loops over the three points are not unrolled)
 #pragma unroll 1
         for (int sub = 0; sub < nsub; ++sub) {
-          const long ra = sub == 0 ? ras[0] : sub == 1 ? ras[1] : ras[2], rb = sub == 0 ? rbs[0] : sub == 1 ? rbs[1] : rbs[2];
-          if (ra + ir < nA) {
-            const int r = trio_front<KR>(A, (ra + ir) * S + rb, sub, slice, k, (warm >> sub) & 1u, pf);
+          const TrioList l1 = trio_list(A, h1);  // the next point's list, the offsets of the one after it
+          const TrioHead h2 = next_head();
+          asm volatile("" ::: "memory");
+          if (h0.pt >= 0) {
+            const int r = trio_front<KR>(A, h0, l0, sub, slice, k, (warm >> sub) & 1u, pf);
             if (r == 2) valid |= 1u << sub;
             else if (r == 1) warm &= ~(1u << sub);
           }
+          h0 = h1;
+          l0 = l1;
+          h1 = h2;
         }
         valid = __builtin_amdgcn_readfirstlane(valid);
         if (valid == 0) continue;
@@ -806,8 +880,7 @@ __global__ void __launch_bounds__(256, 2) letkf_trio_kernel(const PointArgs A) {
 #pragma unroll 1
         for (int sub = 0; sub < nsub; ++sub) {
           if ((valid >> sub) & 1u) {
-            const long ra = sub == 0 ? ras[0] : sub == 1 ? ras[1] : ras[2], rb = sub == 0 ? rbs[0] : sub == 1 ? rbs[1] : rbs[2];
-            const int st = trio_back<KR>(A, (ra + ir) * S + rb, sub, slice, k, pf);
+            const int st = trio_back<KR>(A, point_at(ir, sub), sub, slice, k, pf);
             if (st == 0) warm |= 1u << sub;
             else warm &= ~(1u << sub);
           }
