@@ -296,7 +296,7 @@ int launch(letkf_ctx* c, letkf::PointArgs& a, int warm_run = 0, long warm_stride
     }
     if (c->trio && letkf::trio_kernel_supports(a)) {
       HIP_TRY(letkf::launch_trio_kernel(a, c->num_cu, c->stream));
-      c->last_path = std::string("letkf_trio_kernel<KR=") + (a.k <= 16 ? "16" : "20") + ">";
+      c->last_path = std::string("letkf_trio_kernel<KR=") + (a.k <= 16 ? "16" : "20") + ",P=" + std::to_string(letkf::trio_points_per_wave(a.k)) + ">";
     } else {
     HIP_TRY(letkf::launch_wave_kernel(a, c->num_cu, c->stream));
     c->last_path = "letkf_wave_kernel<KR=" + std::to_string(letkf::wave_kernel_kr(a.k)) + ",NV=" + std::to_string(a.nv) +

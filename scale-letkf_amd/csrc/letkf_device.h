@@ -192,6 +192,7 @@ hipError_t launch_wave_kernel(const PointArgs& a, int num_cu, hipStream_t st);
 // three points per wave for k <= 20 (letkf_trio.hip)
 bool trio_kernel_supports(const PointArgs& a);
 hipError_t launch_trio_kernel(const PointArgs& a, int num_cu, hipStream_t st);
+int trio_points_per_wave(int k);
 int sched_plan_check(long npts, long stride, int run_len, int grid, int ppw, int resident_per_xcd, int ub_of);
 bool trivial_pass_supports(const PointArgs& a);
 hipError_t launch_trivial_points(const PointArgs& a, hipStream_t st);

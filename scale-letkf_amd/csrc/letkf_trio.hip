@@ -25,18 +25,20 @@ namespace letkf {
 
 namespace {
 
-constexpr int kTrioP = 3;
-
-// the wave's LDS slice (doubles)
-template <int KR>
+// the wave's LDS slice (doubles).  P points per wave: 3 (the code is written for any P whose segments fit the line of 32 slots; with more
+// than three the staging batch shrinks to 192 observations so that the parks fit the 20 KB of a wave -- see launch_trio_kernel).
+template <int KR, int P>
 struct TrioLds {
   static constexpr int PSZ = (KR + 2) * KR;              // per point: A, later V, [KR columns][KR rows] | r [KR] | r_det [KR]
+  static constexpr int kSC = P > 3 ? 192 : 256;          // observations per staging batch
   static constexpr int park = 0;
-  static constexpr int lam = park + kTrioP * PSZ;        // [P][32] eigenvalue at every line position
-  static constexpr int st = lam + kTrioP * 32;           // [P][8]  per-point scalars (ST_*)
-  static constexpr int work = st + kTrioP * 8;           // front: staging [256][4]; back: B [BR][16] | spectra [64][2] | Out [32][16]
-  static constexpr int total = work + 1024;
+  static constexpr int lam = park + P * PSZ;             // [P][32] eigenvalue at every line position
+  static constexpr int st = lam + P * 32;                // [P][8]  per-point scalars (ST_*)
+  static constexpr int work = st + P * 8;                // front: staging [kSC][4]; back: B [BR][16] | spectra [64][2] | Out [32][16]
+  static constexpr int wsz = 4 * kSC > 4 * ((KR + 3) / 4) * 16 + 128 + 512 ? 4 * kSC : 4 * ((KR + 3) / 4) * 16 + 128 + 512;
+  static constexpr int total = work + wsz;
   static_assert(PSZ % 2 == 0 && work % 2 == 0, "16-byte accesses");
+  static_assert(total <= 2560, "two workgroups of four waves per CU");
 };
 enum { ST_INFL = 0, ST_P1, ST_P2, ST_P3, ST_N, ST_SWEEPS, ST_CONV, ST_BETA };
 
@@ -58,20 +60,22 @@ struct TrioProf {
 // ---------------------------------------------------------------------------------------------
 // The eigensolve of up to three parked matrices at once (see the head of the file; the iteration itself is jacobi_split's,
 // letkf_jacobi_dev.h, copy-free form).  valid: bit p = point p is parked.
-template <int KR>
+template <int KR, int P>
 __device__ __forceinline__ void jacobi_trio(double* slice, const int k, const unsigned valid, const int max_sweep) {
-  using L = TrioLds<KR>;
-  constexpr int H = KR / 2, P = kTrioP;
+  using L = TrioLds<KR, P>;
+  constexpr int H = KR / 2;
   const int lane = threadIdx.x & 63;
   const int slot = lane & 31, par = lane >> 5;
   const int ncol = (k + 1) & ~1;
   const int S = ncol >> 1, stride = S + 1;
-  const int seg = (slot >= stride ? 1 : 0) + (slot >= 2 * stride ? 1 : 0) + (slot >= 3 * stride ? 1 : 0);
+  int seg = 0;
+#pragma unroll
+  for (int p = 1; p <= P; ++p) seg += slot >= p * stride ? 1 : 0;
   const int sin = slot - seg * stride;
   const bool act = seg < P && sin < S && ((valid >> seg) & 1u);
-  // the last slot of the third point is slot 31 when 3 S + 2 = 32 (k = 19, 20): lane 31's right neighbour in the wave-wide shift
+  // the last slot of the last point is slot 31 when P S + P - 1 = 32 (three points at k = 19, 20): lane 31's right neighbour in the wave-wide shift
   // is lane 32 -- slot 0 of the other row half --, and the other way round; both fetches are zeroed by hand there
-  const bool wrap = __builtin_amdgcn_readfirstlane(2 * stride + S) == 32;
+  const bool wrap = __builtin_amdgcn_readfirstlane((P - 1) * stride + S) == 32;
   double* base = slice + L::park + (seg < P ? seg : 0) * L::PSZ;
   unsigned long long segm[P];
 #pragma unroll
@@ -287,11 +291,12 @@ __device__ __forceinline__ TrioHead trio_head(const PointArgs& A, const long pt)
   }
   return h;
 }
+template <int kSC>
 __device__ __forceinline__ TrioList trio_list(const PointArgs& A, const TrioHead& h) {
   TrioList l;
   const int lane = threadIdx.x & 63;
   const int n = (int)(h.o1 - h.o0);
-  const int ns = (h.pt >= 0 && h.beta != 0.0) ? (n < 256 ? n : 256) : 0;
+  const int ns = (h.pt >= 0 && h.beta != 0.0) ? (n < kSC ? n : kSC) : 0;
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     const int i = ps * 64 + lane;
@@ -312,9 +317,9 @@ __device__ __forceinline__ TrioList trio_list(const PointArgs& A, const TrioHead
 // front: Gram of one point into its park.  Returns 2: parked; 1 / 0: a point the streaming pass has done -- no observations (it
 // leaves no eigenvectors behind for the next point of its run) / beta = 0 (it does not touch the run's).  warm: the park holds
 // the eigenvectors of the previous point of this run.
-template <int KR>
+template <int KR, int P>
 __device__ __forceinline__ int trio_front(const PointArgs& A, const TrioHead& hd, const TrioList& pl, const int sub, double* slice, const int k, const bool warm, TrioProf& pf) {
-  using L = TrioLds<KR>;
+  using L = TrioLds<KR, P>;
   constexpr int RS = KR - 16;                  // members of the narrow second block (letkf_wave.hip STRIP): 4 or 0
   constexpr int NBLK = RS > 0 ? 2 : 1;
   constexpr int RSA = RS > 0 ? RS : 1;
@@ -344,7 +349,7 @@ __device__ __forceinline__ int trio_front(const PointArgs& A, const TrioHead& hd
   }
   int q = lane >> 4, c16 = lane & 15;
   asm volatile("" : "+v"(q), "+v"(c16));
-  constexpr int kSC = 256;
+  constexpr int kSC = L::kSC;
   double* stg = slice + L::work;
   bool rowok[NBLK];
   long mo[NBLK];
@@ -440,7 +445,7 @@ __device__ __forceinline__ int trio_front(const PointArgs& A, const TrioHead& hd
       rlv[ps] = 0.0;
       dv[ps] = 0.0;
       ddv[ps] = 0.0;
-      if (s0 == 0) {                                          // (the first batch was requested a slot ago)
+      if (s0 == 0) {                                          // (the first batch was requested a slot ago: trio_list<kSC>)
         iob[ps] = pl.iob[ps];
         rlv[ps] = pl.rlv[ps];
         rdv[ps] = pl.rdv[ps];
@@ -585,9 +590,9 @@ __device__ __forceinline__ int trio_front(const PointArgs& A, const TrioHead& hd
 
 // ---------------------------------------------------------------------------------------------
 // back: spectra, status, inflation, apply phase on the matrix cores (letkf_wave.hip MAPPLY), analysis members.
-template <int KR>
+template <int KR, int P>
 __device__ __forceinline__ int trio_back(const PointArgs& A, const long pt, const int sub, double* slice, const int k, TrioProf& pf) {
-  using L = TrioLds<KR>;
+  using L = TrioLds<KR, P>;
   constexpr int NV = 11, NB = NV + 2;
   constexpr int KS = (KR + 3) / 4, BR = 4 * KS;
   const int lane = threadIdx.x & 63;
@@ -797,11 +802,11 @@ __device__ __forceinline__ int trio_back(const PointArgs& A, const long pt, cons
   return __builtin_amdgcn_readfirstlane(st);
 }
 
-template <int KR>
+template <int KR, int P>
 __global__ void __launch_bounds__(256, 2) letkf_trio_kernel(const PointArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  using L = TrioLds<KR>;
-  constexpr int P = kTrioP, PPW = 4;
+  using L = TrioLds<KR, P>;
+  constexpr int PPW = 4;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int k = A.k;
@@ -814,7 +819,7 @@ __global__ void __launch_bounds__(256, 2) letkf_trio_kernel(const PointArgs A) {
   bool first_draw = true;
   TrioProf pf;
   for (;;) {
-    // a unit = plan.ub consecutive runs (three, or a multiple: launch_trio), taken three at a time and walked in step
+    // a unit = plan.ub consecutive runs (P, or a multiple: launch_trio), taken P at a time and walked in step
     const int slot0 = first_draw ? (int)(blockIdx.x >> 3) * PPW + wv : -1;
     const int code = sched_next(A.plan, A.sched, (int)(blockIdx.x & 7), slot0);
     first_draw = false;
@@ -841,7 +846,12 @@ __global__ void __launch_bounds__(256, 2) letkf_trio_kernel(const PointArgs A) {
       // the points of the group in front order: (level, run) = (ir0, 0), (ir0, 1), ..., (ir0 + 1, 0), ...
       auto point_at = [&](const int ir, const int sub) -> long {
         if (ir >= ir1) return -1;
-        const long ra = sub == 0 ? ras[0] : sub == 1 ? ras[1] : ras[2], rb = sub == 0 ? rbs[0] : sub == 1 ? rbs[1] : rbs[2];
+        long ra = ras[0], rb = rbs[0];           // (a chain of scalar selects: indexing the arrays by `sub` would put them in scratch)
+#pragma unroll
+        for (int p = 1; p < P; ++p) {
+          ra = sub == p ? ras[p] : ra;
+          rb = sub == p ? rbs[p] : rb;
+        }
         return ra + ir < nA ? (ra + ir) * S + rb : -1;
       };
       int ir_a = ir0, sub_a = 0;                 // the slot whose offsets are requested next
@@ -854,17 +864,17 @@ __global__ void __launch_bounds__(256, 2) letkf_trio_kernel(const PointArgs A) {
         return h;
       };
       TrioHead h0 = next_head(), h1 = next_head();
-      TrioList l0 = trio_list(A, h0);
+      TrioList l0 = trio_list<L::kSC>(A, h0);
       for (int ir = ir0; ir < ir1; ++ir) {
         unsigned valid = 0;
         // (one copy of the front and of the back in the code: the loops over the three points are not unrolled)
 #pragma unroll 1
         for (int sub = 0; sub < nsub; ++sub) {
-          const TrioList l1 = trio_list(A, h1);  // the next point's list, the offsets of the one after it
+          const TrioList l1 = trio_list<L::kSC>(A, h1);  // the next point's list, the offsets of the one after it
           const TrioHead h2 = next_head();
           asm volatile("" ::: "memory");
           if (h0.pt >= 0) {
-            const int r = trio_front<KR>(A, h0, l0, sub, slice, k, (warm >> sub) & 1u, pf);
+            const int r = trio_front<KR, P>(A, h0, l0, sub, slice, k, (warm >> sub) & 1u, pf);
             if (r == 2) valid |= 1u << sub;
             else if (r == 1) warm &= ~(1u << sub);
           }
@@ -875,12 +885,12 @@ __global__ void __launch_bounds__(256, 2) letkf_trio_kernel(const PointArgs A) {
         valid = __builtin_amdgcn_readfirstlane(valid);
         if (valid == 0) continue;
         pf.mark(0);
-        jacobi_trio<KR>(slice, k, valid, A.max_sweep);
+        jacobi_trio<KR, P>(slice, k, valid, A.max_sweep);
         pf.mark(3);
 #pragma unroll 1
         for (int sub = 0; sub < nsub; ++sub) {
           if ((valid >> sub) & 1u) {
-            const int st = trio_back<KR>(A, point_at(ir, sub), sub, slice, k, pf);
+            const int st = trio_back<KR, P>(A, point_at(ir, sub), sub, slice, k, pf);
             if (st == 0) warm |= 1u << sub;
             else warm &= ~(1u << sub);
           }
@@ -898,20 +908,20 @@ __global__ void __launch_bounds__(256, 2) letkf_trio_kernel(const PointArgs A) {
 #endif
 }
 
-template <int KR>
+template <int KR, int P>
 hipError_t launch_trio(const PointArgs& a, int num_cu, hipStream_t st) {
-  using L = TrioLds<KR>;
+  using L = TrioLds<KR, P>;
   const size_t lds = (size_t)4 * L::total * sizeof(double);
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_trio_kernel<KR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&letkf_trio_kernel<KR, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr = true;
   }
   static int occ = 0;
   if (occ == 0) {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, letkf_trio_kernel<KR>, 256, lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, letkf_trio_kernel<KR, P>, 256, lds);
     occ = (e == hipSuccess && nb > 0) ? nb : 2;
     (void)hipGetLastError();
   }
@@ -923,12 +933,12 @@ hipError_t launch_trio(const PointArgs& a, int num_cu, hipStream_t st) {
 #ifndef TRIO_UNITS_PER_WAVE
 #define TRIO_UNITS_PER_WAVE 2
 #endif
-  long rl_ = a.npts / (3 * TRIO_UNITS_PER_WAVE * res * 4);
+  long rl_ = a.npts / (P * TRIO_UNITS_PER_WAVE * res * 4);
   if (rl_ < TRIO_MIN_RUN) rl_ = TRIO_MIN_RUN;
   if (rl_ > a.run_len) rl_ = a.run_len;
   const long S = a.warm_stride > 1 ? a.warm_stride : 1, rl = rl_ > 1 ? rl_ : 1;
   const long nruns = S * ((a.npts / S + rl - 1) / rl);
-  const long nunits = (nruns + kTrioP - 1) / kTrioP;
+  const long nunits = (nruns + P - 1) / P;
   long grid_ = (nunits + 3) / 4;               // a wave-slot per unit, at most what is resident together
   if (grid_ > res) grid_ = res;
   const int grid = (int)(grid_ < 1 ? 1 : grid_);
@@ -937,18 +947,18 @@ hipError_t launch_trio(const PointArgs& a, int num_cu, hipStream_t st) {
   // shorter runs then (the first point of a run starts cold), down to 4 points, until there are two units per wave
   {
     const long slots = res * 4;
-    long want = a.npts / (3 * TRIO_UNITS_PER_WAVE * slots);
+    long want = a.npts / (P * TRIO_UNITS_PER_WAVE * slots);
     if (want < TRIO_MIN_RUN) want = TRIO_MIN_RUN;
     if (b.run_len > want) b.run_len = (int)want;
   }
-  sched_make_plan(b.plan, a.npts, a.warm_stride, b.run_len, grid, 4, 256, kTrioP);   // units of three runs
+  sched_make_plan(b.plan, a.npts, a.warm_stride, b.run_len, grid, 4, 256, P);   // units of P runs
   bool draws = false;
   for (int x = 0; x < 8; ++x) draws = draws || b.plan.whole[x] + 4 * b.plan.f[x] > b.plan.nstat[x];
   if (draws) {
     hipError_t e = hipMemsetAsync(a.sched, 0, 512, st);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((letkf_trio_kernel<KR>), dim3(grid), dim3(256), lds, st, b);
+  hipLaunchKernelGGL((letkf_trio_kernel<KR, P>), dim3(grid), dim3(256), lds, st, b);
   return hipGetLastError();
 }
 
@@ -961,8 +971,12 @@ bool trio_kernel_supports(const PointArgs& a) {
 }
 
 hipError_t launch_trio_kernel(const PointArgs& a, int num_cu, hipStream_t st) {
-  if (a.k <= 16) return launch_trio<16>(a, num_cu, st);
-  return launch_trio<20>(a, num_cu, st);
+  // (P = 5 for k <= 10 -- five segments of <= 5 slots on the line of 32, staging batches of 192 -- was measured, A/B in one call:
+  // C2's grid at MEMBER = 10 44.0 -> 43.5 ms, at MEMBER = 3 37.1 -> 38.7 ms: the group waits for the slowest of five, the parks
+  // crowd the staging area.  Three everywhere.)
+  if (a.k <= 16) return launch_trio<16, 3>(a, num_cu, st);
+  return launch_trio<20, 3>(a, num_cu, st);
 }
+int trio_points_per_wave(int) { return 3; }
 
 }  // namespace letkf
