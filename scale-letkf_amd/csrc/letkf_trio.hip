@@ -2,7 +2,7 @@
 //
 // The register kernel of letkf_wave.hip gives one wave to one point; its row-split Jacobi keeps one column PAIR per slot of two
 // lanes, so at k = 20 ten slots -- 20 of 64 lanes -- work through the eigensolve (43 % of the wave time on C2-k20, 35 % on C1)
-// and every lane computes the rotation of its pair anew.  Here a wave takes three consecutive points of its run:
+// and every lane computes the rotation of its pair anew.  Here a wave takes three points at a time (below: which three):
 //   front (per point)   the Gram on the matrix cores as in letkf_wave.hip (one 16 x 16 tile of the first 16 members; members
 //                       16 .. 19 by broadcast FMAs, the departure columns by plain FMAs), written as the symmetric matrix
 //                       A = Ys^T Ys + (k-1)/rho I -- with r = Ys^T d and r_det beside it -- into the point's PARK in LDS
